@@ -1,0 +1,39 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, 'gnss-ins-sim_amd')
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+for p in (PKG, REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden
+
+
+def ang_close(a, b, tol):
+    """Angles compared modulo 2*pi (a 1-ulp difference at the +-pi wrap must not count)."""
+    d = np.mod(np.asarray(a) - np.asarray(b) + np.pi, 2 * np.pi) - np.pi
+    return np.max(np.abs(d)) <= tol if d.size else True
+
+
+def assert_traj_close(att, pos, vel, g_att, g_pos, g_vel, rtol=1e-9, what=''):
+    """fp64 trajectory tolerance of SURVEY section 8(c): |d| <= rtol * max(1, |x|), angles mod 2*pi."""
+    assert ang_close(att, g_att, rtol * 4), what + ' att'
+    for name, x, g in (('pos', pos, g_pos), ('vel', vel, g_vel)):
+        err = np.abs(x - g) / np.maximum(1.0, np.abs(g))
+        assert np.max(err) <= rtol, '%s %s: %.3e' % (what, name, np.max(err))

@@ -1,0 +1,135 @@
+"""Pin the NumPy oracle (oracle/ins_np.py, oracle/philox.py) against golden vectors produced by
+EXECUTING the unmodified reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import ins_np, philox
+from conftest import load_golden, assert_traj_close, ang_close
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kat:
+        got = philox.philox4x32_10(*[np.uint64(x) for x in c], k[0], k[1])
+        assert tuple(int(x) for x in got) == want
+
+
+def test_normals_moments():
+    z0, z1 = philox.normal_pair(99, np.arange(8)[None, :], 3, np.arange(50000)[:, None])
+    for z in (z0, z1):
+        assert abs(z.mean()) < 4 / np.sqrt(z.size)
+        assert abs(z.std() - 1) < 4 / np.sqrt(2 * z.size)
+    assert abs(np.mean(z0 * z1)) < 4 / np.sqrt(z0.size)
+
+
+@pytest.mark.parametrize('name', ['bosch', 'nxp'])
+def test_t1_given_data_fixture(name):
+    g = load_golden('t1_fixture_' + name)
+    k = g['rows']
+    gyro, accel = g['gyro'][None], g['accel'][None]
+    for tag, rf, ini, erot in (('extg', 0, g['ini'], False), ('wgs', 0, g['ini'][:9], True),
+                               ('rf1', 1, g['ini'][:9], True)):
+        att, pos, vel = ins_np.free_integration(rf, float(g['fs']), gyro, accel, ini, earth_rot=erot)
+        assert_traj_close(att[0][k], pos[0][k], vel[0][k], g['att_' + tag], g['pos_' + tag],
+                          g['vel_' + tag], rtol=1e-11, what=name + tag)
+
+
+@pytest.mark.parametrize('rf', [0, 1])
+def test_t2_pathgen_and_noise_free_loop(rf):
+    g = load_golden('t2_turn_rf%d' % rf)
+    k = g['rows']
+    r = ins_np.path_gen(g['ini_pva'], g['motion_def'], float(g['fs']), float(g['fs_gps']),
+                        g['mobility'], rf, gps=True, odo=True)
+    assert r['imu'].shape[0] == int(g['n'])
+    np.testing.assert_allclose(r['imu'][:, 1:4], g['full_ref_accel'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r['imu'][:, 4:7], g['full_ref_gyro'], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(r['nav'][k, 1:4], g['ref_pos'], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(r['nav'][k, 4:7], g['ref_vel'], rtol=0, atol=1e-12)
+    assert ang_close(r['nav'][k, 7:10], g['ref_att'], 1e-13)
+    np.testing.assert_allclose(r['gps'][:, 1:7], g['ref_gps'], rtol=1e-14, atol=1e-12)
+    np.testing.assert_allclose(r['odo'][k, 2], g['ref_odo'], rtol=0, atol=1e-12)
+    ini = g['ini_pva']
+    gy, ac = r['imu'][None, :, 4:7], r['imu'][None, :, 1:4]
+    att, pos, vel = ins_np.free_integration(rf, 100.0, gy, ac, ini)
+    assert_traj_close(att[0][k], pos[0][k], vel[0][k], g['fi_att'], g['fi_pos'], g['fi_vel'],
+                      rtol=1e-11, what='fi')
+    att, pos, vel = ins_np.free_integration(rf, 100.0, gy, ac, ini, odo=r['odo'][None, :, 2])
+    assert_traj_close(att[0][k], pos[0][k], vel[0][k], g['odo_att'], g['odo_pos'], g['odo_vel'],
+                      rtol=1e-11, what='odo')
+
+
+def _errs(g):
+    acc = {k[6:]: g[k] for k in g if k.startswith('accel_') and k != 'accel'}
+    gyr = {k[5:]: g[k] for k in g if k.startswith('gyro_') and k != 'gyro'}
+    return acc, gyr
+
+
+@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0'])
+def test_t3_injected_noise_end_to_end(name):
+    g = load_golden(name)
+    R, k, fs, rf = int(g['R']), g['rows'], float(g['fs']), int(g['ref_frame'])
+    acc_err, gyr_err = _errs(g)
+    runs = np.arange(R)
+    accel, gyro = ins_np.mc_sensors(int(g['seed']), runs, fs, g['ref_accel'], g['ref_gyro'], acc_err, gyr_err)
+    np.testing.assert_allclose(accel[:, k], g['accel'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(gyro[:, k], g['gyro'], rtol=0, atol=1e-14)
+    odo = None
+    if 'odo' in g:
+        odo = ins_np.mc_odo(int(g['seed']), runs, g['ref_odo'],
+                            {'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])})
+        np.testing.assert_allclose(odo[:, k], g['odo'], rtol=0, atol=1e-12)
+    if 'gps' in g:
+        z = [philox.gps_normals(int(g['seed']), r, g['ref_gps'].shape[0]) for r in runs]
+        gps = ins_np.gps_errors(g['ref_gps'], {'stdp': g['gps_stdp'], 'stdv': g['gps_stdv']}, rf,
+                                np.stack([a for a, _ in z]), np.stack([b for _, b in z]))
+        np.testing.assert_allclose(gps, g['gps'], rtol=1e-14, atol=1e-12)
+    algos = [a for a in ('odo', 'fi') if a + '_att' in g]
+    order = sorted(algos, key=lambda a: 0)  # stats keys are algo0/algo1 in list order of the case
+    for a in algos:
+        att, pos, vel = ins_np.free_integration(rf, fs, gyro, accel, g['ini'], odo=odo if a == 'odo' else None)
+        assert_traj_close(att[:, k], pos[:, k], vel[:, k], g[a + '_att'], g[a + '_pos'], g[a + '_vel'],
+                          rtol=1e-10, what=name + a)
+        e = ins_np.end_point_errors(att, pos, vel, g['ref_att'], g['ref_pos'], g['ref_vel'])
+        st = ins_np.array_stats(e)
+        # which group is this algo? match by comparing to every stored group
+        groups = sorted({key.rsplit('_', 1)[1] for key in g if key.startswith('stat_att_euler_max_')})
+        r2d = 180.0 / np.pi
+        scale = {'att_euler': np.full(3, r2d), 'pos': np.array([r2d, r2d, 1.0]) if rf == 0 else np.ones(3),
+                 'vel': np.ones(3)}
+        ok = False
+        for grp in groups:
+            good = True
+            for dn, sl in (('att_euler', slice(0, 3)), ('pos', slice(3, 6)), ('vel', slice(6, 9))):
+                for s in ('max', 'avg', 'std'):
+                    want = g['stat_%s_%s_%s' % (dn, s, grp)]
+                    got = st[s][sl] * scale[dn]
+                    good &= bool(np.allclose(got, want, rtol=1e-7, atol=1e-12))
+            ok |= good
+        assert ok, 'end-point statistics of %s/%s match no reference group' % (name, a)
+
+
+def test_t2_long_drive_truth_rows():
+    """Full-length pathgen restatement is slow in Python (193k steps); run it only on request."""
+    import os
+    if not os.environ.get('GINSIM_SLOW'):
+        pytest.skip('set GINSIM_SLOW=1 (the C oracle covers this case in test_oracle_c.py)')
+    g = load_golden('t2_long_drive_rf0')
+    r = ins_np.path_gen(g['ini_pva'], g['motion_def'], float(g['fs']), float(g['fs_gps']), g['mobility'], 0,
+                        gps=True, odo=True)
+    assert r['imu'].shape[0] == int(g['n']) and r['gps'].shape[0] == int(g['m'])
+    np.testing.assert_allclose(r['imu'][g['rows']], g['imu'], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(r['nav'][g['rows'], 1:7], g['nav'][:, 1:7], rtol=1e-12, atol=1e-9)
+
+
+def test_allan_matches_reference():
+    g = load_golden('allan_ref')
+    n, fs, seed = int(g['n']), float(g['fs']), int(g['seed'])
+    j = np.arange(n, dtype=np.uint64)
+    x = 0.3 * philox.normal_pair(seed, 7, 5, j)[0] + 1e-3 * np.cumsum(philox.normal_pair(seed, 7, 4, j)[1])
+    avar, tau = ins_np.allan_var(x, fs)
+    np.testing.assert_allclose(tau, g['tau'], rtol=0, atol=0)
+    np.testing.assert_allclose(avar, g['avar'], rtol=1e-12)
