@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Build libginsim.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+    python gnss-ins-sim_amd/build.py [--force] [--verbose]
+
+hipcc cross-compiles without a GPU.  Objects go to gnss-ins-sim_amd/build/, the library to
+gnss-ins-sim_amd/lib/libginsim.so (git-ignored, but shipped to the GPU box by gpurun).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'build')
+LIB = os.path.join(HERE, 'lib', 'libginsim.so')
+ARCH = 'gfx950'
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+COMMON = ['-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(REPO, 'include'), '-I' + CSRC, '-Wall',
+          '-Wno-unused-function']
+# (source, extra flags)
+SOURCES = [
+    ('mc_kernel.hip', ['--offload-arch=' + ARCH]),
+    ('stats.hip', ['--offload-arch=' + ARCH]),
+    ('allan.hip', ['--offload-arch=' + ARCH]),
+    ('ginsim_api.hip', ['--offload-arch=' + ARCH]),
+    # host-only truth generator; no fused multiply-adds (see the file header)
+    ('pathgen.cpp', ['-x', 'c++', '-ffp-contract=off']),
+]
+
+
+def newer(a, b):
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.h'))]
+    deps.append(os.path.join(REPO, 'include', 'ginsim.h'))
+    deps.append(os.path.abspath(__file__))
+    objs = []
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        if not os.path.exists(s):
+            continue
+        o = os.path.join(OBJ, src.rsplit('.', 1)[0] + '.o')
+        objs.append(o)
+        if force or newer(s, o) or any(newer(d, o) for d in deps):
+            cmd = [HIPCC] + COMMON + extra + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.check_call(cmd)
+    if force or any(newer(o, LIB) for o in objs):
+        cmd = [HIPCC, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv))

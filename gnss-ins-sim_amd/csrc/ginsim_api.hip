@@ -1,0 +1,334 @@
+// C ABI of libginsim.so (declared in include/ginsim.h): context handling, argument validation, error
+// reporting and the host-buffer convenience entry points.  No kernels here.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ginsim.h"
+
+namespace ginsim {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream);
+hipError_t launch_rng_probe(uint64_t seed, uint64_t run, uint32_t stream, int64_t count, double* z0, double* z1,
+                            uint32_t* words, hipStream_t stream_h);
+hipError_t launch_aos_to_soa(const double* src, double* dst, int64_t R, int64_t n, int C, hipStream_t s);
+hipError_t launch_gather_runs(const double* series, int C, int64_t n, int64_t runs, const int64_t* ids, int nsel,
+                              double* out, hipStream_t s);
+size_t stats_scratch_bytes(int64_t runs);
+int stats_blocks(int64_t runs);
+hipError_t launch_end_stats(const double* end_err, int64_t runs, void* scratch, hipStream_t s);
+void stats_merge_host(const ginsim_stats* parts, int nparts, ginsim_stats* out);
+
+}  // namespace ginsim
+
+using namespace ginsim;
+
+struct ginsim_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+};
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return GINSIM_ERR_HIP;                                                            \
+        }                                                                                     \
+    } while (0)
+
+#define REQUIRE(cond, ...)            \
+    do {                              \
+        if (!(cond)) {                \
+            set_error(__VA_ARGS__);   \
+            return GINSIM_ERR_ARG;    \
+        }                             \
+    } while (0)
+
+// RAII device allocation for the host-buffer entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+extern "C" {
+
+int ginsim_abi_version(void) { return GINSIM_ABI_VERSION; }
+
+const char* ginsim_last_error(void) { return g_err.c_str(); }
+
+int ginsim_device_count(int* count) {
+    REQUIRE(count, "device_count: NULL output");
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return GINSIM_ERR_NODEV;
+    }
+    *count = n;
+    return GINSIM_OK;
+}
+
+int ginsim_create(int device, ginsim_ctx** out) {
+    REQUIRE(out, "create: NULL output");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+        set_error("no HIP device visible (the engine has no CPU fallback)");
+        return GINSIM_ERR_NODEV;
+    }
+    REQUIRE(device >= 0 && device < n, "create: device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    ginsim_ctx* c = new ginsim_ctx();
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    *out = c;
+    return GINSIM_OK;
+}
+
+int ginsim_destroy(ginsim_ctx* c) {
+    if (!c) return GINSIM_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GINSIM_OK;
+}
+
+int ginsim_device_name(ginsim_ctx* c, char* buf, size_t cap) {
+    REQUIRE(c && buf && cap > 0, "device_name: bad arguments");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    snprintf(buf, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return GINSIM_OK;
+}
+
+int ginsim_malloc(ginsim_ctx* c, size_t bytes, void** dptr) {
+    REQUIRE(c && dptr, "malloc: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 8));
+    return GINSIM_OK;
+}
+
+int ginsim_free(ginsim_ctx* c, void* dptr) {
+    REQUIRE(c, "free: NULL context");
+    if (!dptr) return GINSIM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(dptr));
+    return GINSIM_OK;
+}
+
+int ginsim_memcpy_h2d(ginsim_ctx* c, void* dst, const void* src, size_t bytes) {
+    REQUIRE(c && (bytes == 0 || (dst && src)), "memcpy_h2d: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_memcpy_d2h(ginsim_ctx* c, void* dst, const void* src, size_t bytes) {
+    REQUIRE(c && (bytes == 0 || (dst && src)), "memcpy_d2h: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_memset(ginsim_ctx* c, void* dptr, int value, size_t bytes) {
+    REQUIRE(c && (bytes == 0 || dptr), "memset: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(dptr, value, bytes, c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_sync(ginsim_ctx* c) {
+    REQUIRE(c, "sync: NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_timer_begin(ginsim_ctx* c) {
+    REQUIRE(c, "timer_begin: NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_timer_end(ginsim_ctx* c, float* ms) {
+    REQUIRE(c && ms, "timer_end: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return GINSIM_OK;
+}
+
+static int check_sensor(const ginsim_sensor_model& m, const char* what) {
+    for (int i = 0; i < 3; ++i) {
+        const double v[4] = {m.bias[i], m.gm_a[i], m.gm_b[i], m.white[i]};
+        for (double x : v) REQUIRE(x == x && x - x == 0.0, "mc_run: %s model has a non-finite coefficient", what);
+    }
+    return GINSIM_OK;
+}
+
+int ginsim_mc_run(ginsim_ctx* c, const ginsim_mc_params* p) {
+    REQUIRE(c && p, "mc_run: NULL argument");
+    REQUIRE(p->n >= 1 && p->runs >= 1, "mc_run: n=%lld runs=%lld must be >= 1", (long long)p->n, (long long)p->runs);
+    REQUIRE(p->n <= 0xFFFFFFFFll, "mc_run: n exceeds the 32-bit sample counter of the RNG");
+    REQUIRE(p->runs <= (int64_t)0x7FFFFFFF * 64, "mc_run: too many runs for one launch");
+    REQUIRE(p->fs > 0.0, "mc_run: fs must be positive");
+    REQUIRE(p->ref_frame == 0 || p->ref_frame == 1, "mc_run: ref_frame must be 0 or 1");
+    REQUIRE(p->algo_mask >= 1 && p->algo_mask <= 3, "mc_run: algo_mask must be a combination of GINSIM_ALGO_*");
+    REQUIRE(p->n_ini >= 1 && p->ini, "mc_run: initial-state table missing");
+    const bool odo = (p->algo_mask & GINSIM_ALGO_ODO) != 0, fre = (p->algo_mask & GINSIM_ALGO_FREE) != 0;
+    if (p->given_sensors) {
+        REQUIRE(p->in_gyro, "mc_run: given_sensors needs in_gyro");
+        REQUIRE(!fre || p->in_accel, "mc_run: given_sensors free integration needs in_accel");
+        REQUIRE(!odo || p->in_odo, "mc_run: given_sensors odometer integration needs in_odo");
+    } else {
+        REQUIRE(p->ref_gyro && p->ref_accel, "mc_run: ref_accel/ref_gyro missing");
+        REQUIRE((!odo && !p->out_odo) || p->ref_odo, "mc_run: ref_odo missing");
+        int rc = check_sensor(p->accel, "accel");
+        if (rc) return rc;
+        rc = check_sensor(p->gyro, "gyro");
+        if (rc) return rc;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_mc(*p, c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_end_stats(ginsim_ctx* c, const double* end_err, int64_t runs, ginsim_stats* host_out) {
+    REQUIRE(c && end_err && host_out && runs >= 1, "end_stats: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf scratch;
+    HIP_TRY(scratch.alloc(stats_scratch_bytes(runs)));
+    HIP_TRY(launch_end_stats(end_err, runs, scratch.p, c->stream));
+    const char* res = scratch.as<char>() + stats_scratch_bytes(runs) - sizeof(ginsim_stats);
+    HIP_TRY(hipMemcpyAsync(host_out, res, sizeof(ginsim_stats), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_stats_merge(const ginsim_stats* parts, int32_t nparts, ginsim_stats* out) {
+    REQUIRE(parts && out && nparts >= 1, "stats_merge: bad arguments");
+    stats_merge_host(parts, nparts, out);
+    return GINSIM_OK;
+}
+
+int ginsim_gather_runs(ginsim_ctx* c, const double* series, int32_t ncomp, int64_t n, int64_t runs,
+                       const int64_t* run_ids, int32_t nsel, double* host_out) {
+    REQUIRE(c && series && run_ids && host_out, "gather_runs: NULL argument");
+    REQUIRE(ncomp >= 1 && n >= 1 && runs >= 1 && nsel >= 1, "gather_runs: bad sizes");
+    for (int i = 0; i < nsel; ++i)
+        REQUIRE(run_ids[i] >= 0 && run_ids[i] < runs, "gather_runs: run id %lld out of range", (long long)run_ids[i]);
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf ids, out;
+    const size_t out_bytes = sizeof(double) * (size_t)nsel * n * ncomp;
+    HIP_TRY(ids.alloc(sizeof(int64_t) * nsel));
+    HIP_TRY(out.alloc(out_bytes));
+    HIP_TRY(hipMemcpyAsync(ids.p, run_ids, sizeof(int64_t) * nsel, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_gather_runs(series, ncomp, n, runs, ids.as<int64_t>(), nsel, out.as<double>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(host_out, out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_free_integration(ginsim_ctx* c, int32_t algo, int32_t ref_frame, double fs, int32_t earth_rot,
+                            const double* gyro, const double* accel, const double* odo, int64_t R, int64_t n,
+                            const double* ini, int32_t n_ini, int32_t ini_has_g, uint64_t ini_first, double* att,
+                            double* pos, double* vel) {
+    REQUIRE(c && gyro && ini && att && pos && vel, "free_integration: NULL argument");
+    REQUIRE(algo == GINSIM_ALGO_FREE || algo == GINSIM_ALGO_ODO, "free_integration: algo must be one GINSIM_ALGO_* bit");
+    REQUIRE(algo != GINSIM_ALGO_FREE || accel, "free_integration: accel missing");
+    REQUIRE(algo != GINSIM_ALGO_ODO || odo, "free_integration: odo missing");
+    REQUIRE(R >= 1 && n >= 1 && n_ini >= 1, "free_integration: bad sizes");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t plane = (size_t)R * n;
+    DevBuf d_aos, d_gyro, d_accel, d_odo, d_ini, d_traj;
+    HIP_TRY(d_aos.alloc(sizeof(double) * plane * 3));
+    HIP_TRY(d_gyro.alloc(sizeof(double) * plane * 3));
+    HIP_TRY(d_accel.alloc(sizeof(double) * plane * 3));
+    HIP_TRY(d_odo.alloc(sizeof(double) * plane));
+    HIP_TRY(d_ini.alloc(sizeof(double) * 10 * n_ini));
+    HIP_TRY(d_traj.alloc(sizeof(double) * plane * 9));
+    HIP_TRY(hipMemcpyAsync(d_ini.p, ini, sizeof(double) * 10 * n_ini, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_aos.p, gyro, sizeof(double) * plane * 3, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_aos_to_soa(d_aos.as<double>(), d_gyro.as<double>(), R, n, 3, c->stream));
+    if (algo == GINSIM_ALGO_FREE) {
+        HIP_TRY(hipMemcpyAsync(d_aos.p, accel, sizeof(double) * plane * 3, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_aos_to_soa(d_aos.as<double>(), d_accel.as<double>(), R, n, 3, c->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_aos.p, odo, sizeof(double) * plane, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_aos_to_soa(d_aos.as<double>(), d_odo.as<double>(), R, n, 1, c->stream));
+    }
+    ginsim_mc_params p;
+    memset(&p, 0, sizeof(p));
+    p.n = n; p.runs = R; p.fs = fs; p.ref_frame = ref_frame; p.algo_mask = algo; p.earth_rot = earth_rot;
+    p.n_ini = n_ini; p.ini_first = ini_first; p.ini_has_g = ini_has_g; p.given_sensors = 1;
+    p.ini = d_ini.as<double>();
+    p.in_gyro = d_gyro.as<double>(); p.in_accel = d_accel.as<double>(); p.in_odo = d_odo.as<double>();
+    p.out_traj[algo == GINSIM_ALGO_FREE ? 0 : 1] = d_traj.as<double>();
+    const int rc = ginsim_mc_run(c, &p);
+    if (rc) return rc;
+    // [9][n][R] -> three host arrays [R][n][3]
+    std::vector<int64_t> all(R);
+    for (int64_t i = 0; i < R; ++i) all[i] = i;
+    DevBuf d_ids, d_out;
+    HIP_TRY(d_ids.alloc(sizeof(int64_t) * R));
+    HIP_TRY(d_out.alloc(sizeof(double) * plane * 3));
+    HIP_TRY(hipMemcpyAsync(d_ids.p, all.data(), sizeof(int64_t) * R, hipMemcpyHostToDevice, c->stream));
+    double* host[3] = {att, pos, vel};
+    for (int k = 0; k < 3; ++k) {
+        HIP_TRY(launch_gather_runs(d_traj.as<double>() + (size_t)3 * k * plane, 3, n, R, d_ids.as<int64_t>(), (int)R,
+                                   d_out.as<double>(), c->stream));
+        HIP_TRY(hipMemcpyAsync(host[k], d_out.p, sizeof(double) * plane * 3, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return GINSIM_OK;
+}
+
+int ginsim_rng_normals(ginsim_ctx* c, uint64_t seed, uint64_t run, uint32_t stream, int64_t count, double* host_z0,
+                       double* host_z1, uint32_t* host_words) {
+    REQUIRE(c && host_z0 && host_z1 && count >= 1, "rng_normals: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf z0, z1, w;
+    HIP_TRY(z0.alloc(sizeof(double) * count));
+    HIP_TRY(z1.alloc(sizeof(double) * count));
+    HIP_TRY(w.alloc(sizeof(uint32_t) * 4 * count));
+    HIP_TRY(launch_rng_probe(seed, run, stream, count, z0.as<double>(), z1.as<double>(),
+                             host_words ? w.as<uint32_t>() : nullptr, c->stream));
+    HIP_TRY(hipMemcpyAsync(host_z0, z0.p, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(host_z1, z1.p, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    if (host_words)
+        HIP_TRY(hipMemcpyAsync(host_words, w.p, sizeof(uint32_t) * 4 * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// Strapdown building blocks of the MC kernels.
+//
+// Restates the ZYX subset of gnss_ins_sim/attitude/attitude.py and the WGS-84 model of
+// gnss_ins_sim/geoparams/geoparams.py as register-resident state: the attitude carries its own
+// sin/cos so that the three sincos evaluated for euler2dcm(att[i]) (attitude.py:344-371) are reused
+// by euler_update_zyx at step i+1 (attitude.py:679-721) -- 3 sincos per step instead of 7 trig calls.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace ginsim {
+
+#define GINSIM_HD __host__ __device__ __forceinline__
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kTwoPi = 2.0 * kPi;
+constexpr double kHalfPi = 0.5 * kPi;
+// geoparams.py:17-23, 40-43
+constexpr double kRe = 6378137.0;
+constexpr double kFlat = 1.0 / 298.257223563;
+constexpr double kEcc = 0.0818191908426215;
+constexpr double kEsq = kEcc * kEcc;
+constexpr double kWie = 7292115e-11;
+constexpr double kG0 = 9.7803253359;
+constexpr double kGk = 0.00193185265241;
+constexpr double kGm = 0.00344978650684;
+
+struct Vec3 { double x, y, z; };
+
+GINSIM_HD Vec3 cross3(const Vec3& a, const Vec3& b) {   // attitude.cross3, attitude.py:758-770
+    return Vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+struct Geo { double rm, rn, g, sl, cl; };
+
+// geoparams.geo_param, geoparams.py:25-53
+GINSIM_HD Geo geo_param(double lat, double h) {
+    Geo o;
+    sincos(lat, &o.sl, &o.cl);
+    const double s2 = o.sl * o.sl;
+    const double q = 1.0 - kEsq * s2;
+    const double w = sqrt(q);
+    o.rm = (kRe * (1.0 - kEsq)) / (w * q);
+    o.rn = kRe / w;
+    const double g1 = kG0 * (1.0 + kGk * s2) / w;
+    o.g = g1 * (1.0 - (2.0 / kRe) * (1.0 + kFlat + kGm - 2.0 * kFlat * s2) * h + 3.0 * h * h / kRe / kRe);
+    return o;
+}
+
+// geoparams.lla2ecef, geoparams.py:70-87
+GINSIM_HD Vec3 lla2ecef(double lat, double lon, double alt) {
+    const double sl = sin(lat), cl = cos(lat);
+    const double r = kRe / sqrt(1.0 - kEsq * sl * sl);
+    const double rho = (r + alt) * cl;
+    return Vec3{rho * cos(lon), rho * sin(lon), (r * (1.0 - kEsq) + alt) * sl};
+}
+
+// ZYX Euler attitude with cached trig.
+struct Att {
+    double yaw, pit, rol;
+    double sy, cy, sp, cp, sr, cr;
+
+    GINSIM_HD void set(double y, double p, double r) {
+        yaw = y; pit = p; rol = r;
+        sincos(y, &sy, &cy);
+        sincos(p, &sp, &cp);
+        sincos(r, &sr, &cr);
+    }
+    // attitude.euler2dcm(.,'zyx') rows, attitude.py:360-368 (n -> b)
+    GINSIM_HD Vec3 to_body(const Vec3& v) const {
+        return Vec3{cp * cy * v.x + cp * sy * v.y - sp * v.z,
+                    (sr * sp * cy - cr * sy) * v.x + (sr * sp * sy + cr * cy) * v.y + cp * sr * v.z,
+                    (sp * cr * cy + sy * sr) * v.x + (sp * cr * sy - cy * sr) * v.y + cp * cr * v.z};
+    }
+    GINSIM_HD Vec3 to_nav(const Vec3& v) const {   // transpose
+        return Vec3{cp * cy * v.x + (sr * sp * cy - cr * sy) * v.y + (sp * cr * cy + sy * sr) * v.z,
+                    cp * sy * v.x + (sr * sp * sy + cr * cy) * v.y + (sp * cr * sy - cy * sr) * v.z,
+                    -sp * v.x + cp * sr * v.y + cp * cr * v.z};
+    }
+    // third column of the n->b DCM: C . [0,0,1]
+    GINSIM_HD Vec3 down_in_body() const { return Vec3{-sp, cp * sr, cp * cr}; }
+    // first row of the n->b DCM: C^T . [1,0,0]
+    GINSIM_HD Vec3 fwd_in_nav() const { return Vec3{cp * cy, cp * sy, -sp}; }
+
+    // attitude.euler_update_zyx, attitude.py:679-721, then refresh the cached trig
+    GINSIM_HD void step(const Vec3& w, double dt) {
+        const double q = w.z * cr + w.y * sr;
+        const double icp = 1.0 / cp;
+        double y = yaw + q * icp * dt;
+        double p = pit + (w.y * cr - w.z * sr) * dt;
+        double r = rol + (w.x + q * (sp * icp)) * dt;
+        if (p > kHalfPi) {
+            p = kPi - p; y += kPi; r += kPi;
+        } else if (p < -kHalfPi) {
+            p = -kPi - p; y += kPi; r += kPi;
+        }
+        if (y > kPi) y -= kTwoPi; else if (y < -kPi) y += kTwoPi;
+        if (r > kPi) r -= kTwoPi; else if (r < -kPi) r += kTwoPi;
+        set(y, p, r);
+    }
+};
+
+// attitude.angle_range_pi, attitude.py:799-812 (Python float %: result carries the divisor's sign)
+GINSIM_HD double angle_range_pi(double x) {
+    double m = x - kTwoPi * floor(x / kTwoPi);
+    if (m >= kTwoPi) m -= kTwoPi;
+    if (m < 0.0) m += kTwoPi;
+    return m > kPi ? m - kTwoPi : m;
+}
+
+}  // namespace ginsim

@@ -1,0 +1,311 @@
+// Fused Monte-Carlo kernel: sensor-error injection + strapdown mechanisation + end-point error.
+//
+// One lane = one Monte-Carlo run; one 64-lane wavefront = one workgroup (no inter-lane traffic in the
+// time loop).  Per-run state (Euler attitude + cached trig, body/NED velocity, position, the six
+// Gauss-Markov bias states) lives in VGPRs for the whole time loop.  Truth samples are wave-uniform and
+// come in through the scalar cache.  Everything that leaves the lane is SoA [component][sample][run]
+// (run fastest) so that every store instruction of a wavefront writes 64 x 8 B contiguous bytes.
+//
+// Restates, per run:
+//   Sim.__gen_data_from_pathgen loop body      gnss_ins_sim/sim/ins_sim.py:490-506
+//   pathgen.acc_gen / gyro_gen / bias_drift    gnss_ins_sim/pathgen/pathgen.py:441-594
+//   pathgen.odo_gen                            gnss_ins_sim/pathgen/pathgen.py:627-641
+//   FreeIntegration.run                        demo_algorithms/free_integration.py:63-174
+//   FreeIntegration.run (odometer variant)     demo_algorithms/free_integration_odo.py:63-160
+//   array_error + end-point pick               gnss_ins_sim/sim/ins_data_manager.py:519-541, 737
+#include <hip/hip_runtime.h>
+#include "ginsim.h"
+#include "ins_math.hpp"
+#include "philox.hpp"
+
+namespace ginsim {
+
+constexpr int kWave = 64;
+
+// One strapdown solution (one algorithm instance of one run).
+struct Nav {
+    Att  att;
+    Vec3 vb;    // body velocity (ref_frame 1, free integration)
+    Vec3 vel;   // navigation-frame velocity of the previous sample
+    Vec3 pos;   // ECEF+displacement (ref_frame 1) or LLA (ref_frame 0)
+    double g;   // gravity: constant (ref_frame 1) or the external override of ref_frame 0
+    bool ext_g; // ref_frame 0: use g instead of the WGS-84 model (free_integration.py:143-146)
+};
+
+template <int RF>
+__device__ __forceinline__ void nav_init(Nav& s, const double* __restrict__ ini, int has_g) {
+    // free_integration.py:96-102 / :127-131
+    s.att.set(ini[6], ini[7], ini[8]);
+    s.vb = Vec3{ini[3], ini[4], ini[5]};
+    s.vel = s.att.to_nav(s.vb);
+    if (RF == 1) {
+        s.pos = lla2ecef(ini[0], ini[1], ini[2]);
+        s.g = has_g ? ini[9] : geo_param(ini[0], ini[2]).g;     // free_integration.py:89-93
+    } else {
+        s.pos = Vec3{ini[0], ini[1], ini[2]};
+        s.g = has_g ? ini[9] : 0.0;
+    }
+    s.ext_g = has_g != 0;
+}
+
+// One time step.  ODO == false: free_integration.py:104-116 (RF 1) / :134-172 (RF 0);
+//                 ODO == true : free_integration_odo.py:96-105 (RF 1) / :118-152 (RF 0).
+template <int RF, bool ODO>
+__device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& accel, double odo, double dt,
+                                         int earth_rot) {
+    if (RF == 1) {
+        const Vec3 v_prev = s.vel;
+        if (!ODO) {
+            const Vec3 gb = s.att.down_in_body();          // C(att[i-1]) . [0,0,g]
+            const Vec3 wxv = cross3(gyro, s.vb);
+            s.vb.x += (accel.x + gb.x * s.g) * dt - wxv.x * dt;
+            s.vb.y += (accel.y + gb.y * s.g) * dt - wxv.y * dt;
+            s.vb.z += (accel.z + gb.z * s.g) * dt - wxv.z * dt;
+        }
+        s.att.step(gyro, dt);
+        if (ODO) {
+            const Vec3 f = s.att.fwd_in_nav();
+            s.vel = Vec3{f.x * odo, f.y * odo, f.z * odo};
+        } else {
+            s.vel = s.att.to_nav(s.vb);
+        }
+        s.pos.x += v_prev.x * dt;
+        s.pos.y += v_prev.y * dt;
+        s.pos.z += v_prev.z * dt;
+    } else {
+        const Geo e = geo_param(s.pos.x, s.pos.z);
+        const double irm = 1.0 / (e.rm + s.pos.z);
+        const double irn = 1.0 / (e.rn + s.pos.z);
+        const double icl = 1.0 / e.cl;
+        const Vec3 v = s.vel;
+        const Vec3 w_en{v.y * irn, -v.x * irm, -v.y * e.sl * icl * irn};
+        Vec3 w_ie{0.0, 0.0, 0.0};
+        if (earth_rot) { w_ie.x = kWie * e.cl; w_ie.z = -kWie * e.sl; }
+        const Vec3 wb = s.att.to_body(Vec3{w_en.x + w_ie.x, w_en.y + w_ie.y, w_en.z + w_ie.z});
+        const Vec3 w_nb{gyro.x - wb.x, gyro.y - wb.y, gyro.z - wb.z};
+        Vec3 v_new;
+        if (!ODO) {
+            const Vec3 an = s.att.to_nav(accel);            // C(att[i-1])^T accel
+            const double g = s.ext_g ? s.g : e.g;
+            const Vec3 cor = cross3(Vec3{2.0 * w_ie.x + w_en.x, 2.0 * w_ie.y + w_en.y, 2.0 * w_ie.z + w_en.z}, v);
+            v_new = Vec3{v.x + (an.x - cor.x) * dt, v.y + (an.y - cor.y) * dt, v.z + (an.z + g - cor.z) * dt};
+        }
+        s.att.step(w_nb, dt);
+        if (ODO) {
+            const Vec3 f = s.att.fwd_in_nav();
+            v_new = Vec3{f.x * odo, f.y * odo, f.z * odo};
+        }
+        s.pos.x += v.x * irm * dt;
+        s.pos.y += v.y * irn * icl * dt;
+        s.pos.z += -v.z * dt;
+        s.vel = v_new;
+    }
+}
+
+__device__ __forceinline__ void store9(double* __restrict__ base, int64_t plane, int64_t off, const Nav& s) {
+    base[0 * plane + off] = s.att.yaw;
+    base[1 * plane + off] = s.att.pit;
+    base[2 * plane + off] = s.att.rol;
+    base[3 * plane + off] = s.pos.x;
+    base[4 * plane + off] = s.pos.y;
+    base[5 * plane + off] = s.pos.z;
+    base[6 * plane + off] = s.vel.x;
+    base[7 * plane + off] = s.vel.y;
+    base[8 * plane + off] = s.vel.z;
+}
+
+__device__ __forceinline__ void store3(double* __restrict__ base, int64_t plane, int64_t off, const Vec3& v) {
+    base[off] = v.x;
+    base[plane + off] = v.y;
+    base[2 * plane + off] = v.z;
+}
+
+__device__ __forceinline__ void store_end(double* __restrict__ out, int64_t runs, int64_t r, const Nav& s,
+                                          const double* ref_end) {
+    // array_error(angle=True) on the last sample: ins_data_manager.py:537-541
+    out[0 * runs + r] = angle_range_pi(s.att.yaw - ref_end[0]);
+    out[1 * runs + r] = angle_range_pi(s.att.pit - ref_end[1]);
+    out[2 * runs + r] = angle_range_pi(s.att.rol - ref_end[2]);
+    out[3 * runs + r] = s.pos.x - ref_end[3];
+    out[4 * runs + r] = s.pos.y - ref_end[4];
+    out[5 * runs + r] = s.pos.z - ref_end[5];
+    out[6 * runs + r] = s.vel.x - ref_end[6];
+    out[7 * runs + r] = s.vel.y - ref_end[7];
+    out[8 * runs + r] = s.vel.z - ref_end[8];
+}
+
+// Sensor sample j of one 3-axis sensor: truth + bias + drift + white  (pathgen.py:500, 562), and the
+// Gauss-Markov update d[j+1] = a d[j] + b N[j] (pathgen.py:589-590).
+__device__ __forceinline__ Vec3 sense3(const double* __restrict__ ref, int64_t j, const ginsim_sensor_model& m,
+                                       Vec3& drift, const Vec3& zd, const Vec3& zw) {
+    const double dx = m.white_drift[0] ? m.gm_b[0] * zd.x : drift.x;
+    const double dy = m.white_drift[1] ? m.gm_b[1] * zd.y : drift.y;
+    const double dz = m.white_drift[2] ? m.gm_b[2] * zd.z : drift.z;
+    Vec3 o;
+    o.x = ref[3 * j + 0] + m.bias[0] + dx + m.white[0] * zw.x;
+    o.y = ref[3 * j + 1] + m.bias[1] + dy + m.white[1] * zw.y;
+    o.z = ref[3 * j + 2] + m.bias[2] + dz + m.white[2] * zw.z;
+    drift.x = m.gm_a[0] * drift.x + m.gm_b[0] * zd.x;
+    drift.y = m.gm_a[1] * drift.y + m.gm_b[1] * zd.y;
+    drift.z = m.gm_a[2] * drift.z + m.gm_b[2] * zd.z;
+    return o;
+}
+
+template <int RF, int ALGOS, bool GIVEN>
+__global__ void __launch_bounds__(kWave) mc_kernel(const ginsim_mc_params a) {
+    const int64_t r = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    if (r >= a.runs) return;
+    constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
+    constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
+    const int64_t n = a.n;
+    const int64_t runs = a.runs;
+    const int64_t plane = n * runs;
+    const double dt = 1.0 / a.fs;
+
+    // which set of initial states: free_integration.py:85-87 (run_times counts calls since construction)
+    const uint64_t call = a.ini_first + (uint64_t)r;
+    const double* ini = a.ini + 10 * (call < (uint64_t)a.n_ini ? call : 0);
+    Nav fi, od;
+    if (FREE) nav_init<RF>(fi, ini, a.ini_has_g);
+    if (ODO) nav_init<RF>(od, ini, a.ini_has_g);
+
+    const uint64_t grun = a.run_offset + (uint64_t)r;
+    const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
+    Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
+
+    if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
+    if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
+
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t off = j * runs + r;
+        Vec3 acc, gyr;
+        double odo = 0.0;
+        if (GIVEN) {
+            if (j == n - 1) break;
+            gyr = Vec3{a.in_gyro[off], a.in_gyro[plane + off], a.in_gyro[2 * plane + off]};
+            if (FREE) acc = Vec3{a.in_accel[off], a.in_accel[plane + off], a.in_accel[2 * plane + off]};
+            if (ODO) odo = a.in_odo[off];
+        } else {
+            const bool last = (j == n - 1);
+            // the last sample only exists as sensor output; skip it when nothing stores it
+            if (last && !a.out_accel && !a.out_gyro && !a.out_odo) break;
+            const uint32_t jj = (uint32_t)j;
+            Vec3 zd, zw;
+            if (FREE || a.out_accel) {
+                normal_pair(key, S_ACC_D_XY, jj, zd.x, zd.y);
+                normal_pair(key, S_ACC_DZ_WX, jj, zd.z, zw.x);
+                normal_pair(key, S_ACC_W_YZ, jj, zw.y, zw.z);
+                acc = sense3(a.ref_accel, j, a.accel, da, zd, zw);
+                if (a.out_accel) store3(a.out_accel, plane, off, acc);
+            }
+            normal_pair(key, S_GYR_D_XY, jj, zd.x, zd.y);
+            normal_pair(key, S_GYR_DZ_WX, jj, zd.z, zw.x);
+            normal_pair(key, S_GYR_W_YZ, jj, zw.y, zw.z);
+            gyr = sense3(a.ref_gyro, j, a.gyro, dg, zd, zw);
+            if (a.out_gyro) store3(a.out_gyro, plane, off, gyr);
+            if (ODO || a.out_odo) {
+                double z0, z1;
+                normal_pair(key, S_ODO, jj, z0, z1);
+                odo = a.odo_scale * a.ref_odo[j] + a.odo_stdv * z0;     // pathgen.py:639-640
+                if (a.out_odo) a.out_odo[off] = odo;
+            }
+            if (last) break;
+        }
+        if (FREE) {
+            nav_step<RF, false>(fi, gyr, acc, 0.0, dt, a.earth_rot);
+            if (a.out_traj[0]) store9(a.out_traj[0], plane, off + runs, fi);
+        }
+        if (ODO) {
+            nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot);
+            if (a.out_traj[1]) store9(a.out_traj[1], plane, off + runs, od);
+        }
+    }
+    if (FREE && a.out_end[0]) store_end(a.out_end[0], runs, r, fi, a.ref_end);
+    if (ODO && a.out_end[1]) store_end(a.out_end[1], runs, r, od, a.ref_end);
+}
+
+template <int RF, int ALGOS>
+static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
+    const dim3 grid((unsigned)((p.runs + kWave - 1) / kWave)), block(kWave);
+    if (p.given_sensors)
+        hipLaunchKernelGGL((mc_kernel<RF, ALGOS, true>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+template <int RF>
+static hipError_t launch1(const ginsim_mc_params& p, hipStream_t stream) {
+    switch (p.algo_mask) {
+        case GINSIM_ALGO_FREE: return launch2<RF, GINSIM_ALGO_FREE>(p, stream);
+        case GINSIM_ALGO_ODO: return launch2<RF, GINSIM_ALGO_ODO>(p, stream);
+        default: return launch2<RF, GINSIM_ALGO_FREE | GINSIM_ALGO_ODO>(p, stream);
+    }
+}
+
+hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream) {
+    return p.ref_frame == 1 ? launch1<1>(p, stream) : launch1<0>(p, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RNG self-test: normals (and raw Philox words) of one (seed, run, stream), sample index = global lane.
+__global__ void rng_probe_kernel(uint64_t seed, uint64_t run, uint32_t stream, int64_t count,
+                                 double* __restrict__ z0, double* __restrict__ z1, uint32_t* __restrict__ words) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)run, (uint32_t)(run >> 32)};
+    double a, b;
+    normal_pair(key, stream, (uint32_t)j, a, b);
+    z0[j] = a;
+    z1[j] = b;
+    if (words) {
+        const u32x4 w = philox4x32_10((uint32_t)j, stream, key.r0, key.r1, key.k0, key.k1);
+        words[4 * j + 0] = w.x; words[4 * j + 1] = w.y; words[4 * j + 2] = w.z; words[4 * j + 3] = w.w;
+    }
+}
+
+hipError_t launch_rng_probe(uint64_t seed, uint64_t run, uint32_t stream, int64_t count, double* z0, double* z1,
+                            uint32_t* words, hipStream_t stream_h) {
+    const int tb = 256;
+    hipLaunchKernelGGL(rng_probe_kernel, dim3((unsigned)((count + tb - 1) / tb)), dim3(tb), 0, stream_h, seed, run,
+                       stream, count, z0, z1, words);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Layout helpers for the host-buffer boundary: [R][n][C] (reference per-run arrays) <-> [C][n][R].
+__global__ void aos_to_soa_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t R, int64_t n, int C) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over n*R, run fastest
+    if (idx >= n * R) return;
+    const int64_t r = idx % R, j = idx / R;
+    for (int c = 0; c < C; ++c) dst[(c * n + j) * R + r] = src[(r * n + j) * C + c];
+}
+
+// gather selected runs: series [C][n][runs] -> out [nsel][n][C]
+__global__ void gather_runs_kernel(const double* __restrict__ series, int C, int64_t n, int64_t runs,
+                                   const int64_t* __restrict__ ids, int nsel, double* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over nsel*n*C, component fastest
+    const int64_t total = (int64_t)nsel * n * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int64_t j = (idx / C) % n;
+    const int64_t k = idx / (C * n);
+    out[idx] = series[((int64_t)c * n + j) * runs + ids[k]];
+}
+
+hipError_t launch_aos_to_soa(const double* src, double* dst, int64_t R, int64_t n, int C, hipStream_t s) {
+    const int tb = 256;
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)((n * R + tb - 1) / tb)), dim3(tb), 0, s, src, dst, R, n, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_runs(const double* series, int C, int64_t n, int64_t runs, const int64_t* ids, int nsel,
+                              double* out, hipStream_t s) {
+    const int tb = 256;
+    const int64_t total = (int64_t)nsel * n * C;
+    hipLaunchKernelGGL(gather_runs_kernel, dim3((unsigned)((total + tb - 1) / tb)), dim3(tb), 0, s, series, C, n, runs,
+                       ids, nsel, out);
+    return hipGetLastError();
+}
+
+}  // namespace ginsim

@@ -1,0 +1,64 @@
+// Counter-based normal generator of the MC engine (device side).
+//
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11; Random123 constants) + Box-Muller in fp64.
+// It replaces the reference's serial global np.random.randn stream
+// (gnss_ins_sim/pathgen/pathgen.py:495,557,588,593,621-622,639,660): every (run, stream, sample)
+// triple owns its variates, so lanes never share RNG state and only variates that are consumed are
+// generated.  The stream definition is restated in oracle/philox.py and must stay in lock-step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ginsim {
+
+enum : uint32_t {
+    S_ACC_D_XY = 0, S_ACC_DZ_WX = 1, S_ACC_W_YZ = 2,
+    S_GYR_D_XY = 3, S_GYR_DZ_WX = 4, S_GYR_W_YZ = 5,
+    S_ODO = 6, S_MAG_XY = 7, S_MAG_Z = 8,
+    S_GPS_P_XY = 16, S_GPS_PZ_VX = 17, S_GPS_V_YZ = 18,
+};
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                        uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+// (0,1) uniform with 53 significant bits from two words: ((hi:lo >> 11) + 0.5) * 2^-53
+__host__ __device__ __forceinline__ double uniform53(uint32_t lo, uint32_t hi) {
+    const uint64_t v = (((uint64_t)hi << 32) | lo) >> 11;
+    return ((double)v + 0.5) * 0x1.0p-53;
+}
+
+struct RngKey {
+    uint32_t k0, k1;    // seed
+    uint32_t r0, r1;    // global run id
+};
+
+// Two standard normals for (key.run, stream, sample j).
+__device__ __forceinline__ void normal_pair(const RngKey& key, uint32_t stream, uint32_t j, double& z0, double& z1) {
+    const u32x4 w = philox4x32_10(j, stream, key.r0, key.r1, key.k0, key.k1);
+    const double u1 = uniform53(w.x, w.y);
+    const double u2 = uniform53(w.z, w.w);
+    const double r = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+}  // namespace ginsim

@@ -1,0 +1,126 @@
+"""ctypes binding of libginsim.so (the C ABI declared in include/ginsim.h).
+
+Same loading style as the reference's own FFI use (demo_algorithms/mag_calibrate.py:44,
+demo_algorithms/aceinna_ins.py:172-173): ``cdll.LoadLibrary`` + caller-allocated NumPy buffers passed
+as ``POINTER(c_double)``.  There is NO CPU fallback: if the library is missing, importing this module
+raises; if no GPU is visible, creating a context raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libginsim.so')
+
+ALGO_FREE = 1
+ALGO_ODO = 2
+
+OK, ERR_ARG, ERR_HIP, ERR_NODEV, ERR_RANGE = 0, -1, -2, -3, -4
+
+
+class GinsimError(RuntimeError):
+    """HIP / device failure inside libginsim."""
+
+
+class SensorModel(C.Structure):
+    _fields_ = [('bias', C.c_double * 3), ('gm_a', C.c_double * 3), ('gm_b', C.c_double * 3),
+                ('white', C.c_double * 3), ('white_drift', C.c_int32 * 3), ('reserved', C.c_int32)]
+
+
+class McParams(C.Structure):
+    _fields_ = [('n', C.c_int64), ('runs', C.c_int64), ('run_offset', C.c_uint64), ('seed', C.c_uint64),
+                ('fs', C.c_double), ('ref_frame', C.c_int32), ('algo_mask', C.c_int32),
+                ('earth_rot', C.c_int32), ('n_ini', C.c_int32), ('ini_first', C.c_uint64),
+                ('ini_has_g', C.c_int32), ('given_sensors', C.c_int32),
+                ('accel', SensorModel), ('gyro', SensorModel),
+                ('odo_scale', C.c_double), ('odo_stdv', C.c_double), ('ref_end', C.c_double * 9),
+                ('ini', C.c_void_p), ('ref_accel', C.c_void_p), ('ref_gyro', C.c_void_p), ('ref_odo', C.c_void_p),
+                ('in_accel', C.c_void_p), ('in_gyro', C.c_void_p), ('in_odo', C.c_void_p),
+                ('out_accel', C.c_void_p), ('out_gyro', C.c_void_p), ('out_odo', C.c_void_p),
+                ('out_traj', C.c_void_p * 2), ('out_end', C.c_void_p * 2)]
+
+
+class PathgenParams(C.Structure):
+    _fields_ = [('ini_pva', C.c_double * 9), ('mobility', C.c_double * 3), ('fs', C.c_double),
+                ('fs_gps', C.c_double), ('ref_frame', C.c_int32), ('enable_gps', C.c_int32),
+                ('n_seg', C.c_int32), ('reserved', C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [('count', C.c_double), ('mean', C.c_double * 9), ('m2', C.c_double * 9),
+                ('maxabs', C.c_double * 9)]
+
+
+_PD = C.POINTER(C.c_double)
+_SIGS = {
+    'ginsim_abi_version': (C.c_int, []),
+    'ginsim_last_error': (C.c_char_p, []),
+    'ginsim_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'ginsim_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    'ginsim_destroy': (C.c_int, [C.c_void_p]),
+    'ginsim_device_name': (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    'ginsim_malloc': (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    'ginsim_free': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'ginsim_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    'ginsim_memcpy_d2h': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    'ginsim_memset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    'ginsim_sync': (C.c_int, [C.c_void_p]),
+    'ginsim_timer_begin': (C.c_int, [C.c_void_p]),
+    'ginsim_timer_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    'ginsim_pathgen_capacity': (C.c_int, [C.POINTER(PathgenParams), _PD, C.POINTER(C.c_int64)]),
+    'ginsim_pathgen': (C.c_int, [C.POINTER(PathgenParams), _PD, C.c_int64, _PD, _PD, _PD, _PD,
+                                 C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'ginsim_mc_run': (C.c_int, [C.c_void_p, C.POINTER(McParams)]),
+    'ginsim_end_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Stats)]),
+    'ginsim_stats_merge': (C.c_int, [C.POINTER(Stats), C.c_int32, C.POINTER(Stats)]),
+    'ginsim_gather_runs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
+                                     C.POINTER(C.c_int64), C.c_int32, _PD]),
+    'ginsim_free_integration': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, _PD, _PD, _PD,
+                                          C.c_int64, C.c_int64, _PD, C.c_int32, C.c_int32, C.c_uint64,
+                                          _PD, _PD, _PD]),
+    'ginsim_rng_normals': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, _PD, _PD,
+                                     C.POINTER(C.c_uint32)]),
+}
+# entry points added by later ABI revisions are optional here and bound when present
+_OPTIONAL = {
+    'ginsim_allan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, _PD, _PD,
+                               C.POINTER(C.c_int32), C.c_int32]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('libginsim.so not built: run `python gnss-ins-sim_amd/build.py` '
+                          '(or __graft_entry__.build()); expected %s' % LIB_PATH)
+    lib = C.cdll.LoadLibrary(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    for name, (res, args) in _OPTIONAL.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+EXPORTS = tuple(_SIGS)
+
+
+def check(rc):
+    """Translate a status code into the exception type the reference raises for the same mistake."""
+    if rc == OK:
+        return
+    msg = lib.ginsim_last_error().decode('utf-8', 'replace')
+    if rc in (ERR_ARG, ERR_RANGE):
+        raise ValueError(msg)
+    raise GinsimError(msg)
+
+
+def dptr(a):
+    """POINTER(c_double) of a C-contiguous float64 array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(_PD)

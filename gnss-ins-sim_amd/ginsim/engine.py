@@ -1,0 +1,344 @@
+"""Host-side driver objects over the C ABI: device context/buffers, truth generation, and one
+Monte-Carlo batch (``MonteCarloJob``) = one launch of the fused HIP kernel on one GPU.
+
+Nothing here computes on the CPU: every number a job returns was produced by libginsim on the device
+(pathgen excepted, which is native host code inside the same library and runs once per Sim.run).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, dptr, ALGO_FREE, ALGO_ODO
+
+ALGO_BITS = {'free': ALGO_FREE, 'odo': ALGO_ODO}
+ALGO_SLOT = {'free': 0, 'odo': 1}
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib.ginsim_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class DeviceBuffer(object):
+    """A hipMalloc'ed region owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        check(lib.ginsim_malloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def at(self, byte_offset):
+        return self.ptr + int(byte_offset)
+
+    def free(self):
+        if self.ptr and self.ctx.handle:
+            lib.ginsim_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context(object):
+    """One GPU (one HIP stream).  Raises GinsimError when no GPU is visible -- there is no CPU path."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        self.handle = None
+        check(lib.ginsim_create(int(device), C.byref(h)))
+        self.handle = h.value
+        self.device = int(device)
+
+    def name(self):
+        buf = C.create_string_buffer(256)
+        check(lib.ginsim_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def malloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array)
+        buf = DeviceBuffer(self, max(a.nbytes, 8))
+        check(lib.ginsim_memcpy_h2d(self.handle, buf.ptr, a.ctypes.data, a.nbytes))
+        return buf
+
+    def download(self, buf_or_ptr, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype)
+        ptr = buf_or_ptr.ptr if isinstance(buf_or_ptr, DeviceBuffer) else buf_or_ptr
+        check(lib.ginsim_memcpy_d2h(self.handle, out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    def sync(self):
+        check(lib.ginsim_sync(self.handle))
+
+    def timer_begin(self):
+        check(lib.ginsim_timer_begin(self.handle))
+
+    def timer_end(self):
+        ms = C.c_float(0)
+        check(lib.ginsim_timer_end(self.handle, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.handle:
+            lib.ginsim_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------------------- truth
+def pathgen(ini_pva, motion_def, fs, fs_gps=0.0, mobility=(1.0, 0.5, 2.0), ref_frame=0, gps=False):
+    """pathgen.path_gen through the C ABI.  motion_def is (S,9) with angles in rad, unmodified.
+    Returns {'imu': (n,7), 'nav': (n,10), 'odo': (n,5)[, 'gps': (m,8)]}."""
+    md = np.ascontiguousarray(np.atleast_2d(np.asarray(motion_def, dtype=np.float64)))
+    if md.shape[1] < 9:
+        raise ValueError('motion definition must have nine columns')
+    md = np.ascontiguousarray(md[:, :9])
+    p = _lib.PathgenParams()
+    p.ini_pva[:] = [float(x) for x in np.asarray(ini_pva, dtype=np.float64)[:9]]
+    p.mobility[:] = [float(x) for x in mobility]
+    p.fs, p.fs_gps = float(fs), float(fs_gps)
+    p.ref_frame, p.enable_gps, p.n_seg = int(ref_frame), int(bool(gps)), md.shape[0]
+    cap = C.c_int64(0)
+    check(lib.ginsim_pathgen_capacity(C.byref(p), dptr(md), C.byref(cap)))
+    cap = cap.value
+    imu = np.zeros((cap, 7))
+    nav = np.zeros((cap, 10))
+    odo = np.zeros((cap, 5))
+    gpsb = np.zeros((cap, 8)) if gps else None
+    n, m = C.c_int64(0), C.c_int64(0)
+    check(lib.ginsim_pathgen(C.byref(p), dptr(md), cap, dptr(imu), dptr(nav), dptr(gpsb), dptr(odo),
+                             C.byref(n), C.byref(m)))
+    out = {'imu': imu[:n.value], 'nav': nav[:n.value], 'odo': odo[:n.value]}
+    if gps:
+        out['gps'] = gpsb[:m.value]
+    return out
+
+
+# --------------------------------------------------------------------------------------- sensor models
+def sensor_model(err, rw_key, fs):
+    """Coefficients of pathgen.bias_drift / acc_gen / gyro_gen (pathgen.py:583-593, 496, 558) from an
+    imu_model error dict ('b', 'b_drift', 'b_corr', rw_key)."""
+    m = _lib.SensorModel()
+    b = np.asarray(err['b'], dtype=np.float64) * np.ones(3)
+    drift = np.asarray(err['b_drift'], dtype=np.float64) * np.ones(3)
+    corr = np.asarray(err['b_corr'], dtype=np.float64) * np.ones(3)
+    rw = np.asarray(err[rw_key], dtype=np.float64) * np.ones(3)
+    dt = 1.0 / fs
+    for i in range(3):
+        m.bias[i] = b[i]
+        m.white[i] = rw[i] / math.sqrt(dt)
+        if math.isinf(corr[i]):
+            m.gm_a[i], m.gm_b[i], m.white_drift[i] = 0.0, drift[i], 1
+        else:
+            m.gm_a[i] = 1 - 1 / fs / corr[i]
+            m.gm_b[i] = drift[i] * math.sqrt(1.0 - math.exp(-2 / (fs * corr[i])))
+            m.white_drift[i] = 0
+    return m
+
+
+def ini_table(ini):
+    """(9|10,) or (9|10,k) initial states (free_integration.py:47-61) -> ((k,10) table, has_g)."""
+    a = np.asarray(ini, dtype=np.float64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
+    elif a.ndim != 2:
+        raise ValueError('Initial states should be a 1D or 2D numpy array, but the dimension is %s.' % a.ndim)
+    if a.shape[0] < 9:
+        raise ValueError('initial states need at least 9 elements')
+    has_g = a.shape[0] > 9
+    t = np.zeros((a.shape[1], 10))
+    t[:, :min(a.shape[0], 10)] = a[:10].T
+    return t, has_g
+
+
+class StatsResult(object):
+    """count / mean / M2 / max|e| of the 9 end-point error components (att3, pos3, vel3)."""
+
+    def __init__(self, s):
+        self.count = float(s.count)
+        self.mean = np.array(s.mean[:])
+        self.m2 = np.array(s.m2[:])
+        self.maxabs = np.array(s.maxabs[:])
+
+    @property
+    def std(self):      # np.std(ddof=0), ins_data_manager.py:808
+        return np.sqrt(self.m2 / self.count)
+
+    def pack(self):
+        return np.concatenate([[self.count], self.mean, self.m2, self.maxabs])
+
+    @staticmethod
+    def unpack(v):
+        s = _lib.Stats()
+        s.count = v[0]
+        s.mean[:] = list(v[1:10])
+        s.m2[:] = list(v[10:19])
+        s.maxabs[:] = list(v[19:28])
+        return s
+
+    @staticmethod
+    def merge(packed_rows):
+        """Merge packed partials (one row per device) with the library's Chan merge."""
+        rows = [r for r in packed_rows if r[0] > 0]
+        arr = (_lib.Stats * len(rows))(*[StatsResult.unpack(r) for r in rows])
+        out = _lib.Stats()
+        check(lib.ginsim_stats_merge(arr, len(rows), C.byref(out)))
+        return StatsResult(out)
+
+
+class MonteCarloJob(object):
+    """One batch of MC runs on one device: fused noise injection + mechanisation + end-point error.
+
+    truth: dict with 'ref_accel' (n,3), 'ref_gyro' (n,3), 'ref_att'/'ref_pos'/'ref_vel' (n,3) and, for
+    the odometer algorithm, 'ref_odo' (n,).  algos: subset of ('free', 'odo').
+    """
+
+    def __init__(self, ctx, fs, ref_frame, truth, accel_err, gyro_err, ini, runs, algos=('free',),
+                 odo_err=None, earth_rot=True, seed=0, run_offset=0, ini_first=0,
+                 keep_sensors=False, keep_traj=False):
+        self.ctx = ctx
+        self.algos = tuple(algos)
+        for a in self.algos:
+            if a not in ALGO_BITS:
+                raise ValueError('unknown algorithm %r' % (a,))
+        self.n = int(truth['ref_accel'].shape[0])
+        self.runs = int(runs)
+        self.keep_sensors, self.keep_traj = bool(keep_sensors), bool(keep_traj)
+        self.want_odo = 'odo' in self.algos
+        p = self.params = _lib.McParams()
+        p.n, p.runs, p.run_offset, p.seed = self.n, self.runs, int(run_offset), int(seed) & (2 ** 64 - 1)
+        p.fs, p.ref_frame = float(fs), int(ref_frame)
+        p.algo_mask = sum(ALGO_BITS[a] for a in self.algos)
+        p.earth_rot = int(bool(earth_rot))
+        table, has_g = ini_table(ini)
+        p.n_ini, p.ini_first, p.ini_has_g, p.given_sensors = table.shape[0], int(ini_first), int(has_g), 0
+        p.accel = sensor_model(accel_err, 'vrw', fs)
+        p.gyro = sensor_model(gyro_err, 'arw', fs)
+        if self.want_odo:
+            if odo_err is None or 'ref_odo' not in truth:
+                raise ValueError('the odometer algorithm needs odo_err and truth["ref_odo"]')
+            p.odo_scale, p.odo_stdv = float(odo_err['scale']), float(odo_err['stdv'])
+        end = np.concatenate([truth['ref_att'][-1], truth['ref_pos'][-1], truth['ref_vel'][-1]])
+        p.ref_end[:] = [float(x) for x in end]
+        # device-resident inputs
+        self._bufs = {}
+        self._bufs['ini'] = ctx.upload(table)
+        self._bufs['ref_accel'] = ctx.upload(np.asarray(truth['ref_accel'], dtype=np.float64))
+        self._bufs['ref_gyro'] = ctx.upload(np.asarray(truth['ref_gyro'], dtype=np.float64))
+        p.ini, p.ref_accel, p.ref_gyro = self._bufs['ini'].ptr, self._bufs['ref_accel'].ptr, self._bufs['ref_gyro'].ptr
+        if self.want_odo:
+            self._bufs['ref_odo'] = ctx.upload(np.asarray(truth['ref_odo'], dtype=np.float64))
+            p.ref_odo = self._bufs['ref_odo'].ptr
+        # outputs
+        plane = self.n * self.runs * 8
+        if self.keep_sensors:
+            self._bufs['accel'] = ctx.malloc(3 * plane)
+            self._bufs['gyro'] = ctx.malloc(3 * plane)
+            p.out_accel, p.out_gyro = self._bufs['accel'].ptr, self._bufs['gyro'].ptr
+            if self.want_odo:
+                self._bufs['odo'] = ctx.malloc(plane)
+                p.out_odo = self._bufs['odo'].ptr
+        for a in self.algos:
+            s = ALGO_SLOT[a]
+            self._bufs['end_' + a] = ctx.malloc(9 * self.runs * 8)
+            p.out_end[s] = self._bufs['end_' + a].ptr
+            if self.keep_traj:
+                self._bufs['traj_' + a] = ctx.malloc(9 * plane)
+                p.out_traj[s] = self._bufs['traj_' + a].ptr
+
+    # bytes the launch writes to HBM (the algorithmic traffic of SURVEY 8(d))
+    def bytes_written(self):
+        per_sample = 0
+        if self.keep_sensors:
+            per_sample += 48 + (8 if self.want_odo else 0)
+        if self.keep_traj:
+            per_sample += 72 * len(self.algos)
+        return per_sample * self.n * self.runs + 72 * self.runs * len(self.algos)
+
+    def launch(self):
+        """Enqueue the fused kernel on the context's stream (asynchronous)."""
+        check(lib.ginsim_mc_run(self.ctx.handle, C.byref(self.params)))
+
+    def run(self):
+        self.launch()
+        self.ctx.sync()
+        return self
+
+    def stats(self, algo):
+        s = _lib.Stats()
+        check(lib.ginsim_end_stats(self.ctx.handle, self._bufs['end_' + algo].ptr, self.runs, C.byref(s)))
+        return StatsResult(s)
+
+    def end_errors(self, algo):
+        """(runs, 9) end-point errors [att3 wrapped, pos3, vel3]."""
+        return self.ctx.download(self._bufs['end_' + algo], (9, self.runs)).T.copy()
+
+    def _gather(self, ptr, ncomp, run_ids):
+        ids = np.ascontiguousarray(np.asarray(run_ids, dtype=np.int64).reshape(-1))
+        out = np.empty((ids.size, self.n, ncomp))
+        check(lib.ginsim_gather_runs(self.ctx.handle, ptr, ncomp, self.n, self.runs,
+                                     ids.ctypes.data_as(C.POINTER(C.c_int64)), ids.size, dptr(out)))
+        return out
+
+    def sensors(self, name, run_ids):
+        """Sensor series of selected runs: 'accel'/'gyro' -> (k,n,3); 'odo' -> (k,n)."""
+        if not self.keep_sensors:
+            raise ValueError('sensor series were not kept (keep_sensors=False)')
+        if name == 'odo':
+            return self._gather(self._bufs['odo'].ptr, 1, run_ids)[:, :, 0]
+        return self._gather(self._bufs[name].ptr, 3, run_ids)
+
+    def trajectories(self, algo, run_ids):
+        """(att, pos, vel) of selected runs, each (k,n,3)."""
+        if not self.keep_traj:
+            raise ValueError('trajectories were not kept (keep_traj=False)')
+        base = self._bufs['traj_' + algo].ptr
+        plane = self.n * self.runs * 8
+        return tuple(self._gather(base + 3 * k * plane, 3, run_ids) for k in range(3))
+
+    def release(self):
+        for b in self._bufs.values():
+            b.free()
+        self._bufs = {}
+
+
+def free_integration_host(ctx, algo, ref_frame, fs, gyro, accel=None, odo=None, ini=None, earth_rot=True,
+                          ini_first=0):
+    """Given-data mechanisation through ginsim_free_integration (host buffers in, host buffers out).
+    gyro/accel (R,n,3) or (n,3); odo (R,n) or (n,).  Returns att, pos, vel with gyro's leading shape."""
+    g = np.asarray(gyro, dtype=np.float64)
+    single = g.ndim == 2
+    g = np.ascontiguousarray(g.reshape((-1,) + g.shape[-2:]))
+    R, n, _ = g.shape
+    a = None if accel is None else np.ascontiguousarray(np.asarray(accel, dtype=np.float64).reshape(R, n, 3))
+    o = None if odo is None else np.ascontiguousarray(np.asarray(odo, dtype=np.float64).reshape(R, n))
+    table, has_g = ini_table(ini)
+    att, pos, vel = np.empty((R, n, 3)), np.empty((R, n, 3)), np.empty((R, n, 3))
+    check(lib.ginsim_free_integration(ctx.handle, ALGO_BITS[algo], int(ref_frame), float(fs), int(bool(earth_rot)),
+                                      dptr(g), dptr(a), dptr(o), R, n, dptr(table), table.shape[0], int(has_g),
+                                      int(ini_first), dptr(att), dptr(pos), dptr(vel)))
+    if single:
+        return att[0], pos[0], vel[0]
+    return att, pos, vel
+
+
+def rng_normals(ctx, seed, run, stream, count, words=False):
+    z0, z1 = np.empty(count), np.empty(count)
+    w = np.empty((count, 4), dtype=np.uint32) if words else None
+    check(lib.ginsim_rng_normals(ctx.handle, int(seed), int(run), int(stream), int(count), dptr(z0), dptr(z1),
+                                 None if w is None else w.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return (z0, z1, w) if words else (z0, z1)

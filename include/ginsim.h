@@ -1,0 +1,148 @@
+/*
+ * ginsim.h -- C ABI of the MI355X-native Monte-Carlo strapdown-INS engine (libginsim.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Aceinna/gnss-ins-sim:
+ *     pathgen.path_gen  ->  acc_gen / gyro_gen / bias_drift  ->  FreeIntegration.run  ->  end-point stats
+ * Style mirrors the reference's own FFI precedent (demo_algorithms/mag_calibrate.py:44,78-86 and
+ * demo_algorithms/aceinna_ins.py:172-237): extern "C" functions, POD structs by pointer, caller-owned
+ * row-major double buffers, explicit sizes.  Unlike the precedent every function returns an int status
+ * (0 = ok, <0 = error) and never aborts; ginsim_last_error() returns the thread-local message.
+ *
+ * All reference citations are relative to the reference repository root.
+ */
+#ifndef GINSIM_H
+#define GINSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GINSIM_ABI_VERSION 1
+
+/* status codes */
+#define GINSIM_OK          0
+#define GINSIM_ERR_ARG    -1   /* bad argument (Python wrapper raises ValueError, like the reference) */
+#define GINSIM_ERR_HIP    -2   /* HIP runtime error (message holds hipGetErrorString) */
+#define GINSIM_ERR_NODEV  -3   /* no usable GPU */
+#define GINSIM_ERR_RANGE  -4   /* output capacity too small */
+
+typedef struct ginsim_ctx ginsim_ctx;   /* one context per device; re-entrant per context */
+
+/* ---- context / plumbing -------------------------------------------------------------------- */
+int         ginsim_abi_version(void);
+const char* ginsim_last_error(void);
+int  ginsim_device_count(int* count);
+int  ginsim_create(int device, ginsim_ctx** out);
+int  ginsim_destroy(ginsim_ctx* ctx);
+int  ginsim_device_name(ginsim_ctx* ctx, char* buf, size_t cap);
+int  ginsim_malloc(ginsim_ctx* ctx, size_t bytes, void** dptr);
+int  ginsim_free(ginsim_ctx* ctx, void* dptr);
+int  ginsim_memcpy_h2d(ginsim_ctx* ctx, void* dst, const void* src, size_t bytes);
+int  ginsim_memcpy_d2h(ginsim_ctx* ctx, void* dst, const void* src, size_t bytes);
+int  ginsim_memset(ginsim_ctx* ctx, void* dptr, int value, size_t bytes);
+int  ginsim_sync(ginsim_ctx* ctx);
+/* HIP-event timer on the context's stream (the stream every kernel of this context is launched on). */
+int  ginsim_timer_begin(ginsim_ctx* ctx);
+int  ginsim_timer_end(ginsim_ctx* ctx, float* elapsed_ms);
+
+/* ---- truth: pathgen.path_gen (gnss_ins_sim/pathgen/pathgen.py:26-329, osr == 1) ------------- */
+typedef struct {
+    double  ini_pva[9];     /* lat, lon [rad], alt [m], body vel [m/s], yaw pitch roll [rad]  (ins_sim.py:597-610) */
+    double  mobility[3];    /* max accel, max angular accel [rad/s^2], max angular rate [rad/s] (ins_sim.py:25) */
+    double  fs;             /* IMU / simulation rate [Hz] */
+    double  fs_gps;         /* GPS rate [Hz] (used when enable_gps) */
+    int32_t ref_frame;      /* 0 NED/LLA, 1 virtual inertial frame */
+    int32_t enable_gps;
+    int32_t n_seg;          /* rows of motion_def */
+    int32_t reserved;
+} ginsim_pathgen_params;
+
+/* Upper bound of the IMU sample count: sum of ceil(duration*fs) (pathgen.py:116-127). */
+int ginsim_pathgen_capacity(const ginsim_pathgen_params* p, const double* motion_def /*[n_seg][9]*/, int64_t* cap);
+/* Host buffers, row-major: imu [cap][7] = idx,acc3,gyro3; nav [cap][10] = idx,pos3,velNED3,euler3;
+ * gps [cap][8] = idx,pos3,vel3,visibility (may be NULL); odo [cap][5] = idx,dist,vel_b3 (may be NULL).
+ * motion_def is not modified (the reference overwrites column 7, pathgen.py:122). */
+int ginsim_pathgen(const ginsim_pathgen_params* p, const double* motion_def, int64_t cap,
+                   double* imu, double* nav, double* gps, double* odo, int64_t* n_out, int64_t* m_out);
+
+/* ---- Monte-Carlo fused kernel: noise injection + mechanisation + end-point error ------------- */
+#define GINSIM_ALGO_FREE 1   /* demo_algorithms/free_integration.py:63-174      */
+#define GINSIM_ALGO_ODO  2   /* demo_algorithms/free_integration_odo.py:63-160  */
+
+typedef struct {            /* one 3-axis sensor: pathgen.acc_gen / gyro_gen / bias_drift (pathgen.py:441-594) */
+    double  bias[3];        /* err['b'] */
+    double  gm_a[3];        /* 1 - 1/(fs*tau)                        (pathgen.py:583); 0 when tau is inf */
+    double  gm_b[3];        /* drift*sqrt(1-exp(-2/(fs*tau)))        (pathgen.py:586); drift when tau is inf */
+    double  white[3];       /* rw / sqrt(dt)                         (pathgen.py:496, 558) */
+    int32_t white_drift[3]; /* 1: tau is inf -> drift[j] = gm_b*N[j] (pathgen.py:593) */
+    int32_t reserved;
+} ginsim_sensor_model;
+
+typedef struct {
+    int64_t  n;             /* IMU samples per run */
+    int64_t  runs;          /* Monte-Carlo runs on this device */
+    uint64_t run_offset;    /* global id of this device's first run (enters the RNG counter) */
+    uint64_t seed;          /* Philox key */
+    double   fs;
+    int32_t  ref_frame;     /* 0 NED/LLA (free_integration.py:117-172), 1 virtual inertial (:83-116) */
+    int32_t  algo_mask;     /* GINSIM_ALGO_* bits; both algorithms see the same sensor realisation */
+    int32_t  earth_rot;     /* FreeIntegration(earth_rot=...) (free_integration.py:19, 150-152) */
+    int32_t  n_ini;         /* columns of the initial-state table (free_integration.py:42-61) */
+    uint64_t ini_first;     /* value of FreeIntegration.run_times before this batch (free_integration.py:69, 85-87) */
+    int32_t  ini_has_g;     /* 10th element = externally supplied gravity (free_integration.py:59-61) */
+    int32_t  given_sensors; /* 1: read gyro/accel[/odo] from in_* instead of generating them */
+    ginsim_sensor_model accel, gyro;
+    double   odo_scale, odo_stdv;          /* pathgen.odo_gen (pathgen.py:627-641) */
+    double   ref_end[9];    /* truth att(3) pos(3) vel(3) at the last sample, for the end-point error */
+    /* device pointers */
+    const double* ini;        /* [n_ini][10] */
+    const double* ref_accel;  /* [n][3] truth specific force (pathgen imu cols 1-3) */
+    const double* ref_gyro;   /* [n][3] truth angular rate   (pathgen imu cols 4-6) */
+    const double* ref_odo;    /* [n]    truth forward speed  (pathgen odo col 2), NULL if unused */
+    const double* in_accel;   /* given_sensors: [3][n][runs] */
+    const double* in_gyro;    /* given_sensors: [3][n][runs] */
+    const double* in_odo;     /* given_sensors: [n][runs], NULL if unused */
+    double* out_accel;        /* [3][n][runs] or NULL  (dmgr.accel, ins_sim.py:491-493) */
+    double* out_gyro;         /* [3][n][runs] or NULL  (dmgr.gyro,  ins_sim.py:494-496) */
+    double* out_odo;          /* [n][runs]    or NULL  (dmgr.odo,   ins_sim.py:504-506) */
+    double* out_traj[2];      /* per algorithm bit: [9][n][runs] = att3,pos3,vel3 or NULL */
+    double* out_end[2];       /* per algorithm bit: [9][runs] end-point error (att wrapped to [-pi,pi]) or NULL */
+} ginsim_mc_params;
+
+int ginsim_mc_run(ginsim_ctx* ctx, const ginsim_mc_params* p);
+
+/* ---- end-point statistics: InsDataMgr.__end_point_error_stats / __array_stats
+ *      (gnss_ins_sim/sim/ins_data_manager.py:717-759, 797-808) ------------------------------------ */
+typedef struct {
+    double count;
+    double mean[9];
+    double m2[9];           /* sum of squared deviations from mean; std(ddof=0) = sqrt(m2/count) */
+    double maxabs[9];
+} ginsim_stats;             /* 28 doubles; mergeable across devices (Chan et al.) */
+
+int ginsim_end_stats(ginsim_ctx* ctx, const double* end_err /*device [9][runs]*/, int64_t runs, ginsim_stats* host_out);
+int ginsim_stats_merge(const ginsim_stats* parts, int32_t nparts, ginsim_stats* out);
+
+/* ---- data access: pull selected runs out of a [ncomp][n][runs] device series into host [nsel][n][ncomp] */
+int ginsim_gather_runs(ginsim_ctx* ctx, const double* series, int32_t ncomp, int64_t n, int64_t runs,
+                       const int64_t* run_ids /*host*/, int32_t nsel, double* host_out);
+
+/* ---- given-data mechanisation with host buffers: the plugin's .run(set_of_input) boundary
+ *      (free_integration.py:63-174 / free_integration_odo.py:63-160).  gyro/accel [R][n][3], odo [R][n],
+ *      ini [n_ini][10]; outputs att/pos/vel [R][n][3].  algo is ONE GINSIM_ALGO_* bit. */
+int ginsim_free_integration(ginsim_ctx* ctx, int32_t algo, int32_t ref_frame, double fs, int32_t earth_rot,
+                            const double* gyro, const double* accel, const double* odo, int64_t R, int64_t n,
+                            const double* ini, int32_t n_ini, int32_t ini_has_g, uint64_t ini_first,
+                            double* att, double* pos, double* vel);
+
+/* ---- RNG self-test hook: first `count` normal pairs of (seed, run, stream) computed ON DEVICE ---- */
+int ginsim_rng_normals(ginsim_ctx* ctx, uint64_t seed, uint64_t run, uint32_t stream, int64_t count,
+                       double* host_z0, double* host_z1, uint32_t* host_words /*[count][4] or NULL*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GINSIM_H */

@@ -1,0 +1,214 @@
+"""GPU parity tests: the HIP path (through the C ABI / ctypes) against
+  (1) golden vectors produced by executing the unmodified reference (tests/golden/*.npz), and
+  (2) the NumPy oracle on the same seeds,
+plus size-independent properties at BASELINE.json's full run count.
+
+fp64 tolerance: per-sample |d| <= 1e-9 * max(1,|x|) after n = 1000 steps, angles
+compared modulo 2*pi; end-point statistics 1e-7 relative (std of R=3..4 samples amplifies rounding).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, assert_traj_close, ang_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import ginsim
+    c = ginsim.Context(0)
+    yield c
+    c.close()
+
+
+def test_library_is_the_hip_one(ctx):
+    import ginsim
+    assert 'gfx950' in ctx.name() or 'MI3' in ctx.name(), ctx.name()
+    assert ginsim.LIB_PATH.endswith('gnss-ins-sim_amd/lib/libginsim.so')
+
+
+def test_rng_words_bit_exact_and_normals(ctx):
+    import ginsim
+    from oracle import philox
+    for seed, run, stream in ((0, 0, 0), (20260923, 3, 5), (2 ** 63 + 12345, 2 ** 40 + 7, 18)):
+        z0, z1, w = ginsim.rng_normals(ctx, seed, run, stream, 4096, words=True)
+        j = np.arange(4096, dtype=np.uint64)
+        ref = philox.philox4x32_10(j, np.uint64(stream), np.uint64(run & 0xFFFFFFFF), np.uint64(run >> 32),
+                                   seed & 0xFFFFFFFF, seed >> 32)
+        for k in range(4):
+            assert np.array_equal(w[:, k].astype(np.uint64), ref[k]), 'Philox word %d differs' % k
+        r0, r1 = philox.normal_pair(seed, run, stream, j)
+        np.testing.assert_allclose(z0, r0, rtol=0, atol=2e-14)
+        np.testing.assert_allclose(z1, r1, rtol=0, atol=2e-14)
+
+
+@pytest.mark.parametrize('name', ['bosch', 'nxp'])
+def test_t1_given_data_fixture(ctx, name):
+    import ginsim
+    g = load_golden('t1_fixture_' + name)
+    k = g['rows']
+    for tag, rf, ini, erot in (('extg', 0, g['ini'], False), ('wgs', 0, g['ini'][:9], True),
+                               ('rf1', 1, g['ini'][:9], True)):
+        att, pos, vel = ginsim.free_integration_host(ctx, 'free', rf, float(g['fs']), g['gyro'], accel=g['accel'],
+                                                     ini=ini, earth_rot=erot)
+        assert_traj_close(att[k], pos[k], vel[k], g['att_' + tag], g['pos_' + tag], g['vel_' + tag],
+                          rtol=1e-10, what=name + tag)
+
+
+def _truth_from_pathgen(g, rf, fs=100.0, gps=False):
+    import ginsim
+    r = ginsim.pathgen(g['ini_pva'], g['motion_def'], fs, 10.0, g['mobility'], rf, gps=gps)
+    return {'ref_accel': r['imu'][:, 1:4], 'ref_gyro': r['imu'][:, 4:7], 'ref_pos': r['nav'][:, 1:4],
+            'ref_vel': r['nav'][:, 4:7], 'ref_att': r['nav'][:, 7:10], 'ref_odo': r['odo'][:, 2]}
+
+
+ZERO = {'b': np.zeros(3), 'b_drift': np.zeros(3), 'b_corr': np.full(3, 100.0), 'arw': np.zeros(3), 'vrw': np.zeros(3)}
+
+
+@pytest.mark.parametrize('rf', [0, 1])
+def test_t2_noise_free_closed_loop(ctx, rf):
+    """path_gen (native) -> fused kernel with a zero-noise IMU == reference Sim.run(1) outputs."""
+    import ginsim
+    g = load_golden('t2_turn_rf%d' % rf)
+    k = g['rows']
+    truth = _truth_from_pathgen(g, rf)
+    job = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, ZERO, ZERO, g['ini_pva'], runs=3, algos=('free', 'odo'),
+                               odo_err={'scale': 1.0, 'stdv': 0.0}, seed=1, keep_sensors=True, keep_traj=True).run()
+    for algo, tag in (('free', 'fi'), ('odo', 'odo')):
+        att, pos, vel = job.trajectories(algo, [0, 2])
+        for r in range(2):
+            assert_traj_close(att[r][k], pos[r][k], vel[r][k], g[tag + '_att'], g[tag + '_pos'], g[tag + '_vel'],
+                              rtol=1e-10, what='%s run%d' % (tag, r))
+    np.testing.assert_allclose(job.sensors('accel', [1])[0], truth['ref_accel'], rtol=0, atol=0)
+    # reference noise-free end-point errors
+    e = job.end_errors('free')[0]
+    if rf == 1:
+        assert abs(e[6]) < 1e-11 and abs(e[7]) < 1e-11
+    else:
+        assert abs(e[6] - 1.828e-2) < 2e-5     # the reference's deterministic forward-Euler bias
+    job.release()
+
+
+def _errs(g):
+    acc = {k[6:]: g[k] for k in g if k.startswith('accel_') and k != 'accel'}
+    gyr = {k[5:]: g[k] for k in g if k.startswith('gyro_') and k != 'gyro'}
+    return acc, gyr
+
+
+@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0'])
+def test_t3_injected_noise_vs_reference(ctx, name):
+    """Unmodified reference Sim.run(R) fed the engine's Philox normals == fused kernel, per sample."""
+    import ginsim
+    g = load_golden(name)
+    R, k, fs, rf = int(g['R']), g['rows'], float(g['fs']), int(g['ref_frame'])
+    acc_err, gyr_err = _errs(g)
+    algos = tuple(a for a in ('free', 'odo') if ('fi' if a == 'free' else 'odo') + '_att' in g)
+    truth = {'ref_accel': g['ref_accel'], 'ref_gyro': g['ref_gyro'], 'ref_pos': g['ref_pos'],
+             'ref_vel': g['ref_vel'], 'ref_att': g['ref_att']}
+    odo_err = None
+    if 'odo' in g:
+        truth['ref_odo'] = g['ref_odo']
+        odo_err = {'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])}
+    job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc_err, gyr_err, g['ini'], runs=R, algos=algos, odo_err=odo_err,
+                               seed=int(g['seed']), keep_sensors=True, keep_traj=True).run()
+    runs = np.arange(R)
+    np.testing.assert_allclose(job.sensors('accel', runs)[:, k], g['accel'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(job.sensors('gyro', runs)[:, k], g['gyro'], rtol=0, atol=1e-14)
+    if 'odo' in algos:
+        np.testing.assert_allclose(job.sensors('odo', runs)[:, k], g['odo'], rtol=0, atol=1e-12)
+    groups = sorted({key.rsplit('_', 1)[1] for key in g if key.startswith('stat_att_euler_max_')})
+    r2d = 180.0 / np.pi
+    scale = np.concatenate([np.full(3, r2d), [r2d, r2d, 1.0] if rf == 0 else np.ones(3), np.ones(3)])
+    for a in algos:
+        tag = 'fi' if a == 'free' else 'odo'
+        att, pos, vel = job.trajectories(a, runs)
+        assert_traj_close(att[:, k], pos[:, k], vel[:, k], g[tag + '_att'], g[tag + '_pos'], g[tag + '_vel'],
+                          rtol=1e-9, what=name + a)
+        st = job.stats(a)
+        assert st.count == R
+        matched = False
+        for grp in groups:
+            want = {s: np.concatenate([g['stat_%s_%s_%s' % (dn, s, grp)] for dn in ('att_euler', 'pos', 'vel')])
+                    for s in ('max', 'avg', 'std')}
+            matched |= (np.allclose(st.maxabs * scale, want['max'], rtol=1e-7, atol=1e-12)
+                        and np.allclose(st.mean * scale, want['avg'], rtol=1e-7, atol=1e-12)
+                        and np.allclose(st.std * scale, want['std'], rtol=1e-6, atol=1e-12))
+        assert matched, 'device end-point statistics of %s/%s match no reference group' % (name, a)
+    job.release()
+
+
+@pytest.mark.parametrize('rf,algos', [(1, ('free',)), (1, ('free', 'odo')), (0, ('free', 'odo')), (0, ('odo',))])
+def test_oracle_parity_moderate_batch(ctx, rf, algos):
+    """R = 200 runs (ragged: not a multiple of the 64-lane wavefront), global run ids offset by 1000."""
+    import ginsim
+    from oracle import ins_np
+    g = load_golden('t3_demo_rf1')
+    t2 = load_golden('t2_turn_rf%d' % rf)
+    truth = _truth_from_pathgen(t2, rf)
+    acc_err, gyr_err = _errs(g)
+    odo_err = {'scale': 0.999, 'stdv': 0.1}
+    R, off, seed = 200, 1000, 77
+    job = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc_err, gyr_err, t2['ini_pva'], runs=R, algos=algos,
+                               odo_err=odo_err, seed=seed, run_offset=off, keep_sensors=True, keep_traj=True).run()
+    runs = np.arange(off, off + R)
+    accel, gyro = ins_np.mc_sensors(seed, runs, 100.0, truth['ref_accel'], truth['ref_gyro'], acc_err, gyr_err)
+    odo = ins_np.mc_odo(seed, runs, truth['ref_odo'], odo_err)
+    pick = np.array([0, 63, 64, 199])
+    np.testing.assert_allclose(job.sensors('gyro', pick), gyro[pick], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(job.sensors('accel', pick), accel[pick], rtol=0, atol=1e-12)
+    for a in algos:
+        att, pos, vel = ins_np.free_integration(rf, 100.0, gyro, accel, t2['ini_pva'], odo=odo if a == 'odo' else None)
+        d_att, d_pos, d_vel = job.trajectories(a, pick)
+        assert_traj_close(d_att, d_pos, d_vel, att[pick], pos[pick], vel[pick], rtol=1e-9, what=a)
+        e = ins_np.end_point_errors(att, pos, vel, truth['ref_att'], truth['ref_pos'], truth['ref_vel'])
+        de = job.end_errors(a)
+        assert ang_close(de[:, :3], e[:, :3], 1e-9)
+        np.testing.assert_allclose(de[:, 3:], e[:, 3:], rtol=0, atol=2e-8)      # |pos| ~ 5e6 m in ref_frame 1
+        st, ref = job.stats(a), ins_np.array_stats(e)
+        np.testing.assert_allclose(st.mean, ref['avg'], rtol=1e-6, atol=1e-10)
+        np.testing.assert_allclose(st.std, ref['std'], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(st.maxabs, ref['max'], rtol=1e-7, atol=1e-10)
+    # stats-only launch (nothing materialised) must give the same end-point errors
+    job2 = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc_err, gyr_err, t2['ini_pva'], runs=R, algos=algos,
+                                odo_err=odo_err, seed=seed, run_offset=off).run()
+    for a in algos:
+        np.testing.assert_array_equal(job2.end_errors(a), job.end_errors(a))
+    job.release()
+    job2.release()
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config 2 (90-degree turn, 100 Hz, 65 536 runs, fp64): size-independent properties.
+
+    * sharding invariance: the same global runs computed as one batch or as two shards give bit-identical
+      per-run results and Chan-merged statistics equal to the one-batch statistics;
+    * analytic known answers of the error model: att std ~= ARW*sqrt(T) = 0.01318 deg,
+      horizontal velocity std ~= g*ARW*sqrt(T^3/3) = 0.0130 m/s.
+    """
+    import ginsim
+    t2 = load_golden('t2_turn_rf1')
+    truth = _truth_from_pathgen(t2, 1)
+    D2R = np.pi / 180
+    gyr = {'b': np.zeros(3), 'b_drift': np.full(3, 3.5) * D2R / 3600, 'b_corr': np.full(3, 100.0),
+           'arw': np.full(3, 0.25) * D2R / 60}
+    acc = {'b': np.zeros(3), 'b_drift': np.full(3, 5e-5), 'b_corr': np.full(3, 100.0), 'vrw': np.full(3, 0.03) / 60}
+    R = 65536
+    whole = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, t2['ini_pva'], runs=R, seed=2024).run()
+    st = whole.stats('free')
+    assert st.count == R
+    att_std_deg = st.std[:3] / D2R
+    assert np.all(np.abs(att_std_deg - 0.01318) < 0.01318 * 0.03), att_std_deg
+    assert np.all(np.abs(st.std[6:8] - 0.0130) < 0.0130 * 0.06), st.std[6:9]
+    assert np.all(np.abs(st.mean[:3]) < 5 * st.std[:3] / np.sqrt(R))
+    a = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, t2['ini_pva'], runs=40000, seed=2024).run()
+    b = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, t2['ini_pva'], runs=R - 40000, seed=2024,
+                             run_offset=40000).run()
+    e = whole.end_errors('free')
+    np.testing.assert_array_equal(np.vstack([a.end_errors('free'), b.end_errors('free')]), e)
+    merged = ginsim.StatsResult.merge([a.stats('free').pack(), b.stats('free').pack()])
+    np.testing.assert_allclose(merged.mean, st.mean, rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(merged.std, st.std, rtol=1e-10)
+    np.testing.assert_array_equal(merged.maxabs, st.maxabs)
+    np.testing.assert_allclose(st.std, np.std(e, 0), rtol=1e-10)
+    np.testing.assert_allclose(st.mean, np.mean(e, 0), rtol=1e-8, atol=1e-14)
