@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the Monte-Carlo strapdown-INS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of Monte-Carlo runs on every GPU:
+fused kernel (noise injection + free-integration mechanisation + end-point error, sensors and
+trajectories materialised in HBM exactly as the reference's Sim holds them after run()) -> on-device
+end-point statistics -> (N > 1) one all-reduce of the per-GPU statistics records -> merged mean/std/max.
+Workload = BASELINE.json configs[1]: 90-degree-turn profile @100 Hz (n = 1000), 'mid-accuracy' 6-axis IMU,
+ref_frame = 1, 65 536 runs per GPU, fp64.  Weak scaling: every rank integrates its own 65 536 runs
+(global run ids are disjoint, the Philox counter carries the global id).
+
+Prints ONE JSON line (rank 0).  Inputs (truth, parameters) are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(REPO, 'gnss-ins-sim_amd'), REPO]
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_PER_SAMPLE_MC = 120   # accel3 + gyro3 + att3 + pos3 + vel3 doubles, all writes
+
+
+def cpu_baseline(fs, rf, ini, truth, acc, gyr, seed, budget_s):
+    """oracle/c/ginsim_oracle.c (kind 'port') on the host cores, same workload, bounded sample."""
+    import ctypes
+    from oracle import c_oracle
+    cores = os.cpu_count() or 1
+    c_oracle.lib()
+    try:
+        ctypes.CDLL('libgomp.so.1').omp_set_num_threads(cores)
+    except OSError:
+        cores = 1
+    n = truth['ref_accel'].shape[0]
+    t0 = time.perf_counter()
+    c_oracle.mc_run(seed, 0, 64 * cores, fs, rf, truth, acc, gyr, ini)
+    probe = time.perf_counter() - t0
+    runs = int(max(64 * cores, min(2_000_000, budget_s / max(probe, 1e-6) * 64 * cores)))
+    t0 = time.perf_counter()
+    c_oracle.mc_run(seed, 0, runs, fs, rf, truth, acc, gyr, ini)
+    dt = time.perf_counter() - t0
+    return {'value': runs * n / dt, 'unit': 'sample*MC/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d runs x %d samples of the same workload through oracle/c/ginsim_oracle.c '
+                      '(OpenMP over runs, %.1f s)' % (runs, n, dt)}
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
+    path = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel_key, {}).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--runs-per-gpu', type=int, default=65536)
+    ap.add_argument('--profile', default='turn_90deg')
+    ap.add_argument('--fs', type=float, default=100.0)
+    ap.add_argument('--ref-frame', type=int, default=1)
+    ap.add_argument('--stats-only', action='store_true', help='do not materialise sensors/trajectories')
+    ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import ginsim
+    from ginsim import workloads, distributed
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    ctx = ginsim.Context(local_rank)
+
+    fs, rf, R, seed = args.fs, args.ref_frame, args.runs_per_gpu, 20260923
+    ini, truth, _ = workloads.truth_from_profile(args.profile, fs, rf)
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    n = truth['ref_accel'].shape[0]
+    keep = not args.stats_only
+    job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, algos=('free',), seed=seed,
+                               keep_sensors=keep, keep_traj=keep)
+    group = dist.group.WORLD if world > 1 else None
+    device = torch.device('cuda', local_rank)
+    nsteps = args.warmup + args.steps
+    if 2 * nsteps > 8192:
+        sys.exit('too many steps for the event pool')
+
+    def step(s):
+        job.params.run_offset = (s * world + rank) * R      # a fresh batch of global run ids every step
+        ctx.event_record(2 * s)
+        job.launch()
+        ctx.event_record(2 * s + 1)
+        part = job.stats('free')                            # on-device reduction, 28 doubles back
+        return distributed.allreduce_stats(part, group, device)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        merged = step(s)
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, nsteps):
+        merged = step(s)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = [ctx.event_elapsed(2 * s, 2 * s + 1) for s in range(args.warmup, nsteps)]
+    kern_avg_ms = float(np.mean(kern_ms))
+    assert merged.count == world * R, (merged.count, world * R)
+
+    if rank == 0:
+        total_units = float(world) * R * n * args.steps
+        alg_bytes = (BYTES_PER_SAMPLE_MC if keep else 0) * R * n + 72 * R      # per launch, per GPU
+        achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+        r2d = 180.0 / np.pi
+        out = {
+            'metric': 'Monte-Carlo IMU samples integrated/sec', 'value': total_units / elapsed,
+            'unit': 'sample*MC/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: %s @%g Hz (n=%d), mid-accuracy 6-axis IMU, ref_frame=%d, '
+                                   'free_integration, %d MC runs per GPU, %s' %
+                                   (args.profile, fs, n, rf, R,
+                                    'sensors+trajectories materialised (120 B/sample*MC)' if keep else 'stats-only'),
+                       'runs_per_gpu': R, 'samples_per_run': n, 'total_runs_per_step': world * R,
+                       'parallelism': 'mc-shard x%d, one all-reduce of the 28-double stats record' % world,
+                       'device': ctx.name()},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': pmc_traffic('mc_kernel_rf%d_free_%s' % (rf, 'keep' if keep else 'stats')),
+                         'kernel': 'ginsim::mc_kernel<%d,1,false>' % rf, 'kernel_ms_avg': kern_avg_ms,
+                         'algorithmic_bytes_per_launch': alg_bytes,
+                         'note': 'fp64 transcendental/VALU-bound, not HBM-bound: see DESIGN.md (roofline)'},
+            'result': {'att_std_deg': (merged.std[:3] * r2d).tolist(), 'vel_std_mps': merged.std[6:9].tolist(),
+                       'runs': merged.count},
+        }
+        if world == 1 and args.cpu_baseline_seconds > 0:
+            out['cpu_baseline'] = cpu_baseline(fs, rf, ini, truth, acc, gyr, seed, args.cpu_baseline_seconds)
+        print(json.dumps(out), flush=True)
+
+    job.release()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -42,6 +42,7 @@ struct ginsim_ctx {
     int device;
     hipStream_t stream;
     hipEvent_t ev0, ev1;
+    std::vector<hipEvent_t> pool;   // lazily created, indexed by slot
 };
 
 #define HIP_TRY(expr)                                                                         \
@@ -113,6 +114,8 @@ int ginsim_destroy(ginsim_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->pool)
+        if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return GINSIM_OK;
@@ -185,6 +188,24 @@ int ginsim_timer_end(ginsim_ctx* c, float* ms) {
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return GINSIM_OK;
+}
+
+int ginsim_event_record(ginsim_ctx* c, int32_t slot) {
+    REQUIRE(c && slot >= 0 && slot < GINSIM_MAX_EVENTS, "event_record: slot out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    if ((size_t)slot >= c->pool.size()) c->pool.resize(slot + 1, nullptr);
+    if (!c->pool[slot]) HIP_TRY(hipEventCreate(&c->pool[slot]));
+    HIP_TRY(hipEventRecord(c->pool[slot], c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_event_elapsed(ginsim_ctx* c, int32_t a, int32_t b, float* ms) {
+    REQUIRE(c && ms && a >= 0 && b >= 0 && (size_t)a < c->pool.size() && (size_t)b < c->pool.size() && c->pool[a] &&
+                c->pool[b], "event_elapsed: slots were not recorded");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->pool[b]));
+    HIP_TRY(hipEventElapsedTime(ms, c->pool[a], c->pool[b]));
     return GINSIM_OK;
 }
 

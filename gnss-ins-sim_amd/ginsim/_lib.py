@@ -68,6 +68,8 @@ _SIGS = {
     'ginsim_sync': (C.c_int, [C.c_void_p]),
     'ginsim_timer_begin': (C.c_int, [C.c_void_p]),
     'ginsim_timer_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    'ginsim_event_record': (C.c_int, [C.c_void_p, C.c_int32]),
+    'ginsim_event_elapsed': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     'ginsim_pathgen_capacity': (C.c_int, [C.POINTER(PathgenParams), _PD, C.POINTER(C.c_int64)]),
     'ginsim_pathgen': (C.c_int, [C.POINTER(PathgenParams), _PD, C.c_int64, _PD, _PD, _PD, _PD,
                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

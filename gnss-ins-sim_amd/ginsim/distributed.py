@@ -1,0 +1,42 @@
+"""Multi-GPU side of the engine: Monte-Carlo runs shard embarrassingly (contiguous global run ranges, one
+process per GPU); the only exchange is ONE all-reduce of the per-device statistics record.
+
+The record (count, mean[9], M2[9], max|e|[9]) is placed in row `rank` of a zero (world x 28) matrix and
+summed with a single all-reduce (RCCL over xGMI on GPUs; gloo in the CPU tests).  Every rank then holds
+all per-device records and folds them with the library's Chan merge -- same result on every rank,
+independent of reduction order, and better conditioned than summing raw sum / sum-of-squares.
+Payload: world x 28 doubles (1.8 KB at 8 GPUs) -> latency-bound; link bandwidth is irrelevant.
+"""
+import numpy as np
+
+from .engine import StatsResult
+
+RECORD = 28
+
+
+def shard(total_runs, world, rank):
+    """Contiguous, balanced split of [0,total_runs): returns (first_global_run, runs_on_this_rank)."""
+    base, extra = divmod(int(total_runs), int(world))
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def allreduce_stats(part, group=None, device=None):
+    """Merge per-rank StatsResult objects across `group` with one all-reduce(SUM); identity when not
+    distributed.  `device` is where the exchange tensor lives (cuda:<local_rank> for nccl, cpu for gloo)."""
+    if group is None:
+        return part
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    table = torch.zeros((world, RECORD), dtype=torch.float64, device=device)
+    table[rank] = torch.from_numpy(part.pack()).to(table.device)
+    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    return StatsResult.merge(table.cpu().numpy())
+
+
+def stats_from_errors(e):
+    """Packed record of a host array of end-point errors (runs,9) -- used by tests to fabricate partials."""
+    e = np.asarray(e, dtype=np.float64)
+    m = e.mean(0)
+    return np.concatenate([[e.shape[0]], m, ((e - m) ** 2).sum(0), np.abs(e).max(0)])

@@ -87,6 +87,14 @@ class Context(object):
         check(lib.ginsim_timer_end(self.handle, C.byref(ms)))
         return ms.value
 
+    def event_record(self, slot):
+        check(lib.ginsim_event_record(self.handle, int(slot)))
+
+    def event_elapsed(self, slot_a, slot_b):
+        ms = C.c_float(0)
+        check(lib.ginsim_event_elapsed(self.handle, int(slot_a), int(slot_b), C.byref(ms)))
+        return ms.value
+
     def close(self):
         if self.handle:
             lib.ginsim_destroy(self.handle)

@@ -47,6 +47,11 @@ int  ginsim_sync(ginsim_ctx* ctx);
 /* HIP-event timer on the context's stream (the stream every kernel of this context is launched on). */
 int  ginsim_timer_begin(ginsim_ctx* ctx);
 int  ginsim_timer_end(ginsim_ctx* ctx, float* elapsed_ms);
+/* Event pool for timing many launches without synchronising in between: record event `slot` on the
+ * context's stream; elapsed(a,b) synchronises on b and returns the time between the two records. */
+#define GINSIM_MAX_EVENTS 8192
+int  ginsim_event_record(ginsim_ctx* ctx, int32_t slot);
+int  ginsim_event_elapsed(ginsim_ctx* ctx, int32_t slot_a, int32_t slot_b, float* elapsed_ms);
 
 /* ---- truth: pathgen.path_gen (gnss_ins_sim/pathgen/pathgen.py:26-329, osr == 1) ------------- */
 typedef struct {

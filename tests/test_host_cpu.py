@@ -1,0 +1,161 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/ginsim.h declares, host-side
+argument checking, native pathgen vs the reference goldens, sharding + the all-reduce path on gloo."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, REPO, PKG
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    import ginsim
+    hdr = open(os.path.join(REPO, 'include', 'ginsim.h')).read()
+    declared = set(re.findall(r'\b(ginsim_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 20
+    raw = ctypes.CDLL(ginsim.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(raw, s)]
+    assert not missing, 'declared in include/ginsim.h but not exported: %s' % missing
+    assert set(ginsim.EXPORTS) <= declared
+    assert ginsim.lib.ginsim_abi_version() == 1
+
+
+def test_no_gpu_fails_loudly():
+    import ginsim
+    if ginsim.device_count() > 0:
+        pytest.skip('a GPU is visible')
+    with pytest.raises(ginsim.GinsimError, match='no CPU fallback'):
+        ginsim.Context(0)
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.cpp', '.h')):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
+                assert 'ginsim_oracle' not in src, f
+
+
+@pytest.mark.parametrize('rf', [0, 1])
+def test_native_pathgen_matches_reference(rf):
+    import ginsim
+    g = load_golden('t2_turn_rf%d' % rf)
+    k = g['rows']
+    r = ginsim.pathgen(g['ini_pva'], g['motion_def'], 100.0, 10.0, g['mobility'], rf, gps=True)
+    assert r['imu'].shape == (int(g['n']), 7)
+    np.testing.assert_allclose(r['imu'][:, 1:4], g['full_ref_accel'], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(r['imu'][:, 4:7], g['full_ref_gyro'], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(r['nav'][k, 1:4], g['ref_pos'], rtol=1e-15, atol=0)
+    np.testing.assert_allclose(r['nav'][k, 4:7], g['ref_vel'], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(r['nav'][k, 7:10], g['ref_att'], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(r['gps'][:, 1:7], g['ref_gps'], rtol=1e-15, atol=1e-13)
+    np.testing.assert_allclose(r['gps'][:, 7], g['gps_vis'])
+    np.testing.assert_allclose(r['odo'][k, 2], g['ref_odo'], rtol=0, atol=1e-13)
+
+
+def test_pathgen_error_behaviour():
+    """Same exception type and wording as pathgen.py:117-125 for bad motion definitions."""
+    import ginsim
+    g = load_golden('t2_turn_rf1')
+    md = g['motion_def'].copy()
+    md[1, 7] = -1.0
+    with pytest.raises(ValueError, match='negative time duration'):
+        ginsim.pathgen(g['ini_pva'], md, 100.0, 0.0, g['mobility'], 1)
+    md = g['motion_def'].copy()
+    md[:, 7] = 0.0
+    with pytest.raises(ValueError, match='must be above 0'):
+        ginsim.pathgen(g['ini_pva'], md, 100.0, 0.0, g['mobility'], 1)
+    md = g['motion_def'].copy()
+    md[0, 0] = 7
+    with pytest.raises(ValueError, match='unsupported motion type'):
+        ginsim.pathgen(g['ini_pva'], md, 100.0, 0.0, g['mobility'], 1)
+
+
+def test_sensor_model_coefficients():
+    import ginsim
+    from oracle import ins_np
+    err = {'b': np.array([1e-3, 0, -1e-3]), 'b_drift': np.array([1e-4, 2e-4, 3e-4]),
+           'b_corr': np.array([100.0, np.inf, 50.0]), 'vrw': np.array([0.01, 0.02, 0.03])}
+    m = ginsim.sensor_model(err, 'vrw', 200.0)
+    a, b, white = ins_np.gm_coeffs(err['b_corr'], err['b_drift'], 200.0)
+    np.testing.assert_array_equal(np.array(m.gm_a[:]), a)
+    np.testing.assert_allclose(np.array(m.gm_b[:]), b, rtol=1e-15)
+    assert list(m.white_drift[:]) == [0, 1, 0]
+    np.testing.assert_allclose(np.array(m.white[:]), err['vrw'] / np.sqrt(1 / 200.0), rtol=1e-15)
+
+
+def test_ini_table_shapes():
+    import ginsim
+    t, has_g = ginsim.ini_table(np.arange(9.0))
+    assert t.shape == (1, 10) and not has_g
+    t, has_g = ginsim.ini_table(np.arange(30.0).reshape(10, 3))
+    assert t.shape == (3, 10) and has_g and t[1, 9] == 28.0
+    with pytest.raises(ValueError):
+        ginsim.ini_table(np.zeros((2, 2, 2)))
+
+
+def test_shard_is_a_partition():
+    from ginsim import distributed
+    for total, world in ((1048576, 8), (1000, 3), (5, 8), (65536, 1)):
+        spans = [distributed.shard(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+            assert f0 + c0 == f1
+
+
+def test_stats_merge_host_matches_numpy():
+    import ginsim
+    from ginsim import distributed
+    rng = np.random.default_rng(3)
+    e = rng.normal(size=(1000, 9)) * np.logspace(-6, 3, 9) + np.logspace(-3, 6, 9)
+    parts = [distributed.stats_from_errors(x) for x in np.array_split(e, [17, 400, 401])]
+    m = ginsim.StatsResult.merge(parts)
+    assert m.count == 1000
+    np.testing.assert_allclose(m.mean, e.mean(0), rtol=1e-13)
+    np.testing.assert_allclose(m.std, e.std(0), rtol=1e-11)
+    np.testing.assert_array_equal(m.maxabs, np.abs(e).max(0))
+
+
+_WORKER = r'''
+import os, sys
+sys.path[:0] = [%(pkg)r, %(repo)r]
+import numpy as np, torch, torch.distributed as dist
+import ginsim
+from ginsim import distributed
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=int(sys.argv[1]), world_size=%(world)d)
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(11)
+e = rng.normal(size=(%(total)d, 9)) * np.logspace(-5, 2, 9) + np.linspace(-1, 1, 9)
+first, count = distributed.shard(%(total)d, world, rank)
+part = ginsim.StatsResult(ginsim.StatsResult.unpack(distributed.stats_from_errors(e[first:first + count])))
+m = distributed.allreduce_stats(part, dist.group.WORLD, torch.device('cpu'))
+assert m.count == %(total)d
+np.testing.assert_allclose(m.mean, e.mean(0), rtol=1e-12)
+np.testing.assert_allclose(m.std, e.std(0), rtol=1e-11)
+np.testing.assert_array_equal(m.maxabs, np.abs(e).max(0))
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_two_process_gloo_allreduce_of_stats(tmp_path):
+    """world_size 2 over gloo: shard -> per-rank record -> ONE all-reduce -> Chan merge == NumPy on all runs."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % {'pkg': PKG, 'repo': REPO, 'port': port, 'world': 2, 'total': 1001})
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
