@@ -38,7 +38,8 @@ class McParams(C.Structure):
                 ('ini', C.c_void_p), ('ref_accel', C.c_void_p), ('ref_gyro', C.c_void_p), ('ref_odo', C.c_void_p),
                 ('in_accel', C.c_void_p), ('in_gyro', C.c_void_p), ('in_odo', C.c_void_p),
                 ('out_accel', C.c_void_p), ('out_gyro', C.c_void_p), ('out_odo', C.c_void_p),
-                ('out_traj', C.c_void_p * 2), ('out_end', C.c_void_p * 2)]
+                ('out_traj', C.c_void_p * 2), ('out_end', C.c_void_p * 2),
+                ('wave_trace', C.c_void_p), ('block_threads', C.c_int32), ('reserved', C.c_int32)]
 
 
 class PathgenParams(C.Structure):

@@ -115,6 +115,10 @@ typedef struct {
     double* out_odo;          /* [n][runs]    or NULL  (dmgr.odo,   ins_sim.py:504-506) */
     double* out_traj[2];      /* per algorithm bit: [9][n][runs] = att3,pos3,vel3 or NULL */
     double* out_end[2];       /* per algorithm bit: [9][runs] end-point error (att wrapped to [-pi,pi]) or NULL */
+    /* tuning / telemetry (0 / NULL = defaults) */
+    uint64_t* wave_trace;     /* device [n_waves][4] or NULL: HW_ID, XCC_ID, s_memtime at wave start and end */
+    int32_t   block_threads;  /* workgroup size: 0 (default), 64, 128 or 256 */
+    int32_t   reserved;
 } ginsim_mc_params;
 
 int ginsim_mc_run(ginsim_ctx* ctx, const ginsim_mc_params* p);
