@@ -224,8 +224,10 @@ int ginsim_mc_run(ginsim_ctx* c, const ginsim_mc_params* p) {
     REQUIRE(p->runs <= (int64_t)0x7FFFFFFF * 64, "mc_run: too many runs for one launch");
     REQUIRE(p->fs > 0.0, "mc_run: fs must be positive");
     REQUIRE(p->ref_frame == 0 || p->ref_frame == 1, "mc_run: ref_frame must be 0 or 1");
-    REQUIRE(p->algo_mask >= 1 && p->algo_mask <= 3, "mc_run: algo_mask must be a combination of GINSIM_ALGO_*");
-    REQUIRE(p->n_ini >= 1 && p->ini, "mc_run: initial-state table missing");
+    REQUIRE(p->algo_mask >= 0 && p->algo_mask <= 3, "mc_run: algo_mask must be a combination of GINSIM_ALGO_*");
+    REQUIRE(p->algo_mask != 0 || (!p->given_sensors && (p->out_accel || p->out_gyro || p->out_odo)),
+            "mc_run: algo_mask 0 (sensors only) needs sensor outputs");
+    REQUIRE(p->algo_mask == 0 || (p->n_ini >= 1 && p->ini), "mc_run: initial-state table missing");
     REQUIRE(p->block_threads == 0 || p->block_threads == 64 || p->block_threads == 128 || p->block_threads == 256,
             "mc_run: block_threads must be 0, 64, 128 or 256");
     const bool odo = (p->algo_mask & GINSIM_ALGO_ODO) != 0, fre = (p->algo_mask & GINSIM_ALGO_FREE) != 0;

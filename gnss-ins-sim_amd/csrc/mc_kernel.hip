@@ -205,11 +205,13 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
                 acc = sense3(a.ref_accel, j, a.accel, da, zd, zw);
                 if (a.out_accel) store3(a.out_accel, plane, off, acc);
             }
-            normal_pair(key, S_GYR_D_XY, jj, zd.x, zd.y);
-            normal_pair(key, S_GYR_DZ_WX, jj, zd.z, zw.x);
-            normal_pair(key, S_GYR_W_YZ, jj, zw.y, zw.z);
-            gyr = sense3(a.ref_gyro, j, a.gyro, dg, zd, zw);
-            if (a.out_gyro) store3(a.out_gyro, plane, off, gyr);
+            if (FREE || ODO || a.out_gyro) {
+                normal_pair(key, S_GYR_D_XY, jj, zd.x, zd.y);
+                normal_pair(key, S_GYR_DZ_WX, jj, zd.z, zw.x);
+                normal_pair(key, S_GYR_W_YZ, jj, zw.y, zw.z);
+                gyr = sense3(a.ref_gyro, j, a.gyro, dg, zd, zw);
+                if (a.out_gyro) store3(a.out_gyro, plane, off, gyr);
+            }
             if (ODO || a.out_odo) {
                 double z0, z1;
                 normal_pair(key, S_ODO, jj, z0, z1);
@@ -259,6 +261,7 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
 template <int RF>
 static hipError_t launch1(const ginsim_mc_params& p, hipStream_t stream) {
     switch (p.algo_mask) {
+        case 0: return launch2<RF, 0>(p, stream);      // sensors only (Sim without an algorithm)
         case GINSIM_ALGO_FREE: return launch2<RF, GINSIM_ALGO_FREE>(p, stream);
         case GINSIM_ALGO_ODO: return launch2<RF, GINSIM_ALGO_ODO>(p, stream);
         default: return launch2<RF, GINSIM_ALGO_FREE | GINSIM_ALGO_ODO>(p, stream);

@@ -107,6 +107,18 @@ class Context(object):
             pass
 
 
+_DEFAULT_CTX = None
+
+
+def default_context():
+    """Process-wide context on device LOCAL_RANK (or 0); created on first use."""
+    global _DEFAULT_CTX
+    if _DEFAULT_CTX is None or _DEFAULT_CTX.handle is None:
+        import os
+        _DEFAULT_CTX = Context(int(os.environ.get('LOCAL_RANK', '0')))
+    return _DEFAULT_CTX
+
+
 # --------------------------------------------------------------------------------------- truth
 def pathgen(ini_pva, motion_def, fs, fs_gps=0.0, mobility=(1.0, 0.5, 2.0), ref_frame=0, gps=False):
     """pathgen.path_gen through the C ABI.  motion_def is (S,9) with angles in rad, unmodified.
@@ -226,19 +238,24 @@ class MonteCarloJob(object):
         self.n = int(truth['ref_accel'].shape[0])
         self.runs = int(runs)
         self.keep_sensors, self.keep_traj = bool(keep_sensors), bool(keep_traj)
-        self.want_odo = 'odo' in self.algos
+        self.want_odo = 'odo' in self.algos or (odo_err is not None and 'ref_odo' in truth)
         p = self.params = _lib.McParams()
         p.n, p.runs, p.run_offset, p.seed = self.n, self.runs, int(run_offset), int(seed) & (2 ** 64 - 1)
         p.fs, p.ref_frame = float(fs), int(ref_frame)
         p.algo_mask = sum(ALGO_BITS[a] for a in self.algos)
         p.earth_rot = int(bool(earth_rot))
-        table, has_g = ini_table(ini)
+        if ini is None:
+            if self.algos:
+                raise ValueError('initial states are required when an algorithm is integrated')
+            table, has_g = np.zeros((1, 10)), False
+        else:
+            table, has_g = ini_table(ini)
         p.n_ini, p.ini_first, p.ini_has_g, p.given_sensors = table.shape[0], int(ini_first), int(has_g), 0
         p.accel = sensor_model(accel_err, 'vrw', fs)
         p.gyro = sensor_model(gyro_err, 'arw', fs)
+        if 'odo' in self.algos and (odo_err is None or 'ref_odo' not in truth):
+            raise ValueError('the odometer algorithm needs odo_err and truth["ref_odo"]')
         if self.want_odo:
-            if odo_err is None or 'ref_odo' not in truth:
-                raise ValueError('the odometer algorithm needs odo_err and truth["ref_odo"]')
             p.odo_scale, p.odo_stdv = float(odo_err['scale']), float(odo_err['stdv'])
         end = np.concatenate([truth['ref_att'][-1], truth['ref_pos'][-1], truth['ref_vel'][-1]])
         p.ref_end[:] = [float(x) for x in end]

@@ -1,0 +1,209 @@
+"""Data registry + error statistics, interface-compatible with the reference's ``InsDataMgr``
+(gnss_ins_sim/sim/ins_data_manager.py): the same ~35 named series with the same units/legends
+(:44-273), ``add_data / get_data / get_data_all / get_data_properties / set_algo_output / is_supported /
+is_available / available``, and ``get_error_stats`` returning {'max','avg','std','units'}.
+
+Difference in kind, not in interface: Monte-Carlo series are ``McSeries`` views over GPU buffers and the
+end-point statistics (:717-759, 797-808) are reduced ON THE DEVICE; nothing here loops over runs.
+"""
+import numpy as np
+
+from . import sim_data
+from .sim_data import Sim_data
+
+_XYZ = ['m', 'm', 'm']
+_LLA = ['rad', 'rad', 'm']
+_LLA_OUT = ['deg', 'deg', 'm']
+_RATE = ['rad/s'] * 3
+_RATE_OUT = ['deg/s'] * 3
+_ACC = ['m/s^2'] * 3
+_VEL = ['m/s'] * 3
+_ANG = ['rad'] * 3
+_ANG_OUT = ['deg'] * 3
+_UT = ['uT'] * 3
+
+# name, description, units, output_units, legend, extra kwargs   (ins_data_manager.py:44-231)
+_REGISTRY = [
+    ('fs', 'Sample frequency of IMU', ['Hz'], None, None, {'plottable': False}),
+    ('fs_gps', 'Sample frequency of GPS', ['Hz'], None, None, {'plottable': False}),
+    ('fs_mag', 'Sample frequency of Magnetometer', ['Hz'], None, None, {'plottable': False}),
+    ('ref_frame', 'Reference frame', None, None, None, {'plottable': False}),
+    ('time', 'sample time', ['sec'], None, ['time'], {}),
+    ('gps_time', 'GPS sample time', ['sec'], None, ['gps_time'], {}),
+    ('gps_visibility', 'GPS visibility', None, None, ['gps_visibility'], {}),
+    ('ref_pos', 'true LLA pos in the navigation frame', _LLA, _LLA_OUT, ['ref_pos_lat', 'ref_pos_lon', 'ref_pos_alt'], {}),
+    ('ref_vel', 'true vel in the NED frame', _VEL, None, ['ref_vel_x', 'ref_vel_y', 'ref_vel_z'], {}),
+    ('ref_att_euler', 'true attitude (Euler angles, ZYX)', _ANG, _ANG_OUT, ['ref_Yaw', 'ref_Pitch', 'ref_Roll'], {}),
+    ('ref_att_quat', 'true attitude (quaternion)', None, None, ['q0', 'q1', 'q2', 'q3'], {}),
+    ('ref_gyro', 'true angular velocity in the body frame', _RATE, _RATE_OUT, ['ref_gyro_x', 'ref_gyro_y', 'ref_gyro_z'], {}),
+    ('ref_accel', 'true accel in the body frame', _ACC, None, ['ref_accel_x', 'ref_accel_y', 'ref_accel_z'], {}),
+    ('ref_gps', 'true GPS LLA position and NED velocity', _LLA + _VEL, _LLA_OUT + _VEL,
+     ['ref_gps_lat', 'ref_gps_lon', 'ref_gps_alt', 'ref_gps_vN', 'ref_gps_vE', 'ref_gps_vD'], {}),
+    ('ref_odo', 'true odometer velocity', ['m/s'], None, ['ref_odo'], {}),
+    ('ref_mag', 'true magnetic field in the body frame', _UT, None, ['ref_mag_x', 'ref_mag_y', 'ref_mag_z'], {}),
+    ('gyro', 'gyro measurements', _RATE, _RATE_OUT, ['gyro_x', 'gyro_y', 'gyro_z'], {}),
+    ('accel', 'accel measurements', _ACC, None, ['accel_x', 'accel_y', 'accel_z'], {}),
+    ('gps', 'GPS LLA position and NED velocity measurements', _LLA + _VEL, _LLA_OUT + _VEL,
+     ['gps_lat', 'gps_lon', 'gps_alt', 'gps_vN', 'gps_vE', 'gps_vD'], {}),
+    ('odo', 'odometer velocity measurement', ['m/s'], None, ['odo'], {}),
+    ('mag', 'magnetometer measurements', _UT, None, ['mag_x', 'mag_y', 'mag_z'], {}),
+    ('gyro_cal', 'gyro measurements after factory calibration', _RATE, _RATE_OUT, ['gyro_x', 'gyro_y', 'gyro_z'], {}),
+    ('accel_cal', 'accel measurements after factory calibration', _ACC, None, ['accel_x', 'accel_y', 'accel_z'], {}),
+    ('mag_cal', 'magnetometer measurements after SI&HI calibration', _UT, None, ['mag_x', 'mag_y', 'mag_z'], {}),
+    ('soft_iron', 'soft iron calibration matrix', None, None, None, {'plottable': False}),
+    ('hard_iron', 'hard iron', ['uT'] * 4, None, ['offset_x', 'offset_y', 'offset_z', 'radius'], {'plottable': False}),
+    ('algo_time', 'sample time from algo', ['sec'], None, None, {}),
+    ('pos', 'simulation position from algo', _LLA, _LLA_OUT, ['pos_lat', 'pos_lon', 'pos_alt'], {}),
+    ('vel', 'simulation velocity from algo', _VEL, None, ['vel_x', 'vel_y', 'vel_z'], {}),
+    ('att_quat', 'simulation attitude (quaternion) from algo', None, None, ['q0', 'q1', 'q2', 'q3'], {}),
+    ('att_euler', 'simulation attitude (Euler, ZYX) from algo', _ANG, _ANG_OUT, ['Yaw', 'Pitch', 'Roll'], {}),
+    ('wb', 'gyro bias estimation', _RATE, _RATE_OUT, ['gyro_bias_x', 'gyro_bias_y', 'gyro_bias_z'], {}),
+    ('ab', 'accel bias estimation', _ACC, None, ['accel_bias_x', 'accel_bias_y', 'accel_bias_z'], {}),
+    ('ad_gyro', 'Allan deviation of gyro', _RATE, _RATE_OUT, ['AD_wx', 'AD_wy', 'AD_wz'], {'logx': True, 'logy': True}),
+    ('ad_accel', 'Allan deviation of accel', _ACC, None, ['AD_ax', 'AD_ay', 'AD_az'], {'logx': True, 'logy': True}),
+]
+
+# which slice of the 9-component end-point record each error quantity occupies
+_END_SLICE = {'att_euler': slice(0, 3), 'pos': slice(3, 6), 'vel': slice(6, 9)}
+
+
+class InsDataMgr(object):
+    def __init__(self, fs, ref_frame=0):
+        self._all = {}
+        for name, desc, units, out_units, legend, extra in _REGISTRY:
+            sd = Sim_data(name=name, description=desc, units=units, output_units=out_units, legend=legend, **extra)
+            self._all[name] = sd
+            setattr(self, name, sd)
+        self.ref_frame.data = ref_frame if ref_frame in (0, 1) else 0
+        if self.ref_frame.data == 1:                       # ins_data_manager.py:235-256
+            for s, tag in ((self.ref_pos, 'ref_pos'), (self.pos, 'pos')):
+                s.units, s.output_units = list(_XYZ), list(_XYZ)
+                s.legend = [tag + '_x', tag + '_y', tag + '_z']
+            self.ref_pos.description = 'true position in the local NED frame'
+            for s, tag in ((self.ref_gps, 'ref_gps'), (self.gps, 'gps')):
+                s.units, s.output_units = _XYZ + _VEL, _XYZ + _VEL
+                s.legend = [tag + '_' + c for c in ('x', 'y', 'z', 'vx', 'vy', 'vz')]
+            self.ref_gps.description = 'true GPS position and velocity in the local NED frame'
+            self.gps.description = 'GPS position and velocity measurements in the local NED frame'
+        self.available = [self.ref_frame.name]
+        if fs[0] is None:
+            raise ValueError('IMU sampling frequency cannot be None.')
+        for sd, v in ((self.fs, fs[0]), (self.fs_gps, fs[1]), (self.fs_mag, fs[2])):
+            if v is not None:
+                sd.data = v
+                self.available.append(sd.name)
+        self._do_not_save = ['fs', 'fs_gps', 'fs_mag', 'ref_frame']
+        self._algo_output = []
+        self._mc = None         # device results of the last Sim.run: see set_mc_results
+
+    # ------------------------------------------------------------------ registry
+    def add_data(self, data_name, data, key=None, units=None):
+        if data_name not in self._all:
+            raise ValueError("Unsupported data: %s." % data_name)
+        self._all[data_name].add_data(data, key, units)
+        if data_name not in self.available:
+            self.available.append(data_name)
+
+    def set_algo_output(self, algo_output):
+        for i in algo_output:
+            if not self.is_supported(i):
+                raise ValueError("Unsupported algorithm output: %s." % i)
+            self._algo_output.append(i)
+
+    def get_data(self, data_names):
+        data = []
+        for i in data_names:
+            if i not in self.available:
+                print('%s is not available.' % i)
+                return None
+            data.append(self._all[i].data)
+        return data
+
+    def get_data_all(self, data_name):
+        return self._all.get(data_name)
+
+    def get_data_properties(self, data_name):
+        d = self._all[data_name]
+        return [d.description, d.units, d.plottable, d.logx, d.logy, d.legend]
+
+    def is_supported(self, data_name):
+        return data_name in self._all
+
+    def is_available(self, data_name, key=None):
+        ok = data_name in self.available
+        if ok and key is not None:
+            d = self._all[data_name].data
+            ok = hasattr(d, 'keys') and key in d
+        return ok
+
+    # ------------------------------------------------------------------ Monte-Carlo results on the device
+    def set_mc_results(self, mc):
+        """mc: object with .algo_names (list), .end_stats(algo_name) -> ginsim.StatsResult (already merged
+        across ranks), .process_stats(algo_name, data_name, start_index) (optional)."""
+        self._mc = mc
+
+    def get_error_stats(self, data_name, err_stats_start=0, angle=False, use_output_units=False, extra_opt=''):
+        """InsDataMgr.get_error_stats (ins_data_manager.py:385-452)."""
+        if data_name not in self.available:
+            print('error stats: %s is not available.' % data_name)
+            return None
+        if 'ref_' + data_name not in self.available:
+            print('%s has no reference.' % data_name)
+            return None
+        if self._mc is None or data_name not in _END_SLICE:
+            raise NotImplementedError('error statistics are computed on the device for att_euler/pos/vel of a '
+                                      'Monte-Carlo Sim.run(); %r is outside that path' % data_name)
+        src = self._all[data_name]
+        units, out_units = list(src.units), list(src.output_units)
+        ned = data_name == 'pos' and self.ref_frame.data == 0 and extra_opt == 'ned'
+        if ned:
+            units, out_units = list(_XYZ), list(_XYZ)
+        names = list(self._mc.algo_names)
+        if err_stats_start == -1:                            # end-point statistics, :717-759
+            per_algo = {a: self._mc.end_stats(a, ned=ned) for a in names}
+            sl = _END_SLICE[data_name]
+            pick = lambda st: {'max': st.maxabs[sl].copy(), 'avg': st.mean[sl].copy(), 'std': st.std[sl].copy()}
+            if len(names) == 1:
+                stat = pick(per_algo[names[0]])
+            else:                                            # one group per algorithm name, :810-832
+                stat = {'max': {}, 'avg': {}, 'std': {}}
+                for a in names:
+                    p = pick(per_algo[a])
+                    for s in stat:
+                        stat[s][a] = p[s]
+        else:                                                # process error of every run, :761-795
+            stat = self._mc.process_stats(data_name, max(err_stats_start, 0), angle=angle, ned=ned)
+        if use_output_units:
+            for s in stat:
+                if isinstance(stat[s], dict):
+                    stat[s] = {k: sim_data.convert_unit(v, units, out_units) for k, v in stat[s].items()}
+                else:
+                    stat[s] = sim_data.convert_unit(stat[s], units, out_units)
+        stat['units'] = str(out_units)
+        return stat
+
+    # ------------------------------------------------------------------ files
+    def save_data(self, data_dir, max_runs=None):
+        """InsDataMgr.save_data: every available series to '<name>[-<key>].csv'.  For Monte-Carlo series only
+        the first ``max_runs`` runs are written (None = all) -- a million CSV files help nobody."""
+        saved = []
+        for name in self.available:
+            if name in self._do_not_save:
+                continue
+            sd = self._all[name]
+            keys = None
+            if isinstance(sd.data, sim_data.McSeries) and max_runs is not None:
+                keys = [k for i, k in enumerate(sd.data) if i < max_runs * max(1, len(self._mc.algo_names)) and
+                        self._mc.run_of_key(k) < max_runs]
+            sd.save_to_file(data_dir, keys)
+            saved.append(name)
+        return saved
+
+    def save_kml_files(self, data_dir):
+        print('KML export is outside the accelerated hot path (SURVEY.md section 2, #16); skipped.')
+
+    def plot(self, *args, **kwargs):
+        raise NotImplementedError('plotting is outside the accelerated hot path (SURVEY.md section 2, #17)')
+
+    def show_plot(self):
+        pass

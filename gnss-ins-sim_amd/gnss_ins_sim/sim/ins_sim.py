@@ -1,0 +1,417 @@
+"""INS simulation driver, interface-compatible with the reference's ``Sim``
+(gnss_ins_sim/sim/ins_sim.py:27-832):
+
+    Sim(fs, motion_def, ref_frame=0, imu=None, mode=None, env=None, algorithm=None)
+    .run(num_times)  .results(data_dir, err_stats_start, gen_kml, extra_opt)  .get_data(names)
+    .dmgr  .amgr  .sim_count  .sum
+
+What differs is HOW ``run`` executes (ins_sim.py:164-192, 490-506 in the reference are two serial Python
+loops over runs): here the truth comes from the native ``ginsim_pathgen``, and ALL Monte-Carlo runs go
+through ONE launch of the fused HIP kernel (noise injection + mechanisation + end-point error) per GPU.
+Sensor series and algorithm outputs stay in HBM; ``dmgr.<series>.data`` are mapping views that pull a run
+to the host only when it is indexed.  With ``torch.distributed`` initialised (one process per GPU) the runs
+are sharded across ranks and the end-point statistics are combined with one all-reduce.
+
+Keyword-only extras (defaults keep the reference behaviour):
+    seed               64-bit Philox key.  None: drawn from ``np.random`` (so ``np.random.seed(s)`` before
+                       ``run`` makes a simulation repeatable, as it does for the reference).
+    keep_trajectories  'auto' | True | False: materialise sensors + outputs in HBM ('auto': when they fit
+                       ``max_device_bytes``), else keep only per-run end-point errors (stats-only).
+    max_device_bytes   budget for materialised series on one GPU (default 64 GiB of the 288 GB).
+    device             GPU index (default LOCAL_RANK or 0).
+"""
+import math
+import os
+import time
+
+import numpy as np
+
+from .ins_data_manager import InsDataMgr
+from .ins_algo_manager import InsAlgoMgr
+from .sim_data import McSeries
+from ..attitude import attitude
+
+NAME = 'gnss-ins-sim'
+VERSION = '3.0.0_alpha'
+high_mobility = np.array([1.0, 0.5, 2.0])       # m/s/s, rad/s/s, rad/s  (ins_sim.py:25)
+
+
+class _McResults(object):
+    """Device results of one Sim.run: per-algorithm jobs + cross-rank merge of the statistics."""
+
+    def __init__(self, jobs, names, kinds, first_run, runs_local, total_runs, group, device):
+        self.jobs, self.algo_names, self.kinds = jobs, names, kinds
+        self.first_run, self.runs_local, self.total_runs = first_run, runs_local, total_runs
+        self._group, self._device, self._stats = group, device, {}
+
+    def job_of(self, name):
+        return self.jobs[self.algo_names.index(name)]
+
+    def end_stats(self, name, ned=False):
+        if ned:
+            raise NotImplementedError("extra_opt='ned' end-point statistics are not on the device path yet")
+        if name not in self._stats:
+            from ginsim import distributed
+            part = self.job_of(name).stats(self.kinds[self.algo_names.index(name)])
+            self._stats[name] = distributed.allreduce_stats(part, self._group, self._device)
+        return self._stats[name]
+
+    def process_stats(self, data_name, start, angle=False, ned=False):
+        raise NotImplementedError('process-error statistics (err_stats_start >= 0) are not on the device path yet; '
+                                  'use err_stats_start=-1 (end-point statistics)')
+
+    def run_of_key(self, key):
+        return int(str(key).rsplit('_', 1)[-1]) if isinstance(key, str) else int(key)
+
+
+class Sim(object):
+    def __init__(self, fs, motion_def, ref_frame=0, imu=None, mode=None, env=None, algorithm=None, *,
+                 seed=None, keep_trajectories='auto', max_device_bytes=64 * 2 ** 30, device=None):
+        self.name, self.version = NAME, VERSION
+        self.fs, self.imu, self.mode, self.env = fs, imu, mode, env
+        self.ref_frame = ref_frame if ref_frame in (0, 1) else 0
+        self.sim_count = 1
+        self.sim_complete = False
+        self.sim_results = False
+        self.dmgr = InsDataMgr(fs, self.ref_frame)
+        self.data_src = motion_def
+        self.data_from_files = False
+        self.amgr = InsAlgoMgr(algorithm)
+        self.interested_error = {'att_euler': 'angle', 'pos': None, 'vel': None}
+        self.sum = ''
+        self.seed, self.keep_trajectories, self.max_device_bytes, self.device = seed, keep_trajectories, max_device_bytes, device
+        self.mc = None
+        if env is not None:
+            raise NotImplementedError('vibration models (env) are outside the accelerated hot path; every BASELINE '
+                                      'configuration uses env=None (SURVEY.md section 2, #15)')
+
+    # ------------------------------------------------------------------------------------ run
+    def run(self, num_times=1):
+        self.sim_count = max(int(num_times), 1)
+        if isinstance(self.data_src, str) and os.path.isdir(self.data_src):
+            self._run_from_files()
+        else:
+            self._run_monte_carlo()
+        self.sim_complete = True
+
+    def _context(self):
+        import ginsim
+        if self.device is None:
+            return ginsim.default_context()
+        return ginsim.Context(self.device)
+
+    @staticmethod
+    def _dist():
+        """(rank, world, group, exchange device) of the torch.distributed job, or a single-process stand-in."""
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return 0, 1, None, None
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0, 1, None, None
+        import torch
+        dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))) if dist.get_backend() == 'nccl' \
+            else torch.device('cpu')
+        return dist.get_rank(), dist.get_world_size(), dist.group.WORLD, dev
+
+    def _pick_seed(self, group, dev):
+        seed = self.seed
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 62))
+        if group is not None:                      # every rank must use rank 0's key
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([seed], dtype=torch.int64, device=dev)
+            dist.broadcast(t, src=0, group=group)
+            seed = int(t.item())
+        return seed
+
+    def _run_monte_carlo(self):
+        import ginsim
+        from ginsim import workloads, distributed
+        if self.imu is None:
+            raise ValueError('an IMU model is required to generate sensor data from a motion definition')
+        ini_pva, motion_def = workloads.parse_motion(self.data_src)
+        mobility = self._parse_mode(self.mode)
+        fs_imu = self.fs[0]
+        if self.imu.magnetometer:
+            raise NotImplementedError('9-axis (magnetometer) generation is not on the device path yet')
+        raw = ginsim.pathgen(ini_pva, motion_def, fs_imu, self.fs[1] if self.imu.gps else 0.0, mobility,
+                             self.ref_frame, gps=self.imu.gps)
+        d = self.dmgr
+        nav, imu_t = raw['nav'], raw['imu']
+        n = nav.shape[0]
+        d.add_data(d.time.name, nav[:, 0] / fs_imu)                       # ins_sim.py:467-480
+        d.add_data(d.ref_pos.name, np.ascontiguousarray(nav[:, 1:4]))
+        d.add_data(d.ref_vel.name, np.ascontiguousarray(nav[:, 4:7]))
+        d.add_data(d.ref_att_euler.name, np.ascontiguousarray(nav[:, 7:10]))
+        d.add_data(d.ref_accel.name, np.ascontiguousarray(imu_t[:, 1:4]))
+        d.add_data(d.ref_gyro.name, np.ascontiguousarray(imu_t[:, 4:7]))
+        if self.imu.gps:
+            d.add_data(d.gps_time.name, raw['gps'][:, 0] / fs_imu)
+            d.add_data(d.ref_gps.name, np.ascontiguousarray(raw['gps'][:, 1:7]))
+            d.add_data(d.gps_visibility.name, raw['gps'][:, 7].copy())
+        if self.imu.odo:
+            d.add_data(d.ref_odo.name, np.ascontiguousarray(raw['odo'][:, 2]))
+        d.add_data(d.ref_att_quat.name, attitude.euler2quat(d.ref_att_euler.data))     # ins_sim.py:729-748
+        truth = {'ref_accel': d.ref_accel.data, 'ref_gyro': d.ref_gyro.data, 'ref_pos': d.ref_pos.data,
+                 'ref_vel': d.ref_vel.data, 'ref_att': d.ref_att_euler.data}
+        if self.imu.odo:
+            truth['ref_odo'] = d.ref_odo.data
+
+        # which plugins are inside the fused kernel
+        algos = self.amgr.algo or []
+        kinds = [getattr(a, 'mc_algo', None) for a in algos]
+        fused = [i for i, k in enumerate(kinds) if k in ('free', 'odo')]
+        hosted = [i for i in range(len(algos)) if i not in fused]
+        for i in fused:
+            if kinds[i] == 'odo' and not self.imu.odo:
+                raise ValueError("algorithm %d needs 'odo' but the IMU model has no odometer" % i)
+
+        rank, world, group, xdev = self._dist()
+        first, count = distributed.shard(self.sim_count, world, rank)
+        seed = self._pick_seed(group, xdev)
+        ctx = self._context()
+        per_sample = 48 + (8 if self.imu.odo else 0) + 72 * len(fused)
+        keep = self.keep_trajectories
+        if keep == 'auto':
+            keep = per_sample * n * max(count, 1) <= self.max_device_bytes
+        if hosted and not keep:
+            raise ValueError('plugins outside the fused kernel need the sensor series: use keep_trajectories=True')
+        self.kept = bool(keep)
+
+        # one launch per distinct (initial states, earth_rot); identical noise in every launch (counter RNG)
+        groups = []
+        for i in fused:
+            a = algos[i]
+            for g in groups:
+                if np.array_equal(g['ini'], a.ini) and g['earth_rot'] == a.earth_rot and kinds[i] not in g['kinds'] \
+                        and g['first'] == a.run_times:
+                    g['kinds'].append(kinds[i])
+                    g['idx'].append(i)
+                    break
+            else:
+                groups.append({'ini': a.ini, 'earth_rot': a.earth_rot, 'kinds': [kinds[i]], 'idx': [i], 'first': a.run_times})
+        jobs_by_algo = {}
+        sensor_job = None
+        if count > 0:
+            for gi, g in enumerate(groups):
+                job = ginsim.MonteCarloJob(ctx, fs_imu, self.ref_frame, truth, self.imu.accel_err, self.imu.gyro_err,
+                                           g['ini'], runs=count, algos=tuple(g['kinds']), odo_err=self.imu.odo_err,
+                                           earth_rot=g['earth_rot'], seed=seed, run_offset=first,
+                                           ini_first=g['first'] + first, keep_sensors=bool(keep) and sensor_job is None,
+                                           keep_traj=bool(keep))
+                job.launch()
+                if sensor_job is None and keep:
+                    sensor_job = job
+                for i in g['idx']:
+                    jobs_by_algo[i] = job
+            if not groups and keep:            # Sim without algorithm: sensor generation only (demo_no_algo.py)
+                sensor_job = ginsim.MonteCarloJob(ctx, fs_imu, self.ref_frame, truth, self.imu.accel_err,
+                                                  self.imu.gyro_err, None, runs=count, algos=(), odo_err=self.imu.odo_err,
+                                                  seed=seed, run_offset=first, keep_sensors=True)
+                sensor_job.launch()
+            ctx.sync()
+        for i in fused:                         # FreeIntegration.run_times accounting (free_integration.py:69)
+            algos[i].run_times += self.sim_count
+
+        # expose device series through the data manager
+        runs = range(first, first + count)
+        if sensor_job is not None:
+            def sens(name, squeeze=False, job=sensor_job):
+                return McSeries(count, lambda pos, j=job, nm=name: j.sensors(nm, pos)[..., None] if nm == 'odo'
+                                else j.sensors(nm, pos), key_of=lambda i: first + i,
+                                pos_of=lambda k: int(k) - first if isinstance(k, (int, np.integer)) and
+                                first <= int(k) < first + count else None, squeeze=squeeze)
+            d.add_data(d.accel.name, sens('accel'))
+            d.add_data(d.gyro.name, sens('gyro'))
+            if self.imu.odo:
+                d.add_data(d.odo.name, sens('odo', squeeze=True))
+        if self.amgr.algo is not None:
+            d.set_algo_output(self.amgr.output)
+        names = [self.amgr.get_algo_name(i) for i in fused]
+        if fused and keep and count > 0:
+            for out_name, comp in (('att_euler', 0), ('pos', 1), ('vel', 2)):
+                d.add_data(out_name, self._output_view(jobs_by_algo, fused, kinds, names, comp, first, count))
+            d.add_data('att_quat', self._output_view(jobs_by_algo, fused, kinds, names, 0, first, count, quat=True))
+        elif fused:
+            for out_name in ('att_euler', 'pos', 'vel'):       # stats-only: names are known, series are not kept
+                d.add_data(out_name, {})
+        if fused:
+            self.mc = _McResults([jobs_by_algo.get(i) for i in fused], names, [kinds[i] for i in fused], first, count,
+                                 self.sim_count, group, xdev)
+            d.set_mc_results(self.mc)
+        # plugins outside the fused kernel: the reference's per-run loop over host copies (user code)
+        if hosted:
+            inputs = d.get_data(self.amgr.input)
+            out = self.amgr.run_algo(inputs, list(runs), only=hosted)
+            for j, oname in enumerate(self.amgr.output):
+                if out[j]:
+                    merged = dict(out[j])
+                    d.add_data(oname, merged)
+
+    def _output_view(self, jobs_by_algo, fused, kinds, names, comp, first, count, quat=False):
+        """Mapping '<algo>_<run>' -> (n,3) (or (n,4) quaternion) over the trajectory buffers of all fused plugins."""
+        order = [(names[k], jobs_by_algo[i], kinds[i]) for k, i in enumerate(fused)]
+
+        def locate(key):
+            if not isinstance(key, str) or '_' not in key:
+                return None
+            nm, _, r = key.rpartition('_')
+            if not r.isdigit() or not (first <= int(r) < first + count):
+                return None
+            for a, (name, _, _) in enumerate(order):
+                if name == nm:
+                    return a * count + int(r) - first
+            return None
+
+        def fetch(positions):
+            out = []
+            for p in positions:
+                a, r = divmod(p, count)
+                x = order[a][1].trajectories(order[a][2], [r])[comp][0]
+                out.append(attitude.euler2quat(x) if quat else x)
+            return np.stack(out)
+
+        return McSeries(count * len(order), fetch, key_of=lambda p: order[p // count][0] + '_' + str(first + p % count),
+                        pos_of=locate)
+
+    # ------------------------------------------------------------------------------------ logged data
+    def _run_from_files(self):
+        """Sim with a directory of logged CSV files (ins_sim.py:426-442): every plugin runs once per data key on
+        the given-data entry point of the library."""
+        self.data_src = os.path.abspath(self.data_src)
+        self.data_from_files = True
+        d = self.dmgr
+        for fname in sorted(os.listdir(self.data_src)):
+            low = fname.lower()
+            if not low.endswith('.csv'):
+                continue
+            name, key = low[:-4], None
+            cut = name.rfind('-')
+            if cut != -1:
+                key = name[cut + 1:]
+                name = name[:cut]
+                key = int(key) if key.isdigit() else key
+            if not d.is_supported(name):
+                continue
+            full = os.path.join(self.data_src, fname)
+            data = np.genfromtxt(full, delimiter=',', skip_header=1)
+            with open(full) as f:
+                cols = f.readline().split(',')
+            units = [c[c.find('(') + 1:c.rfind(')')] for c in cols if '(' in c and c.rfind(')') > c.find('(')]
+            units = units if len(units) == len(cols) else None
+            if name in ('ref_pos', 'pos') and self.ref_frame == 1 and units in (['deg', 'deg', 'm'], ['rad', 'rad', 'm']):
+                raise NotImplementedError('LLA -> local-frame conversion of logged positions is outside the hot path')
+            d.add_data(name, data, key, units)
+        if self.amgr.algo is not None:
+            d.set_algo_output(self.amgr.output)
+            inputs = d.get_data(self.amgr.input)
+            out = self.amgr.run_algo(inputs, range(self.sim_count))
+            for j, oname in enumerate(self.amgr.output):
+                d.add_data(oname, out[j])
+
+    # ------------------------------------------------------------------------------------ results
+    def results(self, data_dir=None, err_stats_start=0, gen_kml=False, extra_opt='', *, max_saved_runs=16):
+        """Sim.results (ins_sim.py:194-251).  CSV files are written for at most ``max_saved_runs`` Monte-Carlo runs."""
+        if not self.sim_complete:
+            print("Call Sim.run() to run the simulaltion first.")
+            return None
+        data_saved = []
+        if data_dir is not None:
+            data_dir = self._check_data_dir(data_dir)
+            data_saved = self.dmgr.save_data(data_dir, max_runs=max_saved_runs)
+        if gen_kml is True:
+            self.dmgr.save_kml_files(data_dir)
+        self._summary(data_dir, data_saved, err_stats_start, extra_opt)
+        self.sim_results = True
+        return self.dmgr.available
+
+    def _summary(self, data_dir, data_saved, err_stats_start=0, extra_opt=''):
+        """Same text as Sim.__summary (ins_sim.py:339-413)."""
+        d = self.dmgr
+        line = '\n------------------------------------------------------------\n'
+        s = line
+        s += d.fs.description + ': [' + d.fs.name + '] = ' + str(d.fs.data) + ' ' + d.fs.units[0] + '\n'
+        s += d.ref_frame.description + ': ' + str(d.ref_frame.data) + '\n'
+        s += 'Simulation time duration: ' + str(len(d.time.data) / d.fs.data) + ' s' + '\n'
+        s += 'Simulation runs: ' + str(self.sim_count) + '\n'
+        if data_dir is not None:
+            s += line + 'Simulation results are saved to ' + data_dir + '\n' + 'The following results are saved:\n'
+            for i in data_saved:
+                s += '\t' + i + ': ' + d.get_data_all(i).description + '\n'
+        header = False
+        self.err_stats = {}
+        for data_name, kind in self.interested_error.items():
+            if data_name not in d.available or self.mc is None:
+                continue
+            st = d.get_error_stats(data_name, err_stats_start=err_stats_start, angle=(kind == 'angle'),
+                                   use_output_units=True, extra_opt=extra_opt)
+            if st is None:
+                continue
+            self.err_stats[data_name] = st
+            if not header:
+                header = True
+                s += line + 'The following are error statistics.'
+            s += '\n-----------statistics for ' + d.get_data_all(data_name).description + \
+                 ' (in units of ' + st['units'] + ')\n'
+            if isinstance(st['max'], dict):
+                for k in sorted(st['max'].keys()):
+                    s += '\tSimulation run ' + str(k) + ':\n'
+                    s += '\t\t--Max error: ' + str(st['max'][k]) + '\n'
+                    s += '\t\t--Avg error: ' + str(st['avg'][k]) + '\n'
+                    s += '\t\t--Std of error: ' + str(st['std'][k]) + '\n'
+            else:
+                s += '\t--Max error: ' + str(st['max']) + '\n'
+                s += '\t--Avg error: ' + str(st['avg']) + '\n'
+                s += '\t--Std of error: ' + str(st['std']) + '\n'
+        self.sum += s
+        if self._dist()[0] == 0:
+            print(self.sum)
+            if data_dir is not None:
+                try:
+                    with open(data_dir + '//summary.txt', 'w') as f:
+                        f.write(self.sum + '\n')
+                except Exception:
+                    raise IOError('Unable to save summary to %s.' % data_dir)
+
+    def plot(self, what_to_plot, sim_idx=None, opt=None, extra_opt=''):
+        raise NotImplementedError('plotting is outside the accelerated hot path (SURVEY.md section 2, #17)')
+
+    def get_names_of_available_data(self):
+        return self.dmgr.available
+
+    def get_data(self, data_names):
+        return self.dmgr.get_data(data_names).copy()
+
+    def get_data_properties(self, data_name):
+        return self.dmgr.get_data_properties(data_name)
+
+    # ------------------------------------------------------------------------------------ helpers
+    @staticmethod
+    def _parse_mode(mode):
+        """Sim.__parse_mode (ins_sim.py:612-640)."""
+        if mode is None or isinstance(mode, str):
+            return high_mobility
+        if isinstance(mode, np.ndarray):
+            if mode.shape != (3,):
+                raise TypeError('mode should be of size (3,)')
+            m = mode.astype(np.float64)
+            m[1] *= attitude.D2R
+            m[2] *= attitude.D2R
+            return m
+        raise TypeError('mode should be a string or a numpy array of size (3,)')
+
+    @staticmethod
+    def _check_data_dir(data_dir):
+        """Sim.__check_data_dir (ins_sim.py:703-727)."""
+        if data_dir == '':
+            data_dir = os.path.join(os.path.abspath('.//demo_saved_data//'),
+                                    time.strftime('%Y-%m-%d-%H-%M-%S', time.localtime()))
+        data_dir = os.path.abspath(data_dir)
+        if not os.path.exists(data_dir):
+            try:
+                os.makedirs(data_dir)
+            except Exception:
+                raise IOError('Cannot create dir: %s.' % data_dir)
+        return data_dir

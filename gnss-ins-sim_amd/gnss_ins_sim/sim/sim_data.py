@@ -1,0 +1,169 @@
+"""Named data series with units, interface-compatible with the reference's ``Sim_data``
+(gnss_ins_sim/sim/sim_data.py:13-260): ``name/description/units/output_units/legend/data``,
+``add_data``, ``save_to_file`` (same CSV header + np.savetxt format) and ``convert_unit``.
+
+``data`` may be a scalar, an ndarray, a dict of arrays, or -- for Monte-Carlo series that live on the
+GPU -- a ``McSeries``: a read-only mapping run-key -> (n,k) array that pulls a run out of HBM on demand.
+"""
+from collections import OrderedDict
+from collections.abc import Mapping
+
+import numpy as np
+
+from ..attitude import attitude
+
+_SCALES = {('deg', 'rad'): attitude.D2R, ('deg/s', 'rad/s'): attitude.D2R, ('deg/hr', 'rad/s'): attitude.D2R / 3600.0,
+           ('rad', 'deg'): 1.0 / attitude.D2R, ('rad/s', 'deg/s'): 1.0 / attitude.D2R,
+           ('rad/s', 'deg/hr'): 3600.0 / attitude.D2R}
+
+
+def unit_conversion_scale(src_unit, dst_unit):
+    """sim_data.unit_conversion_scale (sim_data.py:208-233)."""
+    scale = np.ones(len(dst_unit))
+    for i, (s, d) in enumerate(zip(src_unit, dst_unit)):
+        if (s, d) in _SCALES:
+            scale[i] = _SCALES[(s, d)]
+        elif s != d:
+            print('Cannot convert unit from %s in %s to %s.' % (s, src_unit, d))
+    return scale
+
+
+def convert_unit_ndarray_scalar(x, scale):
+    """sim_data.convert_unit_ndarray_scalar (sim_data.py:235-260); never modifies its input."""
+    m = scale.shape[0]
+    if isinstance(x, np.ndarray):
+        if x.ndim == 2:
+            k = min(m, x.shape[1])
+            x = x.copy()
+            x[:, :k] = x[:, :k] * scale[:k]
+            return x
+        if x.ndim == 1:
+            return x * scale if len(x) == m else x * scale[0]
+        raise ValueError('Input x should be a scalar, 1D or 2D array, ndim = %s' % x.ndim)
+    if isinstance(x, (int, float, np.floating, np.integer)):
+        return x * scale[0]
+    raise ValueError('Input x should be a scalar, 1D or 2D array')
+
+
+def convert_unit(data, src_unit, dst_unit):
+    """sim_data.convert_unit (sim_data.py:187-206)."""
+    scale = unit_conversion_scale(src_unit, dst_unit)
+    if isinstance(data, Mapping):
+        return {k: convert_unit_ndarray_scalar(data[k], scale) for k in data}
+    return convert_unit_ndarray_scalar(data, scale)
+
+
+class McSeries(Mapping):
+    """Read-only mapping  key -> ndarray  over a Monte-Carlo series resident in GPU memory.
+
+    ``fetch(list_of_positions) -> (k, n, ncomp) ndarray`` pulls runs out of the device buffer
+    (ginsim_gather_runs).  Keys are produced by ``key_of(position)``: the integer run id for sensor
+    series (dmgr.accel.data[i], ins_sim.py:493) or '<algo>_<run>' for algorithm outputs
+    (ins_algo_manager.py:95).  A small LRU keeps recently used runs on the host.
+    """
+
+    def __init__(self, count, fetch, key_of=None, pos_of=None, squeeze=False, cache=64):
+        self._count, self._fetch, self._squeeze = int(count), fetch, squeeze
+        self._key_of = key_of or (lambda i: i)
+        self._pos_of = pos_of or (lambda k: k if isinstance(k, (int, np.integer)) and 0 <= k < self._count else None)
+        self._cache, self._cap = OrderedDict(), cache
+
+    def __len__(self):
+        return self._count
+
+    def __iter__(self):
+        return (self._key_of(i) for i in range(self._count))
+
+    def __contains__(self, key):
+        try:
+            return self._pos_of(key) is not None
+        except Exception:
+            return False
+
+    def __getitem__(self, key):
+        if key in self._cache:
+            self._cache.move_to_end(key)
+            return self._cache[key]
+        pos = self._pos_of(key) if self.__contains__(key) else None
+        if pos is None:
+            raise KeyError(key)
+        a = self._fetch([pos])[0]
+        if self._squeeze:
+            a = a[:, 0]
+        self._cache[key] = a
+        if len(self._cache) > self._cap:
+            self._cache.popitem(last=False)
+        return a
+
+    def copy(self):
+        return self
+
+    def take(self, positions):
+        """Several runs at once: (k, n, ncomp)."""
+        a = self._fetch(list(positions))
+        return a[:, :, 0] if self._squeeze else a
+
+
+class Sim_data(object):
+    def __init__(self, name, description, units=None, output_units=None, plottable=True, logx=False, logy=False,
+                 grid='on', legend=None):
+        self.name, self.description = name, description
+        self.units = [''] if units is None else list(units)
+        if output_units is None:
+            self.output_units = self.units
+        else:
+            self.output_units = list(output_units)
+            while len(self.output_units) < len(self.units):
+                self.output_units.append(self.units[len(self.output_units)])
+            while len(self.units) < len(self.output_units):
+                self.units.append(self.output_units[len(self.units)])
+        self.plottable, self.logx, self.logy = plottable, logx, logy
+        self.grid = grid if grid.lower() == 'off' else 'on'
+        self.legend = legend
+        self.data = {}
+
+    def add_data(self, data, key=None, units=None):
+        """Sim_data.add_data (sim_data.py:77-115)."""
+        if units is not None:
+            units = list(units)
+            if len(units) != len(self.units):
+                print(units)
+                print(self.units)
+                raise ValueError('Units are of different lengths.')
+            if units != self.units:
+                data = convert_unit(data, units, self.units)
+        if key is None:
+            self.data = data
+        else:
+            if not isinstance(self.data, dict):
+                self.data = {}
+            self.data[key] = data
+
+    def _header(self, cols):
+        if cols > 0:
+            parts = []
+            for i in range(cols):
+                unit = ' (' + self.output_units[i] + ')' if i < len(self.output_units) else ''
+                label = self.legend[i] if (self.legend is not None and cols == len(self.legend)) else self.name + '_' + str(i)
+                parts.append(label + unit)
+            return ','.join(parts)
+        return self.name + (' (' + self.output_units[0] + ')' if len(self.output_units) > 0 else '')
+
+    def save_to_file(self, data_dir, keys=None):
+        """Sim_data.save_to_file (sim_data.py:117-165): '<name>[-<key>].csv', header 'legend (unit)',
+        np.savetxt default %.18e.  ``keys`` limits which runs of a keyed series are written."""
+        if isinstance(self.data, Mapping):
+            for k in (self.data if keys is None else [k for k in keys if k in self.data]):
+                a = np.asarray(self.data[k])
+                cols = a.shape[1] if a.ndim > 1 else 0
+                np.savetxt(data_dir + '//' + self.name + '-' + str(k) + '.csv',
+                           convert_unit(a, self.units, self.output_units), header=self._header(cols),
+                           delimiter=',', comments='')
+        else:
+            a = np.asarray(self.data)
+            cols = a.shape[1] if a.ndim > 1 else 0
+            np.savetxt(data_dir + '//' + self.name + '.csv', convert_unit(a, self.units, self.output_units)
+                       if a.ndim > 0 else np.atleast_1d(a), header=self._header(cols), delimiter=',', comments='')
+
+    def plot(self, *args, **kwargs):
+        raise NotImplementedError('plotting is outside the accelerated hot path (SURVEY.md section 2, #17)')

@@ -93,7 +93,7 @@ typedef struct {
     uint64_t seed;          /* Philox key */
     double   fs;
     int32_t  ref_frame;     /* 0 NED/LLA (free_integration.py:117-172), 1 virtual inertial (:83-116) */
-    int32_t  algo_mask;     /* GINSIM_ALGO_* bits; both algorithms see the same sensor realisation */
+    int32_t  algo_mask;     /* GINSIM_ALGO_* bits; both algorithms see the same sensor realisation; 0 = sensors only */
     int32_t  earth_rot;     /* FreeIntegration(earth_rot=...) (free_integration.py:19, 150-152) */
     int32_t  n_ini;         /* columns of the initial-state table (free_integration.py:42-61) */
     uint64_t ini_first;     /* value of FreeIntegration.run_times before this batch (free_integration.py:69, 85-87) */

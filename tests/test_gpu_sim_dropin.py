@@ -1,0 +1,108 @@
+"""The drop-in surface on the GPU: the calling sequence of the reference's demo_free_integration.py, verbatim
+except for the motion-profile path, reproduces the statistics the UNMODIFIED reference printed for the same
+injected noise (golden t3_demo_rf1: Sim.run(4), algorithm=[odo, free], ref_frame=1)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, PKG, assert_traj_close
+
+pytestmark = pytest.mark.gpu
+D2R = math.pi / 180
+
+
+def _demo_imu():
+    return {'gyro_b': np.array([0.0, 0.0, 0.0]),
+            'gyro_arw': np.array([0.25, 0.25, 0.25]) * 1.0,
+            'gyro_b_stability': np.array([3.5, 3.5, 3.5]) * 1.0,
+            'gyro_b_corr': np.array([100.0, 100.0, 100.0]),
+            'accel_b': np.array([0.0e-3, 0.0e-3, 0.0e-3]),
+            'accel_vrw': np.array([0.03119, 0.03009, 0.04779]) * 1.0,
+            'accel_b_stability': np.array([4.29e-5, 5.72e-5, 8.02e-5]) * 1.0,
+            'accel_b_corr': np.array([200.0, 200.0, 200.0]),
+            'mag_std': np.array([0.2, 0.2, 0.2]) * 1.0}
+
+
+def test_demo_free_integration_sequence(capsys):
+    from gnss_ins_sim.sim import imu_model
+    from gnss_ins_sim.sim import ins_sim
+    from demo_algorithms import free_integration_odo
+    from demo_algorithms import free_integration
+    g = load_golden('t3_demo_rf1')
+    fs = 100.0
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    imu = imu_model.IMU(accuracy=_demo_imu(), axis=6, gps=False, odo=True, odo_opt={'scale': 0.999, 'stdv': 0.1})
+    ini_pos_vel_att = np.genfromtxt(csv, delimiter=',', skip_header=1, max_rows=1)
+    ini_pos_vel_att[0] = ini_pos_vel_att[0] * D2R
+    ini_pos_vel_att[1] = ini_pos_vel_att[1] * D2R
+    ini_pos_vel_att[6:9] = ini_pos_vel_att[6:9] * D2R
+    algo1 = free_integration_odo.FreeIntegration(ini_pos_vel_att)
+    algo2 = free_integration.FreeIntegration(ini_pos_vel_att)
+    sim = ins_sim.Sim([fs, 0.0, 0.0], csv, ref_frame=1, imu=imu, mode=None, env=None, algorithm=[algo1, algo2],
+                      seed=int(g['seed']))
+    sim.run(int(g['R']))
+    avail = sim.results(err_stats_start=-1, gen_kml=True)
+    text = capsys.readouterr().out
+    assert 'Simulation runs: 4' in text and 'The following are error statistics.' in text
+    assert 'Simulation run algo0:' in text and 'Simulation run algo1:' in text
+    for name in ('att_euler', 'pos', 'vel', 'accel', 'gyro', 'odo', 'ref_pos', 'att_quat', 'ref_att_quat'):
+        assert name in avail, name
+    # statistics == what the reference computed on the same noise
+    for dn in ('att_euler', 'pos', 'vel'):
+        st = sim.err_stats[dn]
+        for s in ('max', 'avg', 'std'):
+            for grp in ('algo0', 'algo1'):
+                np.testing.assert_allclose(st[s][grp], g['stat_%s_%s_%s' % (dn, s, grp)], rtol=1e-6, atol=1e-11)
+    # data views: per-run arrays exactly like dmgr.<series>.data[key] of the reference
+    k = g['rows']
+    d = sim.dmgr
+    assert len(d.accel.data) == 4 and list(d.accel.data.keys()) == [0, 1, 2, 3]
+    for r in range(4):
+        np.testing.assert_allclose(d.accel.data[r][k], g['accel'][r], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(d.gyro.data[r][k], g['gyro'][r], rtol=0, atol=1e-14)
+        np.testing.assert_allclose(d.odo.data[r][k], g['odo'][r], rtol=0, atol=1e-12)
+        assert_traj_close(d.att_euler.data['algo0_%d' % r][k], d.pos.data['algo0_%d' % r][k], d.vel.data['algo0_%d' % r][k],
+                          g['odo_att'][r], g['odo_pos'][r], g['odo_vel'][r], rtol=1e-9, what='odo')
+        assert_traj_close(d.att_euler.data['algo1_%d' % r][k], d.pos.data['algo1_%d' % r][k], d.vel.data['algo1_%d' % r][k],
+                          g['fi_att'][r], g['fi_pos'][r], g['fi_vel'][r], rtol=1e-9, what='fi')
+    assert d.att_quat.data['algo1_2'].shape == (1000, 4)
+    assert 'algo1_4' not in d.pos.data and 7 not in d.accel.data
+    assert algo1.run_times == 4 and algo2.run_times == 4
+    data = sim.get_data(['ref_frame', 'fs', 'gyro'])
+    assert data[0] == 1 and data[1] == fs and data[2][3].shape == (1000, 3)
+
+
+def test_plugin_run_given_data_like_openimu_demo():
+    """demo_free_integration_openimu.py recipe: plugin.run() on logged data, ref_frame 0, external gravity."""
+    from demo_algorithms import free_integration
+    g = load_golden('t1_fixture_bosch')
+    algo = free_integration.FreeIntegration(g['ini'], earth_rot=False)
+    algo.run([0, 100.0, g['gyro'], g['accel']])
+    att, pos, vel = algo.get_results()
+    k = g['rows']
+    assert_traj_close(att[k], pos[k], vel[k], g['att_extg'], g['pos_extg'], g['vel_extg'], rtol=1e-10)
+
+
+def test_stats_only_large_run_and_seed_convention():
+    """65 536 runs, keep_trajectories=False: statistics only; np.random.seed() makes it repeatable."""
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    ini = np.genfromtxt(csv, delimiter=',', skip_header=1, max_rows=1)
+    ini[0:2] *= D2R
+    ini[6:9] *= D2R
+    out = []
+    for _ in range(2):
+        np.random.seed(5)
+        imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False)
+        sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, algorithm=free_integration.FreeIntegration(ini),
+                          keep_trajectories=False)
+        sim.run(65536)
+        sim.results(err_stats_start=-1)
+        out.append(sim.err_stats)
+    np.testing.assert_array_equal(out[0]['vel']['std'], out[1]['vel']['std'])
+    att_std = out[0]['att_euler']['std']
+    assert np.all(np.abs(att_std - 0.01318) < 0.01318 * 0.03), att_std          # ARW*sqrt(T), deg
+    assert 'accel' not in sim.dmgr.available
