@@ -1,0 +1,122 @@
+// Lean fp64 elementary functions for the MC kernel, specialised to the argument ranges the kernel needs.
+//
+// ROCm's OCML double-precision log / sincos / sincospi are <1 ulp and pay for it with double-double
+// arithmetic and a Payne-Hanek large-argument path (~1000 v_add_f64 in the first build of mc_kernel).
+// The kernel only needs:
+//   * log(u) for a uniform u in (0,1]               -> Box-Muller radius
+//   * sin/cos(pi*x) for x = 2u in (0,2)             -> Box-Muller angle
+//   * sin/cos(a + d) from sin/cos(a) for small |d|  -> Euler-angle attitude propagation
+// Errors are a few ulp (validated against libm in tests/test_fastmath.py through the probe entry point);
+// the engine's parity tolerances are 1e-12..1e-9.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ginsim {
+
+#define GINSIM_FM __device__ __forceinline__
+
+// 1/x to ~1 ulp: hardware v_rcp_f64 estimate + two Newton steps.
+GINSIM_FM double rcp_nr(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+// Natural log for 0 < u <= 1 (normal, not denormal: u >= 2^-54 by construction of uniform53).
+//   u = m * 2^e, m in [sqrt(1/2), sqrt(2));  ln u = e ln2 + 2 atanh(s),  s = (m-1)/(m+1),  |s| <= 0.1716
+// The exponent/mantissa split is done on the high word with integer arithmetic only (no compare/select):
+// adding (0x3ff00000 - 0x3fe6a09e) moves the sqrt(1/2) boundary onto an exponent boundary.
+GINSIM_FM double log_u01(double u) {
+    uint32_t hx = (uint32_t)__double2hiint(u) + (0x3ff00000u - 0x3fe6a09eu);
+    const int e = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    const double m = __hiloint2double((int)hx, __double2loint(u));
+    const double num = m - 1.0, den = m + 1.0;
+    const double y = rcp_nr(den);
+    double s = num * y;
+    s = __builtin_fma(__builtin_fma(-den, s, num), y, s);   // one correction step: s = num/den to ~1 ulp
+    const double t = s * s;
+    // atanh(s)/s = sum t^k/(2k+1); t <= 0.02944 -> k = 10 leaves 2e-17
+    double p = 1.0 / 21.0;
+    p = __builtin_fma(p, t, 1.0 / 19.0);
+    p = __builtin_fma(p, t, 1.0 / 17.0);
+    p = __builtin_fma(p, t, 1.0 / 15.0);
+    p = __builtin_fma(p, t, 1.0 / 13.0);
+    p = __builtin_fma(p, t, 1.0 / 11.0);
+    p = __builtin_fma(p, t, 1.0 / 9.0);
+    p = __builtin_fma(p, t, 1.0 / 7.0);
+    p = __builtin_fma(p, t, 1.0 / 5.0);
+    p = __builtin_fma(p, t, 1.0 / 3.0);
+    const double s2 = s + s;
+    const double lnm = __builtin_fma(s2 * t, p, s2);          // 2s + 2s t p
+    const double ed = (double)e;
+    // ln2 split so that ed * ln2_hi is exact for |e| < 2^10
+    return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lnm));
+}
+
+// sin/cos of theta for |theta| <= pi/4 (Taylor, truncation < 5e-17 / 2e-18)
+GINSIM_FM void sincos_q(double th, double& s, double& c) {
+    const double t = th * th;
+    double ps = -1.0 / 1307674368000.0;                        // -1/15!
+    ps = __builtin_fma(ps, t, 1.0 / 6227020800.0);             //  1/13!
+    ps = __builtin_fma(ps, t, -1.0 / 39916800.0);              // -1/11!
+    ps = __builtin_fma(ps, t, 1.0 / 362880.0);                 //  1/9!
+    ps = __builtin_fma(ps, t, -1.0 / 5040.0);
+    ps = __builtin_fma(ps, t, 1.0 / 120.0);
+    ps = __builtin_fma(ps, t, -1.0 / 6.0);
+    s = __builtin_fma(th * t, ps, th);
+    double pc = 1.0 / 20922789888000.0;                        //  1/16!
+    pc = __builtin_fma(pc, t, -1.0 / 87178291200.0);           // -1/14!
+    pc = __builtin_fma(pc, t, 1.0 / 479001600.0);              //  1/12!
+    pc = __builtin_fma(pc, t, -1.0 / 3628800.0);               // -1/10!
+    pc = __builtin_fma(pc, t, 1.0 / 40320.0);
+    pc = __builtin_fma(pc, t, -1.0 / 720.0);
+    pc = __builtin_fma(pc, t, 1.0 / 24.0);
+    pc = __builtin_fma(pc, t, -0.5);
+    c = __builtin_fma(t, pc, 1.0);
+}
+
+// sin(pi x), cos(pi x) for 0 <= x <= 2.  2x = k + r, k integer, |r| <= 1/2 (exact), angle = k pi/2 + r pi/2.
+GINSIM_FM void sincospi_02(double x, double& s, double& c) {
+    const double x2 = x + x;
+    const double kd = __builtin_rint(x2);
+    const double r = x2 - kd;                                   // exact
+    const int k = (int)kd;
+    // theta = r * pi/2 with a two-term constant so the product carries ~1 ulp of the angle
+    const double th = __builtin_fma(r, 1.57079632679489655800e+00, r * 6.12323399573676603587e-17);
+    double sq, cq;
+    sincos_q(th, sq, cq);
+    const bool swap = (k & 1) != 0;
+    const double ss = swap ? cq : sq;
+    const double cc = swap ? sq : cq;
+    // negate through the sign bit: sin flips for k in {2,3}, cos for k in {1,2} (mod 4)
+    s = __hiloint2double(__double2hiint(ss) ^ ((k & 2) << 30), __double2loint(ss));
+    c = __hiloint2double(__double2hiint(cc) ^ (((k + 1) & 2) << 30), __double2loint(cc));
+}
+
+// Rotate (s,c) = (sin a, cos a) by a small angle d: returns sin/cos(a+d).  Valid for |d| <= 0.25 rad
+// (truncation < 3e-18); callers fall back to an exact sincos for larger steps.
+GINSIM_FM void rotate_sincos(double d, double& s, double& c) {
+    const double t = d * d;
+    double ps = -1.0 / 39916800.0;                              // -1/11!
+    ps = __builtin_fma(ps, t, 1.0 / 362880.0);
+    ps = __builtin_fma(ps, t, -1.0 / 5040.0);
+    ps = __builtin_fma(ps, t, 1.0 / 120.0);
+    ps = __builtin_fma(ps, t, -1.0 / 6.0);
+    const double sd = __builtin_fma(d * t, ps, d);              // sin d
+    double pc = 1.0 / 479001600.0;                              // 1/12!
+    pc = __builtin_fma(pc, t, -1.0 / 3628800.0);
+    pc = __builtin_fma(pc, t, 1.0 / 40320.0);
+    pc = __builtin_fma(pc, t, -1.0 / 720.0);
+    pc = __builtin_fma(pc, t, 1.0 / 24.0);
+    pc = __builtin_fma(pc, t, -0.5);
+    const double cm1 = t * pc;                                  // cos d - 1
+    const double s0 = s, c0 = c;
+    s = __builtin_fma(c0, sd, __builtin_fma(s0, cm1, s0));      // s + s (cos d - 1) + c sin d
+    c = __builtin_fma(-s0, sd, __builtin_fma(c0, cm1, c0));     // c + c (cos d - 1) - s sin d
+}
+
+}  // namespace ginsim

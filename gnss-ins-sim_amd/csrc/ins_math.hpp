@@ -7,10 +7,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include "fastmath.hpp"
 
 namespace ginsim {
 
-#define GINSIM_HD __host__ __device__ __forceinline__
+#define GINSIM_HD __device__ __forceinline__
 
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kTwoPi = 2.0 * kPi;
@@ -24,6 +25,7 @@ constexpr double kWie = 7292115e-11;
 constexpr double kG0 = 9.7803253359;
 constexpr double kGk = 0.00193185265241;
 constexpr double kGm = 0.00344978650684;
+constexpr int kTrigResync = 32;   // exact sincos of the attitude (and latitude) every this many steps
 
 struct Vec3 { double x, y, z; };
 
@@ -33,18 +35,26 @@ GINSIM_HD Vec3 cross3(const Vec3& a, const Vec3& b) {   // attitude.cross3, atti
 
 struct Geo { double rm, rn, g, sl, cl; };
 
-// geoparams.geo_param, geoparams.py:25-53
-GINSIM_HD Geo geo_param(double lat, double h) {
+// geoparams.geo_param, geoparams.py:25-53, with sin/cos(lat) supplied by the caller.  The three divisions by
+// sqrt(1 - e^2 sin^2) become one reciprocal (Newton-refined v_rcp_f64) and products.
+GINSIM_HD Geo geo_param_sc(double sl, double cl, double h) {
     Geo o;
-    sincos(lat, &o.sl, &o.cl);
-    const double s2 = o.sl * o.sl;
+    o.sl = sl;
+    o.cl = cl;
+    const double s2 = sl * sl;
     const double q = 1.0 - kEsq * s2;
-    const double w = sqrt(q);
-    o.rm = (kRe * (1.0 - kEsq)) / (w * q);
-    o.rn = kRe / w;
-    const double g1 = kG0 * (1.0 + kGk * s2) / w;
-    o.g = g1 * (1.0 - (2.0 / kRe) * (1.0 + kFlat + kGm - 2.0 * kFlat * s2) * h + 3.0 * h * h / kRe / kRe);
+    const double iw = rcp_nr(sqrt(q));
+    o.rn = kRe * iw;
+    o.rm = (kRe * (1.0 - kEsq)) * iw * (iw * iw);
+    const double g1 = kG0 * (1.0 + kGk * s2) * iw;
+    o.g = g1 * (1.0 - (2.0 / kRe) * (1.0 + kFlat + kGm - 2.0 * kFlat * s2) * h + (3.0 / (kRe * kRe)) * (h * h));
     return o;
+}
+
+GINSIM_HD Geo geo_param(double lat, double h) {
+    double sl, cl;
+    sincos(lat, &sl, &cl);
+    return geo_param_sc(sl, cl, h);
 }
 
 // geoparams.lla2ecef, geoparams.py:70-87
@@ -82,21 +92,39 @@ struct Att {
     // first row of the n->b DCM: C^T . [1,0,0]
     GINSIM_HD Vec3 fwd_in_nav() const { return Vec3{cp * cy, cp * sy, -sp}; }
 
-    // attitude.euler_update_zyx, attitude.py:679-721, then refresh the cached trig
-    GINSIM_HD void step(const Vec3& w, double dt) {
+    // attitude.euler_update_zyx, attitude.py:679-721, then refresh the cached trig.
+    // The angles themselves are propagated exactly as the reference does; their cached sin/cos are ROTATED by
+    // the step (angle-addition with short sin/cos(d) series, fastmath.hpp) instead of re-evaluated, and are
+    // re-evaluated exactly when `resync` is set (every kTrigResync steps, wave-uniform), when the pitch folds
+    // over +-pi/2, or when a step exceeds 0.25 rad.  +-2pi wraps leave the trig untouched.
+    GINSIM_HD void step(const Vec3& w, double dt, bool resync) {
         const double q = w.z * cr + w.y * sr;
-        const double icp = 1.0 / cp;
-        double y = yaw + q * icp * dt;
-        double p = pit + (w.y * cr - w.z * sr) * dt;
-        double r = rol + (w.x + q * (sp * icp)) * dt;
-        if (p > kHalfPi) {
-            p = kPi - p; y += kPi; r += kPi;
-        } else if (p < -kHalfPi) {
-            p = -kPi - p; y += kPi; r += kPi;
+        const double icp = rcp_nr(cp);
+        const double dy = q * icp * dt;
+        const double dp = (w.y * cr - w.z * sr) * dt;
+        const double dr = (w.x + q * (sp * icp)) * dt;
+        double y = yaw + dy;
+        double p = pit + dp;
+        double r = rol + dr;
+        const bool fold = (p > kHalfPi) || (p < -kHalfPi);
+        const double big = fmax(fabs(dy), fmax(fabs(dp), fabs(dr)));
+        if (resync || fold || !(big <= 0.25)) {
+            if (p > kHalfPi) {
+                p = kPi - p; y += kPi; r += kPi;
+            } else if (p < -kHalfPi) {
+                p = -kPi - p; y += kPi; r += kPi;
+            }
+            if (y > kPi) y -= kTwoPi; else if (y < -kPi) y += kTwoPi;
+            if (r > kPi) r -= kTwoPi; else if (r < -kPi) r += kTwoPi;
+            set(y, p, r);
+        } else {
+            rotate_sincos(dy, sy, cy);
+            rotate_sincos(dp, sp, cp);
+            rotate_sincos(dr, sr, cr);
+            if (y > kPi) y -= kTwoPi; else if (y < -kPi) y += kTwoPi;
+            if (r > kPi) r -= kTwoPi; else if (r < -kPi) r += kTwoPi;
+            yaw = y; pit = p; rol = r;
         }
-        if (y > kPi) y -= kTwoPi; else if (y < -kPi) y += kTwoPi;
-        if (r > kPi) r -= kTwoPi; else if (r < -kPi) r += kTwoPi;
-        set(y, p, r);
     }
 };
 

@@ -22,6 +22,20 @@ namespace ginsim {
 
 constexpr int kWave = 64;
 
+// The by-value parameter block sits at offset 0 of the kernarg segment.  Its bulky members (two sensor models,
+// ref_end) are re-read from there with scalar loads where they are used: kept in SGPRs for the whole time loop
+// they overflow the SGPR file and the compiler parks them in VGPR lanes (v_readlane/v_writelane = VALU issue
+// slots, ~14 % of the loop in the first build).  The empty asm makes the pointer opaque per iteration so the
+// loads are not hoisted back out of the loop.
+typedef const ginsim_mc_params __attribute__((address_space(4))) * params_ptr;
+__device__ __forceinline__ params_ptr kernarg_params() {
+    params_ptr p = (params_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+typedef const ginsim_sensor_model __attribute__((address_space(4))) * model_ptr;
+
+
 // One strapdown solution (one algorithm instance of one run).
 struct Nav {
     Att  att;
@@ -29,6 +43,7 @@ struct Nav {
     Vec3 vel;   // navigation-frame velocity of the previous sample
     Vec3 pos;   // ECEF+displacement (ref_frame 1) or LLA (ref_frame 0)
     double g;   // gravity: constant (ref_frame 1) or the external override of ref_frame 0
+    double sl, cl;  // ref_frame 0: cached sin/cos of the latitude pos.x
     bool ext_g; // ref_frame 0: use g instead of the WGS-84 model (free_integration.py:143-146)
 };
 
@@ -44,6 +59,7 @@ __device__ __forceinline__ void nav_init(Nav& s, const double* __restrict__ ini,
     } else {
         s.pos = Vec3{ini[0], ini[1], ini[2]};
         s.g = has_g ? ini[9] : 0.0;
+        sincos(ini[0], &s.sl, &s.cl);
     }
     s.ext_g = has_g != 0;
 }
@@ -52,7 +68,7 @@ __device__ __forceinline__ void nav_init(Nav& s, const double* __restrict__ ini,
 //                 ODO == true : free_integration_odo.py:96-105 (RF 1) / :118-152 (RF 0).
 template <int RF, bool ODO>
 __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& accel, double odo, double dt,
-                                         int earth_rot) {
+                                         int earth_rot, bool resync) {
     if (RF == 1) {
         const Vec3 v_prev = s.vel;
         if (!ODO) {
@@ -62,7 +78,7 @@ __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& a
             s.vb.y += (accel.y + gb.y * s.g) * dt - wxv.y * dt;
             s.vb.z += (accel.z + gb.z * s.g) * dt - wxv.z * dt;
         }
-        s.att.step(gyro, dt);
+        s.att.step(gyro, dt, resync);
         if (ODO) {
             const Vec3 f = s.att.fwd_in_nav();
             s.vel = Vec3{f.x * odo, f.y * odo, f.z * odo};
@@ -73,10 +89,10 @@ __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& a
         s.pos.y += v_prev.y * dt;
         s.pos.z += v_prev.z * dt;
     } else {
-        const Geo e = geo_param(s.pos.x, s.pos.z);
-        const double irm = 1.0 / (e.rm + s.pos.z);
-        const double irn = 1.0 / (e.rn + s.pos.z);
-        const double icl = 1.0 / e.cl;
+        const Geo e = geo_param_sc(s.sl, s.cl, s.pos.z);
+        const double irm = rcp_nr(e.rm + s.pos.z);
+        const double irn = rcp_nr(e.rn + s.pos.z);
+        const double icl = rcp_nr(e.cl);
         const Vec3 v = s.vel;
         const Vec3 w_en{v.y * irn, -v.x * irm, -v.y * e.sl * icl * irn};
         Vec3 w_ie{0.0, 0.0, 0.0};
@@ -90,12 +106,15 @@ __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& a
             const Vec3 cor = cross3(Vec3{2.0 * w_ie.x + w_en.x, 2.0 * w_ie.y + w_en.y, 2.0 * w_ie.z + w_en.z}, v);
             v_new = Vec3{v.x + (an.x - cor.x) * dt, v.y + (an.y - cor.y) * dt, v.z + (an.z + g - cor.z) * dt};
         }
-        s.att.step(w_nb, dt);
+        s.att.step(w_nb, dt, resync);
         if (ODO) {
             const Vec3 f = s.att.fwd_in_nav();
             v_new = Vec3{f.x * odo, f.y * odo, f.z * odo};
         }
-        s.pos.x += v.x * irm * dt;
+        const double dlat = v.x * irm * dt;
+        if (resync || !(fabs(dlat) <= 0.25)) sincos(s.pos.x + dlat, &s.sl, &s.cl);
+        else rotate_sincos(dlat, s.sl, s.cl);
+        s.pos.x += dlat;
         s.pos.y += v.y * irn * icl * dt;
         s.pos.z += -v.z * dt;
         s.vel = v_new;
@@ -120,8 +139,10 @@ __device__ __forceinline__ void store3(double* __restrict__ base, int64_t plane,
     base[2 * plane + off] = v.z;
 }
 
-__device__ __forceinline__ void store_end(double* __restrict__ out, int64_t runs, int64_t r, const Nav& s,
-                                          const double* ref_end) {
+__device__ __forceinline__ void store_end(double* __restrict__ out, int64_t runs, int64_t r, const Nav& s) {
+    const params_ptr kp = kernarg_params();
+    const double ref_end[9] = {kp->ref_end[0], kp->ref_end[1], kp->ref_end[2], kp->ref_end[3], kp->ref_end[4],
+                               kp->ref_end[5], kp->ref_end[6], kp->ref_end[7], kp->ref_end[8]};
     // array_error(angle=True) on the last sample: ins_data_manager.py:537-541
     out[0 * runs + r] = angle_range_pi(s.att.yaw - ref_end[0]);
     out[1 * runs + r] = angle_range_pi(s.att.pit - ref_end[1]);
@@ -134,20 +155,31 @@ __device__ __forceinline__ void store_end(double* __restrict__ out, int64_t runs
     out[8 * runs + r] = s.vel.z - ref_end[8];
 }
 
+// Truth samples are the same for every lane.  Reading them through the constant address space tells the
+// compiler the data are invariant, so a wave-uniform index becomes an s_load (scalar cache, lgkmcnt) instead
+// of a per-lane global_load -- which matters beyond the 64x fewer bytes: vector loads share the vmcnt counter
+// with the trajectory stores, and the s_waitcnt vmcnt(0) guarding them drained every outstanding store once
+// per step (measured: +0.45 ms at 65 536 runs).
+typedef const double __attribute__((address_space(4))) * uniform_ptr;
+__device__ __forceinline__ uniform_ptr as_uniform(const double* p) {
+    return (uniform_ptr)(uintptr_t)p;
+}
+
 // Sensor sample j of one 3-axis sensor: truth + bias + drift + white  (pathgen.py:500, 562), and the
 // Gauss-Markov update d[j+1] = a d[j] + b N[j] (pathgen.py:589-590).
-__device__ __forceinline__ Vec3 sense3(const double* __restrict__ ref, int64_t j, const ginsim_sensor_model& m,
-                                       Vec3& drift, const Vec3& zd, const Vec3& zw) {
-    const double dx = m.white_drift[0] ? m.gm_b[0] * zd.x : drift.x;
-    const double dy = m.white_drift[1] ? m.gm_b[1] * zd.y : drift.y;
-    const double dz = m.white_drift[2] ? m.gm_b[2] * zd.z : drift.z;
+__device__ __forceinline__ Vec3 sense3(uniform_ptr ref, int64_t j, model_ptr m, Vec3& drift, const Vec3& zd,
+                                       const Vec3& zw) {
+    const double bx = m->gm_b[0] * zd.x, by = m->gm_b[1] * zd.y, bz = m->gm_b[2] * zd.z;
+    const double dx = m->white_drift[0] ? bx : drift.x;
+    const double dy = m->white_drift[1] ? by : drift.y;
+    const double dz = m->white_drift[2] ? bz : drift.z;
     Vec3 o;
-    o.x = ref[3 * j + 0] + m.bias[0] + dx + m.white[0] * zw.x;
-    o.y = ref[3 * j + 1] + m.bias[1] + dy + m.white[1] * zw.y;
-    o.z = ref[3 * j + 2] + m.bias[2] + dz + m.white[2] * zw.z;
-    drift.x = m.gm_a[0] * drift.x + m.gm_b[0] * zd.x;
-    drift.y = m.gm_a[1] * drift.y + m.gm_b[1] * zd.y;
-    drift.z = m.gm_a[2] * drift.z + m.gm_b[2] * zd.z;
+    o.x = ref[3 * j + 0] + m->bias[0] + dx + m->white[0] * zw.x;
+    o.y = ref[3 * j + 1] + m->bias[1] + dy + m->white[1] * zw.y;
+    o.z = ref[3 * j + 2] + m->bias[2] + dz + m->white[2] * zw.z;
+    drift.x = __builtin_fma(m->gm_a[0], drift.x, bx);
+    drift.y = __builtin_fma(m->gm_a[1], drift.y, by);
+    drift.z = __builtin_fma(m->gm_a[2], drift.z, bz);
     return o;
 }
 
@@ -197,40 +229,47 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
             // the last sample only exists as sensor output; skip it when nothing stores it
             if (last && !a.out_accel && !a.out_gyro && !a.out_odo) break;
             const uint32_t jj = (uint32_t)j;
-            Vec3 zd, zw;
-            if (FREE || a.out_accel) {
-                normal_pair(key, S_ACC_D_XY, jj, zd.x, zd.y);
-                normal_pair(key, S_ACC_DZ_WX, jj, zd.z, zw.x);
-                normal_pair(key, S_ACC_W_YZ, jj, zw.y, zw.z);
-                acc = sense3(a.ref_accel, j, a.accel, da, zd, zw);
-                if (a.out_accel) store3(a.out_accel, plane, off, acc);
+            const bool need_acc = FREE || a.out_accel;
+            const bool need_gyr = FREE || ODO || a.out_gyro;
+            const bool need_odo = ODO || a.out_odo;
+            if (need_acc && need_gyr) {             // the common case: six streams in one phased batch
+                double z0[6], z1[6];
+                normal_pairs<6>(key, S_ACC_D_XY, jj, z0, z1);
+                const params_ptr kp = kernarg_params();
+                acc = sense3(as_uniform(a.ref_accel), j, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
+                gyr = sense3(as_uniform(a.ref_gyro), j, &kp->gyro, dg, Vec3{z0[3], z1[3], z0[4]}, Vec3{z1[4], z0[5], z1[5]});
+            } else if (need_acc) {
+                double z0[3], z1[3];
+                normal_pairs<3>(key, S_ACC_D_XY, jj, z0, z1);
+                acc = sense3(as_uniform(a.ref_accel), j, &kernarg_params()->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
+            } else if (need_gyr) {
+                double z0[3], z1[3];
+                normal_pairs<3>(key, S_GYR_D_XY, jj, z0, z1);
+                gyr = sense3(as_uniform(a.ref_gyro), j, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             }
-            if (FREE || ODO || a.out_gyro) {
-                normal_pair(key, S_GYR_D_XY, jj, zd.x, zd.y);
-                normal_pair(key, S_GYR_DZ_WX, jj, zd.z, zw.x);
-                normal_pair(key, S_GYR_W_YZ, jj, zw.y, zw.z);
-                gyr = sense3(a.ref_gyro, j, a.gyro, dg, zd, zw);
-                if (a.out_gyro) store3(a.out_gyro, plane, off, gyr);
-            }
-            if (ODO || a.out_odo) {
+            if (need_acc && a.out_accel) store3(a.out_accel, plane, off, acc);
+            if (need_gyr && a.out_gyro) store3(a.out_gyro, plane, off, gyr);
+            if (need_odo) {
                 double z0, z1;
                 normal_pair(key, S_ODO, jj, z0, z1);
-                odo = a.odo_scale * a.ref_odo[j] + a.odo_stdv * z0;     // pathgen.py:639-640
+                const params_ptr kq = kernarg_params();
+                odo = kq->odo_scale * as_uniform(a.ref_odo)[j] + kq->odo_stdv * z0;     // pathgen.py:639-640
                 if (a.out_odo) a.out_odo[off] = odo;
             }
             if (last) break;
         }
+        const bool resync = ((j + 1) & (kTrigResync - 1)) == 0;
         if (FREE) {
-            nav_step<RF, false>(fi, gyr, acc, 0.0, dt, a.earth_rot);
+            nav_step<RF, false>(fi, gyr, acc, 0.0, dt, a.earth_rot, resync);
             if (a.out_traj[0]) store9(a.out_traj[0], plane, off + runs, fi);
         }
         if (ODO) {
-            nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot);
+            nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot, resync);
             if (a.out_traj[1]) store9(a.out_traj[1], plane, off + runs, od);
         }
     }
-    if (FREE && a.out_end[0]) store_end(a.out_end[0], runs, r, fi, a.ref_end);
-    if (ODO && a.out_end[1]) store_end(a.out_end[1], runs, r, od, a.ref_end);
+    if (FREE && a.out_end[0]) store_end(a.out_end[0], runs, r, fi);
+    if (ODO && a.out_end[1]) store_end(a.out_end[1], runs, r, od);
     if (trace) trace[3] = __builtin_amdgcn_s_memtime();
 }
 

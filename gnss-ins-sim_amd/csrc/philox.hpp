@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "fastmath.hpp"
 
 namespace ginsim {
 
@@ -40,8 +41,10 @@ __host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1
 
 // (0,1) uniform with 53 significant bits from two words: ((hi:lo >> 11) + 0.5) * 2^-53
 __host__ __device__ __forceinline__ double uniform53(uint32_t lo, uint32_t hi) {
-    const uint64_t v = (((uint64_t)hi << 32) | lo) >> 11;
-    return ((double)v + 0.5) * 0x1.0p-53;
+    const uint32_t top = hi >> 11;                         // 21 bits
+    const uint32_t low = (hi << 21) | (lo >> 11);          // 32 bits (one v_alignbit_b32)
+    const double v = __builtin_fma((double)top, 4294967296.0, (double)low);     // exact, < 2^53
+    return __builtin_fma(v, 0x1.0p-53, 0x1.0p-54);          // == (v + 0.5) * 2^-53, same rounding
 }
 
 struct RngKey {
@@ -54,11 +57,39 @@ __device__ __forceinline__ void normal_pair(const RngKey& key, uint32_t stream, 
     const u32x4 w = philox4x32_10(j, stream, key.r0, key.r1, key.k0, key.k1);
     const double u1 = uniform53(w.x, w.y);
     const double u2 = uniform53(w.z, w.w);
-    const double r = sqrt(-2.0 * log(u1));
+    const double r = sqrt(-2.0 * log_u01(u1));
     double s, c;
-    sincospi(2.0 * u2, &s, &c);
+    sincospi_02(2.0 * u2, s, c);
     z0 = r * c;
     z1 = r * s;
+}
+
+// N consecutive streams (first, first+1, ...) of one sample, evaluated phase by phase -- all Philox blocks, then
+// all logarithms, then all square roots, then all sin/cos -- instead of N complete Box-Muller transforms in a
+// row.  Each phase is N independent dependency chains (ILP for a lone wavefront on its SIMD) and only ONE
+// polynomial's fp64 constants are live at a time; interleaving the transforms kept ~35 constants (70 SGPRs) live
+// and spilled SGPRs to VGPR lanes (~240 v_readlane/v_writelane per step in the first build).
+template <int N>
+__device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, uint32_t j, double (&z0)[N], double (&z1)[N]) {
+    double u1[N], u2[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const u32x4 w = philox4x32_10(j, first + k, key.r0, key.r1, key.k0, key.k1);
+        u1[k] = uniform53(w.x, w.y);
+        u2[k] = uniform53(w.z, w.w);
+    }
+    double r[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = -2.0 * log_u01(u1[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = sqrt(r[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double s, c;
+        sincospi_02(u2[k] + u2[k], s, c);
+        z0[k] = r[k] * c;
+        z1[k] = r[k] * s;
+    }
 }
 
 }  // namespace ginsim

@@ -23,7 +23,7 @@ for rf in (1, 0):
                 if keep and R * 1000 * 8 * (6 + 9 * len(algos)) > 60e9:
                     continue
                 job = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc, gyr, g['ini_pva'], runs=R, algos=algos,
-                                           odo_err={'scale': 0.999, 'stdv': 0.1}, seed=1, keep_sensors=keep, keep_traj=keep)
+                                           odo_err={'scale': 0.999, 'stdv': 0.1} if 'odo' in algos else None, seed=1, keep_sensors=keep, keep_traj=keep)
                 job.run()
                 ts = []
                 for _ in range(3):
