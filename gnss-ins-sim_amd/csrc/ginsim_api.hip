@@ -2,6 +2,7 @@
 // reporting and the host-buffer convenience entry points.  No kernels here.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -33,6 +34,15 @@ size_t stats_scratch_bytes(int64_t runs);
 int stats_blocks(int64_t runs);
 hipError_t launch_end_stats(const double* end_err, int64_t runs, void* scratch, hipStream_t s);
 void stats_merge_host(const ginsim_stats* parts, int nparts, ginsim_stats* out);
+struct AllanLevel {
+    int64_t n_in, n_out, in_stride, out_stride;
+    int64_t nb[9];
+    int32_t chunks_per_block, nchunks;
+};
+hipError_t launch_allan_level(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries,
+                              double* sums, hipStream_t st);
+int allan_chunks(int64_t n_in);
+int allan_chunks_per_block(int64_t total_chunks);
 
 }  // namespace ginsim
 
@@ -43,7 +53,29 @@ struct ginsim_ctx {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     std::vector<hipEvent_t> pool;   // lazily created, indexed by slot
+    void* ws[4] = {nullptr, nullptr, nullptr, nullptr};   // grow-only scratch regions (stats / allan)
+    size_t ws_bytes[4] = {0, 0, 0, 0};
 };
+
+// grow-only scratch owned by the context: avoids a hipMalloc/hipFree pair (~100 us each) per call
+static hipError_t scratch(ginsim_ctx* c, int slot, size_t bytes, void** out) {
+    if (c->ws_bytes[slot] < bytes) {
+        if (c->ws[slot]) {
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) return e;
+            e = hipFree(c->ws[slot]);
+            if (e != hipSuccess) return e;
+            c->ws[slot] = nullptr;
+            c->ws_bytes[slot] = 0;
+        }
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipMalloc(&c->ws[slot], want);
+        if (e != hipSuccess) return e;
+        c->ws_bytes[slot] = want;
+    }
+    *out = c->ws[slot];
+    return hipSuccess;
+}
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -116,6 +148,8 @@ int ginsim_destroy(ginsim_ctx* c) {
     (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->pool)
         if (e) (void)hipEventDestroy(e);
+    for (void* w : c->ws)
+        if (w) (void)hipFree(w);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return GINSIM_OK;
@@ -251,10 +285,10 @@ int ginsim_mc_run(ginsim_ctx* c, const ginsim_mc_params* p) {
 int ginsim_end_stats(ginsim_ctx* c, const double* end_err, int64_t runs, ginsim_stats* host_out) {
     REQUIRE(c && end_err && host_out && runs >= 1, "end_stats: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
-    DevBuf scratch;
-    HIP_TRY(scratch.alloc(stats_scratch_bytes(runs)));
-    HIP_TRY(launch_end_stats(end_err, runs, scratch.p, c->stream));
-    const char* res = scratch.as<char>() + stats_scratch_bytes(runs) - sizeof(ginsim_stats);
+    void* ws = nullptr;
+    HIP_TRY(scratch(c, 0, stats_scratch_bytes(runs), &ws));
+    HIP_TRY(launch_end_stats(end_err, runs, ws, c->stream));
+    const char* res = reinterpret_cast<char*>(ws) + stats_scratch_bytes(runs) - sizeof(ginsim_stats);
     HIP_TRY(hipMemcpyAsync(host_out, res, sizeof(ginsim_stats), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GINSIM_OK;
@@ -335,6 +369,78 @@ int ginsim_free_integration(ginsim_ctx* c, int32_t algo, int32_t ref_frame, doub
         HIP_TRY(hipMemcpyAsync(host[k], d_out.p, sizeof(double) * plane * 3, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return GINSIM_OK;
+}
+
+int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int64_t series_stride, double fs, double* tau,
+                 double* avar, int32_t* ntau, int32_t cap) {
+    REQUIRE(c && x && tau && avar && ntau, "allan: NULL argument");
+    REQUIRE(n >= 1 && nseries >= 1 && series_stride >= n && fs > 0, "allan: bad sizes");
+    // averaging factors exactly as allan.py:29-43
+    const double ts = 1.0 / fs;
+    const int64_t mmax = (int64_t)floor((double)n / 9.0);
+    *ntau = 0;
+    if ((double)mmax * ts < 1.0) return GINSIM_OK;
+    std::vector<int64_t> mult;
+    const int decades = (int)ceil(log10((double)mmax));
+    double scale = 0.1;
+    for (int i = 0; i < decades; ++i) {
+        scale *= 10;
+        for (int j = 1; j < 10; ++j) {
+            const int64_t m = (int64_t)(j * scale);
+            if (m > mmax) break;
+            mult.push_back(m);
+        }
+    }
+    const int nt = (int)mult.size();
+    if (nt > cap) { set_error("allan: %d averaging factors but capacity %d", nt, cap); return GINSIM_ERR_RANGE; }
+    HIP_TRY(hipSetDevice(c->device));
+    const int levels = decades;
+    const int64_t n1 = n / 10;
+    struct Region { void* p; double* d() const { return reinterpret_cast<double*>(p); } } ping, pong, partial, sums;
+    const size_t b_ping = sizeof(double) * (size_t)nseries * (n1 + 1), b_pong = sizeof(double) * (size_t)nseries * (n1 / 10 + 1);
+    const size_t b_part = sizeof(double) * 9 * (size_t)nseries * allan_chunks(n), b_sums = sizeof(double) * 9 * (size_t)nseries * levels;
+    void* region = nullptr;
+    HIP_TRY(scratch(c, 1, b_ping + b_pong + b_part + b_sums + 1024, &region));
+    ping.p = region;
+    pong.p = reinterpret_cast<char*>(region) + ((b_ping + 255) & ~(size_t)255);
+    partial.p = reinterpret_cast<char*>(pong.p) + ((b_pong + 255) & ~(size_t)255);
+    sums.p = reinterpret_cast<char*>(partial.p) + ((b_part + 255) & ~(size_t)255);
+    const double* in = x;
+    int64_t stride_in = series_stride, n_in = n, pow10 = 1;
+    for (int k = 0; k < levels; ++k) {
+        AllanLevel lv;
+        lv.n_in = n_in;
+        lv.n_out = (k + 1 < levels) ? n_in / 10 : 0;
+        lv.in_stride = stride_in;
+        lv.out_stride = lv.n_out;
+        for (int j = 1; j <= 9; ++j) lv.nb[j - 1] = (j * pow10 <= mmax) ? n / (j * pow10) : 0;
+        lv.nchunks = allan_chunks(n_in);
+        lv.chunks_per_block = allan_chunks_per_block((int64_t)lv.nchunks * nseries);
+        double* out = (k % 2 == 0) ? ping.d() : pong.d();
+        HIP_TRY(launch_allan_level(in, out, partial.d(), lv, nseries, sums.d() + (size_t)9 * nseries * k, c->stream));
+        in = out;
+        stride_in = lv.n_out;
+        n_in = lv.n_out;
+        pow10 *= 10;
+    }
+    std::vector<double> h((size_t)9 * nseries * levels);
+    HIP_TRY(hipMemcpyAsync(h.data(), sums.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nt; ++i) {
+        const int64_t m = mult[i];
+        int k = 0;
+        int64_t p = 1;
+        while (m / p >= 10) { p *= 10; ++k; }
+        const int j = (int)(m / p);
+        const int64_t nb = n / m;
+        tau[i] = (double)m * ts;
+        for (int s = 0; s < nseries; ++s) {
+            const double sum = h[((size_t)k * nseries + s) * 9 + (j - 1)];
+            avar[(size_t)s * cap + i] = 0.5 / (double)(nb - 1) * sum / ((double)m * (double)m);
+        }
+    }
+    *ntau = nt;
     return GINSIM_OK;
 }
 

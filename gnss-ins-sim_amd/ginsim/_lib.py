@@ -82,14 +82,12 @@ _SIGS = {
     'ginsim_free_integration': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, _PD, _PD, _PD,
                                           C.c_int64, C.c_int64, _PD, C.c_int32, C.c_int32, C.c_uint64,
                                           _PD, _PD, _PD]),
+    'ginsim_allan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_double, _PD, _PD,
+                               C.POINTER(C.c_int32), C.c_int32]),
     'ginsim_rng_normals': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, _PD, _PD,
                                      C.POINTER(C.c_uint32)]),
 }
-# entry points added by later ABI revisions are optional here and bound when present
-_OPTIONAL = {
-    'ginsim_allan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, _PD, _PD,
-                               C.POINTER(C.c_int32), C.c_int32]),
-}
+_OPTIONAL = {}
 
 
 def _load():

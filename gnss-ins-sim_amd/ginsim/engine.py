@@ -367,3 +367,26 @@ def rng_normals(ctx, seed, run, stream, count, words=False):
     check(lib.ginsim_rng_normals(ctx.handle, int(seed), int(run), int(stream), int(count), dptr(z0), dptr(z1),
                                  None if w is None else w.ctypes.data_as(C.POINTER(C.c_uint32))))
     return (z0, z1, w) if words else (z0, z1)
+
+
+def allan_var(ctx, x, n, nseries, series_stride, fs, cap=128):
+    """Allan variance of `nseries` device-resident series (DeviceBuffer or raw pointer), allan.py:18-59.
+    Returns (avar (nseries, ntau), tau (ntau,))."""
+    ptr = x.ptr if isinstance(x, DeviceBuffer) else x
+    tau = np.zeros(cap)
+    avar = np.zeros((nseries, cap))
+    nt = C.c_int32(0)
+    check(lib.ginsim_allan(ctx.handle, ptr, int(n), int(nseries), int(series_stride), float(fs), dptr(tau), dptr(avar),
+                           C.byref(nt), cap))
+    return avar[:, :nt.value].copy(), tau[:nt.value].copy()
+
+
+def allan_var_host(ctx, series, fs):
+    """Host arrays in: series (n,) or (S, n).  Uploads, runs the device kernels, returns (avar, tau)."""
+    a = np.ascontiguousarray(np.atleast_2d(np.asarray(series, dtype=np.float64)))
+    buf = ctx.upload(a)
+    try:
+        avar, tau = allan_var(ctx, buf, a.shape[1], a.shape[0], a.shape[1], fs)
+    finally:
+        buf.free()
+    return (avar[0], tau) if np.ndim(series) == 1 else (avar, tau)

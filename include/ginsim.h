@@ -147,6 +147,14 @@ int ginsim_free_integration(ginsim_ctx* ctx, int32_t algo, int32_t ref_frame, do
                             const double* ini, int32_t n_ini, int32_t ini_has_g, uint64_t ini_first,
                             double* att, double* pos, double* vel);
 
+/* ---- Allan variance: allan.allan_var (gnss_ins_sim/allan/allan.py:18-59) for a batch of series, as the Allan
+ *      plugin applies it to each sensor axis (demo_algorithms/allan_analysis.py:33-49).
+ *      x: device pointer, series s occupies x[s*series_stride .. +n).  Outputs (host): tau[cap] and
+ *      avar[nseries][cap] (Allan VARIANCE; the plugin reports its square root); *ntau = number of averaging
+ *      factors (0 when the series is shorter than 9 s, allan.py:30-31). */
+int ginsim_allan(ginsim_ctx* ctx, const double* x, int64_t n, int32_t nseries, int64_t series_stride, double fs,
+                 double* tau, double* avar, int32_t* ntau, int32_t cap);
+
 /* ---- RNG self-test hook: first `count` normal pairs of (seed, run, stream) computed ON DEVICE ---- */
 int ginsim_rng_normals(ginsim_ctx* ctx, uint64_t seed, uint64_t run, uint32_t stream, int64_t count,
                        double* host_z0, double* host_z1, uint32_t* host_words /*[count][4] or NULL*/);

@@ -1,0 +1,75 @@
+"""On-device Allan variance vs the reference's allan.allan_var (golden) and vs the oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import ginsim
+    c = ginsim.Context(0)
+    yield c
+    c.close()
+
+
+def _series(seed, n):
+    from oracle import philox
+    j = np.arange(n, dtype=np.uint64)
+    return 0.3 * philox.normal_pair(seed, 7, 5, j)[0] + 1e-3 * np.cumsum(philox.normal_pair(seed, 7, 4, j)[1])
+
+
+def test_allan_matches_reference_golden(ctx):
+    import ginsim
+    g = load_golden('allan_ref')
+    x = _series(int(g['seed']), int(g['n']))
+    avar, tau = ginsim.allan_var_host(ctx, x, float(g['fs']))
+    np.testing.assert_allclose(tau, g['tau'], rtol=1e-15)
+    np.testing.assert_allclose(avar, g['avar'], rtol=1e-10)          # SURVEY 8(c) T6 tolerance
+
+
+@pytest.mark.parametrize('n,fs', [(360000, 100.0), (123457, 50.0), (2519, 10.0), (2521, 10.0), (25200, 100.0), (899, 100.0), (90, 10.0)])
+def test_allan_matches_oracle_ragged_lengths(ctx, n, fs):
+    import ginsim
+    from oracle import ins_np
+    x = np.stack([_series(s, n) + 5.0 * s for s in range(3)])          # large offsets: shift invariance
+    avar, tau = ginsim.allan_var_host(ctx, x, fs)
+    for s in range(3):
+        ra, rt = ins_np.allan_var(x[s], fs)
+        assert tau.shape == rt.shape
+        np.testing.assert_allclose(tau, rt, rtol=1e-15)
+        np.testing.assert_allclose(avar[s], ra, rtol=1e-9)
+
+
+def test_allan_plugin_and_module_surface(ctx):
+    from gnss_ins_sim.allan import allan
+    from demo_algorithms import allan_analysis
+    from oracle import ins_np
+    n, fs = 50000, 100.0
+    acc = np.stack([_series(s, n) for s in range(3)], axis=1)
+    gyr = np.stack([_series(s + 3, n) * 0.01 for s in range(3)], axis=1)
+    a = allan_analysis.Allan()
+    a.run([fs, acc, gyr])
+    tau, ad_a, ad_g = a.get_results()
+    ra, rt = ins_np.allan_var(gyr[:, 1], fs)
+    np.testing.assert_allclose(tau, rt)
+    np.testing.assert_allclose(ad_g[:, 1], np.sqrt(ra), rtol=1e-9)
+    assert ad_a.shape == (tau.size, 3)
+    av, t2 = allan.allan_var(acc[:, 0], fs)
+    np.testing.assert_allclose(av, ins_np.allan_var(acc[:, 0], fs)[0], rtol=1e-9)
+    assert allan.allan_var(acc[:50, 0], fs) == ([], [])
+
+
+def test_allan_full_size_white_noise_slope(ctx):
+    """Config 5 size: 3600 s @ 400 Hz (n = 1 440 000, 46 tau).  White noise of density N: AD(tau) = N/sqrt(tau)."""
+    import ginsim
+    n, fs, N = 1440000, 400.0, 7.27e-5
+    z0, _ = ginsim.rng_normals(ctx, 11, 0, 5, n)
+    x = N * np.sqrt(fs) * z0
+    avar, tau = ginsim.allan_var_host(ctx, x, fs)
+    assert tau.size == 46 and tau[-1] == 250.0
+    ad = np.sqrt(avar)
+    k = tau <= 10.0
+    np.testing.assert_allclose(ad[k], N / np.sqrt(tau[k]), rtol=0.08)
