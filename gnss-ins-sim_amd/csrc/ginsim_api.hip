@@ -25,6 +25,7 @@ void set_error(const char* fmt, ...) {
 }
 
 hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream);
+hipError_t launch_aux(const ginsim_aux_params& p, hipStream_t s);
 hipError_t launch_rng_probe(uint64_t seed, uint64_t run, uint32_t stream, int64_t count, double* z0, double* z1,
                             uint32_t* words, hipStream_t stream_h);
 hipError_t launch_aos_to_soa(const double* src, double* dst, int64_t R, int64_t n, int C, hipStream_t s);
@@ -279,6 +280,18 @@ int ginsim_mc_run(ginsim_ctx* c, const ginsim_mc_params* p) {
     }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_mc(*p, c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_aux_sensors(ginsim_ctx* c, const ginsim_aux_params* p) {
+    REQUIRE(c && p, "aux_sensors: NULL argument");
+    REQUIRE(p->runs >= 1 && p->n >= 0 && p->m >= 0, "aux_sensors: bad sizes");
+    REQUIRE(!p->out_gps || p->ref_gps, "aux_sensors: ref_gps missing");
+    REQUIRE(!p->out_mag || p->ref_mag, "aux_sensors: ref_mag missing");
+    REQUIRE(p->n <= 0xFFFFFFFFll && p->m <= 0xFFFFFFFFll, "aux_sensors: sample index exceeds the RNG counter");
+    REQUIRE((double)p->n * (double)p->runs < 5.0e11 && (double)p->m * (double)p->runs < 5.0e11, "aux_sensors: too many elements");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_aux(*p, c->stream));
     return GINSIM_OK;
 }
 

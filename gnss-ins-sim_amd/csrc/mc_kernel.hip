@@ -312,6 +312,46 @@ hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Auxiliary sensors: one thread per (sample, run), run fastest.  gps_gen: pathgen.py:621-624; mag_gen: :658-661.
+__global__ void __launch_bounds__(256) aux_gps_kernel(const ginsim_aux_params a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.m * a.runs) return;
+    const int64_t r = idx % a.runs, k = idx / a.runs;
+    const uint64_t grun = a.run_offset + (uint64_t)r;
+    const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
+    double z0[3], z1[3];
+    normal_pairs<3>(key, S_GPS_P_XY, (uint32_t)k, z0, z1);
+    const double z[6] = {z0[0], z1[0], z0[1], z1[1], z0[2], z1[2]};     // pos x,y,z  vel x,y,z
+    const int64_t plane = a.m * a.runs;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a.out_gps[c * plane + idx] = a.ref_gps[6 * k + c] + a.gps_sigma[c] * z[c];
+}
+
+__global__ void __launch_bounds__(256) aux_mag_kernel(const ginsim_aux_params a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n * a.runs) return;
+    const int64_t r = idx % a.runs, j = idx / a.runs;
+    const uint64_t grun = a.run_offset + (uint64_t)r;
+    const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
+    double z0[2], z1[2];
+    normal_pairs<2>(key, S_MAG_XY, (uint32_t)j, z0, z1);
+    const double z[3] = {z0[0], z1[0], z0[1]};
+    const double v[3] = {a.ref_mag[3 * j] + a.mag_hi[0], a.ref_mag[3 * j + 1] + a.mag_hi[1], a.ref_mag[3 * j + 2] + a.mag_hi[2]};
+    const int64_t plane = a.n * a.runs;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)     // (ref + hi) . si^T  + std * N
+        a.out_mag[c * plane + idx] = a.mag_si[3 * c] * v[0] + a.mag_si[3 * c + 1] * v[1] + a.mag_si[3 * c + 2] * v[2] + a.mag_std[c] * z[c];
+}
+
+hipError_t launch_aux(const ginsim_aux_params& p, hipStream_t s) {
+    if (p.out_gps && p.ref_gps && p.m > 0)
+        hipLaunchKernelGGL(aux_gps_kernel, dim3((unsigned)((p.m * p.runs + 255) / 256)), dim3(256), 0, s, p);
+    if (p.out_mag && p.ref_mag && p.n > 0)
+        hipLaunchKernelGGL(aux_mag_kernel, dim3((unsigned)((p.n * p.runs + 255) / 256)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // RNG self-test: normals (and raw Philox words) of one (seed, run, stream), sample index = global lane.
 __global__ void rng_probe_kernel(uint64_t seed, uint64_t run, uint32_t stream, int64_t count,
                                  double* __restrict__ z0, double* __restrict__ z1, uint32_t* __restrict__ words) {

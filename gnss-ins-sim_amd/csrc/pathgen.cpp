@@ -120,7 +120,7 @@ extern "C" int ginsim_pathgen_capacity(const ginsim_pathgen_params* p, const dou
 }
 
 extern "C" int ginsim_pathgen(const ginsim_pathgen_params* p, const double* md, int64_t cap, double* imu, double* nav,
-                              double* gps, double* odo, int64_t* n_out, int64_t* m_out) {
+                              double* gps, double* odo, double* mag, int64_t* n_out, int64_t* m_out) {
     int64_t need = 0;
     const int rc = ginsim_pathgen_capacity(p, md, &need);
     if (rc != GINSIM_OK) return rc;
@@ -148,6 +148,12 @@ extern "C" int ginsim_pathgen(const ginsim_pathgen_params* p, const double* md, 
         const double r = kRe / std::sqrt(1.0 - kEsq * sl * sl);
         const double rho = (r + pos0[2]) * cl;
         pos0 = V3{{rho * std::cos(pos0[1]), rho * std::sin(pos0[1]), (r * (1.0 - kEsq) + pos0[2]) * sl}};
+    }
+    const bool want_mag = p->enable_mag && mag;
+    V3 geo_mag{{p->geo_mag_n[0], p->geo_mag_n[1], p->geo_mag_n[2]}};
+    if (want_mag && p->ref_frame == 1) {                          // pathgen.py:169-171: remove the declination
+        geo_mag[0] = std::sqrt(geo_mag[0] * geo_mag[0] + geo_mag[1] * geo_mag[1]);
+        geo_mag[1] = 0.0;
     }
     V3 att_dot{{0, 0, 0}}, vel_dot_b{{0, 0, 0}};
     int64_t k = 0, kg = 0;
@@ -223,6 +229,11 @@ extern "C" int ginsim_pathgen(const ginsim_pathgen_params* p, const double* md, 
                 qn[1 + i] = pos[i];
                 qn[4 + i] = vel_n[i];
                 qn[7 + i] = eul[i];
+            }
+            if (want_mag) {                                       // pathgen.py:273-279
+                const V3 mb = mul_t(c_nb, geo_mag);
+                double* qm = mag + 4 * k;
+                qm[0] = (double)k; qm[1] = mb[0]; qm[2] = mb[1]; qm[3] = mb[2];
             }
             if (odo) {
                 double* qo = odo + 5 * k;

@@ -45,7 +45,14 @@ class McParams(C.Structure):
 class PathgenParams(C.Structure):
     _fields_ = [('ini_pva', C.c_double * 9), ('mobility', C.c_double * 3), ('fs', C.c_double),
                 ('fs_gps', C.c_double), ('ref_frame', C.c_int32), ('enable_gps', C.c_int32),
-                ('n_seg', C.c_int32), ('reserved', C.c_int32)]
+                ('n_seg', C.c_int32), ('enable_mag', C.c_int32), ('geo_mag_n', C.c_double * 3)]
+
+
+class AuxParams(C.Structure):
+    _fields_ = [('n', C.c_int64), ('m', C.c_int64), ('runs', C.c_int64), ('run_offset', C.c_uint64),
+                ('seed', C.c_uint64), ('gps_sigma', C.c_double * 6), ('mag_si', C.c_double * 9),
+                ('mag_hi', C.c_double * 3), ('mag_std', C.c_double * 3), ('ref_gps', C.c_void_p),
+                ('ref_mag', C.c_void_p), ('out_gps', C.c_void_p), ('out_mag', C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -72,8 +79,9 @@ _SIGS = {
     'ginsim_event_record': (C.c_int, [C.c_void_p, C.c_int32]),
     'ginsim_event_elapsed': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     'ginsim_pathgen_capacity': (C.c_int, [C.POINTER(PathgenParams), _PD, C.POINTER(C.c_int64)]),
-    'ginsim_pathgen': (C.c_int, [C.POINTER(PathgenParams), _PD, C.c_int64, _PD, _PD, _PD, _PD,
+    'ginsim_pathgen': (C.c_int, [C.POINTER(PathgenParams), _PD, C.c_int64, _PD, _PD, _PD, _PD, _PD,
                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'ginsim_aux_sensors': (C.c_int, [C.c_void_p, C.POINTER(AuxParams)]),
     'ginsim_mc_run': (C.c_int, [C.c_void_p, C.POINTER(McParams)]),
     'ginsim_end_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Stats)]),
     'ginsim_stats_merge': (C.c_int, [C.POINTER(Stats), C.c_int32, C.POINTER(Stats)]),

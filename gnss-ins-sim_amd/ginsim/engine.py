@@ -120,9 +120,10 @@ def default_context():
 
 
 # --------------------------------------------------------------------------------------- truth
-def pathgen(ini_pva, motion_def, fs, fs_gps=0.0, mobility=(1.0, 0.5, 2.0), ref_frame=0, gps=False):
+def pathgen(ini_pva, motion_def, fs, fs_gps=0.0, mobility=(1.0, 0.5, 2.0), ref_frame=0, gps=False, geo_mag_n=None):
     """pathgen.path_gen through the C ABI.  motion_def is (S,9) with angles in rad, unmodified.
-    Returns {'imu': (n,7), 'nav': (n,10), 'odo': (n,5)[, 'gps': (m,8)]}."""
+    geo_mag_n: geomagnetic field [uT] in the N frame at the initial position -> also emits 'mag' (n,4).
+    Returns {'imu': (n,7), 'nav': (n,10), 'odo': (n,5)[, 'gps': (m,8)][, 'mag': (n,4)]}."""
     md = np.ascontiguousarray(np.atleast_2d(np.asarray(motion_def, dtype=np.float64)))
     if md.shape[1] < 9:
         raise ValueError('motion definition must have nine columns')
@@ -132,6 +133,9 @@ def pathgen(ini_pva, motion_def, fs, fs_gps=0.0, mobility=(1.0, 0.5, 2.0), ref_f
     p.mobility[:] = [float(x) for x in mobility]
     p.fs, p.fs_gps = float(fs), float(fs_gps)
     p.ref_frame, p.enable_gps, p.n_seg = int(ref_frame), int(bool(gps)), md.shape[0]
+    if geo_mag_n is not None:
+        p.enable_mag = 1
+        p.geo_mag_n[:] = [float(x) for x in geo_mag_n]
     cap = C.c_int64(0)
     check(lib.ginsim_pathgen_capacity(C.byref(p), dptr(md), C.byref(cap)))
     cap = cap.value
@@ -139,12 +143,15 @@ def pathgen(ini_pva, motion_def, fs, fs_gps=0.0, mobility=(1.0, 0.5, 2.0), ref_f
     nav = np.zeros((cap, 10))
     odo = np.zeros((cap, 5))
     gpsb = np.zeros((cap, 8)) if gps else None
+    magb = np.zeros((cap, 4)) if geo_mag_n is not None else None
     n, m = C.c_int64(0), C.c_int64(0)
-    check(lib.ginsim_pathgen(C.byref(p), dptr(md), cap, dptr(imu), dptr(nav), dptr(gpsb), dptr(odo),
+    check(lib.ginsim_pathgen(C.byref(p), dptr(md), cap, dptr(imu), dptr(nav), dptr(gpsb), dptr(odo), dptr(magb),
                              C.byref(n), C.byref(m)))
     out = {'imu': imu[:n.value], 'nav': nav[:n.value], 'odo': odo[:n.value]}
     if gps:
         out['gps'] = gpsb[:m.value]
+    if magb is not None:
+        out['mag'] = magb[:n.value]
     return out
 
 
@@ -334,6 +341,61 @@ class MonteCarloJob(object):
         base = self._bufs['traj_' + algo].ptr
         plane = self.n * self.runs * 8
         return tuple(self._gather(base + 3 * k * plane, 3, run_ids) for k in range(3))
+
+    def release(self):
+        for b in self._bufs.values():
+            b.free()
+        self._bufs = {}
+
+
+class AuxSensorJob(object):
+    """GPS / magnetometer measurements of a Monte-Carlo batch (pathgen.gps_gen, mag_gen), kept in HBM as
+    gps[6][m][runs] and mag[3][n][runs].  Same Philox streams as the reference-injection shim (oracle/ref_shim.py)."""
+
+    def __init__(self, ctx, runs, seed=0, run_offset=0, ref_gps=None, gps_err=None, ref_frame=0, ref_mag=None,
+                 mag_err=None):
+        from gnss_ins_sim.geoparams import geoparams
+        self.ctx, self.runs = ctx, int(runs)
+        p = self.params = _lib.AuxParams()
+        p.runs, p.run_offset, p.seed = self.runs, int(run_offset), int(seed) & (2 ** 64 - 1)
+        self._bufs = {}
+        self.m = self.n = 0
+        if ref_gps is not None:
+            ref_gps = np.ascontiguousarray(ref_gps, dtype=np.float64)
+            self.m = p.m = ref_gps.shape[0]
+            sig = np.concatenate([np.asarray(gps_err['stdp'], dtype=np.float64) * np.ones(3),
+                                  np.asarray(gps_err['stdv'], dtype=np.float64) * np.ones(3)])
+            if ref_frame == 0:                       # metres -> rad at the FIRST GPS point, pathgen.py:616-619
+                rm, rn, _, _, cl, _ = geoparams.geo_param(ref_gps[0, 0:3])
+                sig[0] = sig[0] / rm
+                sig[1] = sig[1] / rn / cl
+            p.gps_sigma[:] = [float(x) for x in sig]
+            self._bufs['ref_gps'] = ctx.upload(ref_gps)
+            self._bufs['gps'] = ctx.malloc(6 * self.m * self.runs * 8)
+            p.ref_gps, p.out_gps = self._bufs['ref_gps'].ptr, self._bufs['gps'].ptr
+        if ref_mag is not None:
+            ref_mag = np.ascontiguousarray(ref_mag, dtype=np.float64)
+            self.n = p.n = ref_mag.shape[0]
+            p.mag_si[:] = [float(x) for x in np.asarray(mag_err['si'], dtype=np.float64).reshape(9)]
+            p.mag_hi[:] = [float(x) for x in np.asarray(mag_err['hi'], dtype=np.float64) * np.ones(3)]
+            p.mag_std[:] = [float(x) for x in np.asarray(mag_err['std'], dtype=np.float64) * np.ones(3)]
+            self._bufs['ref_mag'] = ctx.upload(ref_mag)
+            self._bufs['mag'] = ctx.malloc(3 * self.n * self.runs * 8)
+            p.ref_mag, p.out_mag = self._bufs['ref_mag'].ptr, self._bufs['mag'].ptr
+
+    def run(self):
+        check(lib.ginsim_aux_sensors(self.ctx.handle, C.byref(self.params)))
+        self.ctx.sync()
+        return self
+
+    def series(self, name, run_ids):
+        """'gps' -> (k, m, 6); 'mag' -> (k, n, 3)."""
+        ids = np.ascontiguousarray(np.asarray(run_ids, dtype=np.int64).reshape(-1))
+        ncomp, length = (6, self.m) if name == 'gps' else (3, self.n)
+        out = np.empty((ids.size, length, ncomp))
+        check(lib.ginsim_gather_runs(self.ctx.handle, self._bufs[name].ptr, ncomp, length, self.runs,
+                                     ids.ctypes.data_as(C.POINTER(C.c_int64)), ids.size, dptr(out)))
+        return out
 
     def release(self):
         for b in self._bufs.values():

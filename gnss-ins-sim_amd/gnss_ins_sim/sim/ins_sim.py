@@ -19,6 +19,9 @@ Keyword-only extras (defaults keep the reference behaviour):
                        ``max_device_bytes``), else keep only per-run end-point errors (stats-only).
     max_device_bytes   budget for materialised series on one GPU (default 64 GiB of the 288 GB).
     device             GPU index (default LOCAL_RANK or 0).
+    geo_mag_n          geomagnetic field [uT] in the N frame at the initial position, needed for a 9-axis IMU.  The
+                       reference evaluates the WMM model once per run for this vector (pathgen.py:164-168,
+                       date = today); that model is outside the accelerated path, so the caller supplies the vector.
 """
 import math
 import os
@@ -66,7 +69,7 @@ class _McResults(object):
 
 class Sim(object):
     def __init__(self, fs, motion_def, ref_frame=0, imu=None, mode=None, env=None, algorithm=None, *,
-                 seed=None, keep_trajectories='auto', max_device_bytes=64 * 2 ** 30, device=None):
+                 seed=None, keep_trajectories='auto', max_device_bytes=64 * 2 ** 30, device=None, geo_mag_n=None):
         self.name, self.version = NAME, VERSION
         self.fs, self.imu, self.mode, self.env = fs, imu, mode, env
         self.ref_frame = ref_frame if ref_frame in (0, 1) else 0
@@ -80,6 +83,7 @@ class Sim(object):
         self.interested_error = {'att_euler': 'angle', 'pos': None, 'vel': None}
         self.sum = ''
         self.seed, self.keep_trajectories, self.max_device_bytes, self.device = seed, keep_trajectories, max_device_bytes, device
+        self.geo_mag_n = geo_mag_n
         self.mc = None
         if env is not None:
             raise NotImplementedError('vibration models (env) are outside the accelerated hot path; every BASELINE '
@@ -134,10 +138,12 @@ class Sim(object):
         ini_pva, motion_def = workloads.parse_motion(self.data_src)
         mobility = self._parse_mode(self.mode)
         fs_imu = self.fs[0]
-        if self.imu.magnetometer:
-            raise NotImplementedError('9-axis (magnetometer) generation is not on the device path yet')
+        if self.imu.magnetometer and self.geo_mag_n is None:
+            raise NotImplementedError('a 9-axis IMU needs the local geomagnetic field: pass Sim(..., geo_mag_n=[bx,by,bz] uT) '
+                                      '(the WMM evaluation of pathgen.py:164-168 is outside the accelerated path)')
         raw = ginsim.pathgen(ini_pva, motion_def, fs_imu, self.fs[1] if self.imu.gps else 0.0, mobility,
-                             self.ref_frame, gps=self.imu.gps)
+                             self.ref_frame, gps=self.imu.gps,
+                             geo_mag_n=self.geo_mag_n if self.imu.magnetometer else None)
         d = self.dmgr
         nav, imu_t = raw['nav'], raw['imu']
         n = nav.shape[0]
@@ -151,6 +157,8 @@ class Sim(object):
             d.add_data(d.gps_time.name, raw['gps'][:, 0] / fs_imu)
             d.add_data(d.ref_gps.name, np.ascontiguousarray(raw['gps'][:, 1:7]))
             d.add_data(d.gps_visibility.name, raw['gps'][:, 7].copy())
+        if self.imu.magnetometer:
+            d.add_data(d.ref_mag.name, np.ascontiguousarray(raw['mag'][:, 1:4]))
         if self.imu.odo:
             d.add_data(d.ref_odo.name, np.ascontiguousarray(raw['odo'][:, 2]))
         d.add_data(d.ref_att_quat.name, attitude.euler2quat(d.ref_att_euler.data))     # ins_sim.py:729-748
@@ -172,7 +180,8 @@ class Sim(object):
         first, count = distributed.shard(self.sim_count, world, rank)
         seed = self._pick_seed(group, xdev)
         ctx = self._context()
-        per_sample = 48 + (8 if self.imu.odo else 0) + 72 * len(fused)
+        per_sample = 48 + (8 if self.imu.odo else 0) + 72 * len(fused) + (24 if self.imu.magnetometer else 0) + \
+            (48.0 * raw['gps'].shape[0] / n if self.imu.gps else 0)
         keep = self.keep_trajectories
         if keep == 'auto':
             keep = per_sample * n * max(count, 1) <= self.max_device_bytes
@@ -227,6 +236,19 @@ class Sim(object):
             d.add_data(d.gyro.name, sens('gyro'))
             if self.imu.odo:
                 d.add_data(d.odo.name, sens('odo', squeeze=True))
+        if keep and count > 0 and (self.imu.gps or self.imu.magnetometer):      # ins_sim.py:497-503
+            aux = ginsim.AuxSensorJob(ctx, count, seed=seed, run_offset=first,
+                                      ref_gps=d.ref_gps.data if self.imu.gps else None, gps_err=self.imu.gps_err,
+                                      ref_frame=self.ref_frame,
+                                      ref_mag=d.ref_mag.data if self.imu.magnetometer else None, mag_err=self.imu.mag_err).run()
+            self._aux = aux
+            view = lambda nm: McSeries(count, lambda pos, a=aux, nm=nm: a.series(nm, pos), key_of=lambda i: first + i,
+                                       pos_of=lambda k: int(k) - first if isinstance(k, (int, np.integer)) and
+                                       first <= int(k) < first + count else None)
+            if self.imu.gps:
+                d.add_data(d.gps.name, view('gps'))
+            if self.imu.magnetometer:
+                d.add_data(d.mag.name, view('mag'))
         if self.amgr.algo is not None:
             d.set_algo_output(self.amgr.output)
         names = [self.amgr.get_algo_name(i) for i in fused]

@@ -62,7 +62,9 @@ typedef struct {
     int32_t ref_frame;      /* 0 NED/LLA, 1 virtual inertial frame */
     int32_t enable_gps;
     int32_t n_seg;          /* rows of motion_def */
-    int32_t reserved;
+    int32_t enable_mag;     /* emit the true magnetic field in the body frame (pathgen.py:273-279) */
+    double  geo_mag_n[3];   /* geomagnetic field at the initial position in the N frame [uT] (pathgen.py:164-168; the WMM
+                             * evaluation itself is outside the hot path).  ref_frame 1 drops the declination (:169-171). */
 } ginsim_pathgen_params;
 
 /* Upper bound of the IMU sample count: sum of ceil(duration*fs) (pathgen.py:116-127). */
@@ -71,7 +73,8 @@ int ginsim_pathgen_capacity(const ginsim_pathgen_params* p, const double* motion
  * gps [cap][8] = idx,pos3,vel3,visibility (may be NULL); odo [cap][5] = idx,dist,vel_b3 (may be NULL).
  * motion_def is not modified (the reference overwrites column 7, pathgen.py:122). */
 int ginsim_pathgen(const ginsim_pathgen_params* p, const double* motion_def, int64_t cap,
-                   double* imu, double* nav, double* gps, double* odo, int64_t* n_out, int64_t* m_out);
+                   double* imu, double* nav, double* gps, double* odo, double* mag /*[cap][4] = idx,mag3 or NULL*/,
+                   int64_t* n_out, int64_t* m_out);
 
 /* ---- Monte-Carlo fused kernel: noise injection + mechanisation + end-point error ------------- */
 #define GINSIM_ALGO_FREE 1   /* demo_algorithms/free_integration.py:63-174      */
@@ -122,6 +125,26 @@ typedef struct {
 } ginsim_mc_params;
 
 int ginsim_mc_run(ginsim_ctx* ctx, const ginsim_mc_params* p);
+
+/* ---- auxiliary sensors of a Monte-Carlo batch: pathgen.gps_gen (pathgen.py:596-625) and pathgen.mag_gen (:643-661).
+ *      FreeIntegration does not consume them, so they are generated only when they are to be kept. */
+typedef struct {
+    int64_t  n;             /* IMU samples (magnetometer rate) */
+    int64_t  m;             /* GPS samples */
+    int64_t  runs;
+    uint64_t run_offset;
+    uint64_t seed;
+    double   gps_sigma[6];  /* position sigma (already in rad,rad,m for ref_frame 0: pathgen.py:616-619) and velocity sigma */
+    double   mag_si[9];     /* soft-iron matrix, row major */
+    double   mag_hi[3];     /* hard iron [uT] */
+    double   mag_std[3];    /* noise sigma [uT] */
+    const double* ref_gps;  /* device [m][6] or NULL */
+    const double* ref_mag;  /* device [n][3] or NULL */
+    double*  out_gps;       /* device [6][m][runs] or NULL */
+    double*  out_mag;       /* device [3][n][runs] or NULL */
+} ginsim_aux_params;
+
+int ginsim_aux_sensors(ginsim_ctx* ctx, const ginsim_aux_params* p);
 
 /* ---- end-point statistics: InsDataMgr.__end_point_error_stats / __array_stats
  *      (gnss_ins_sim/sim/ins_data_manager.py:717-759, 797-808) ------------------------------------ */

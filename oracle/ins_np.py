@@ -110,7 +110,7 @@ def euler_range_three_axis(a):
 
 
 # ----------------------------------------------------------------------------- truth (pathgen)
-def path_gen(ini_pva, motion_def, fs, fs_gps, mobility, ref_frame, gps=False, odo=False):
+def path_gen(ini_pva, motion_def, fs, fs_gps, mobility, ref_frame, gps=False, odo=False, geo_mag_n=None):
     """pathgen.path_gen (pathgen.py:26-329) with sim_osr == 1 (ins_sim.py:451).
 
     ``motion_def`` is (S,9) with angles already in rad (ins_sim.py:604-608); it is NOT
@@ -139,6 +139,12 @@ def path_gen(ini_pva, motion_def, fs, fs_gps, mobility, ref_frame, gps=False, od
     gps_every = round(fs / fs_gps) if gps else 0
     gps_rows = np.zeros((total, 8))
     odo_rows = np.zeros((total, 5))
+    mag_rows = np.zeros((total, 4))
+    if geo_mag_n is not None:                       # pathgen.py:164-171
+        geo_mag_n = np.array(geo_mag_n, dtype=np.float64)
+        if ref_frame == 1:
+            geo_mag_n[0] = math.sqrt(geo_mag_n[0] * geo_mag_n[0] + geo_mag_n[1] * geo_mag_n[1])
+            geo_mag_n[1] = 0.0
 
     pos0 = np.array(ini_pva[0:3], dtype=np.float64)
     vel_b = np.array(ini_pva[3:6], dtype=np.float64)
@@ -197,6 +203,9 @@ def path_gen(ini_pva, motion_def, fs, fs_gps, mobility, ref_frame, gps=False, od
             nav[k, 4:7] = vel_n
             nav[k, 7:10] = euler_range_three_axis(att)
             odo_rows[k] = (k, odo_dist, vel_b[0], vel_b[1], vel_b[2])
+            if geo_mag_n is not None:               # pathgen.py:273-279
+                mag_rows[k, 0] = k
+                mag_rows[k, 1:4] = c_nb.T.dot(geo_mag_n)
             if gps and (k % gps_every) == 0:
                 gps_rows[kg, 0] = k
                 gps_rows[kg, 1:4] = pos0 + dpos
@@ -218,6 +227,8 @@ def path_gen(ini_pva, motion_def, fs, fs_gps, mobility, ref_frame, gps=False, od
         out['gps'] = gps_rows[:kg]
     if odo:
         out['odo'] = odo_rows[:k]
+    if geo_mag_n is not None:
+        out['mag'] = mag_rows[:k]
     return out
 
 

@@ -176,9 +176,9 @@ def err_dict_arrays(prefix, e):
     return {prefix + k: np.array(v, dtype=np.float64) for k, v in e.items()}
 
 
-def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0):
+def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=6):
     csv = MOTION + 'motion_def-90deg_turn.csv'
-    imu = imu_model.IMU(accuracy=accuracy, axis=6, gps=gps, odo=odo_opt is not None, odo_opt=odo_opt)
+    imu = imu_model.IMU(accuracy=accuracy, axis=axis, gps=gps, odo=odo_opt is not None, odo_opt=odo_opt)
     ini = read_ini(csv)
     objs = []
     for a in algos:
@@ -187,7 +187,7 @@ def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0):
     sim = ins_sim.Sim([100.0, fs_gps, 0.0], csv, ref_frame=ref_frame, imu=imu, algorithm=objs)
     n = 1000
     m = 100 if gps else 0
-    shim = RandnShim(SEED, n, imu.accel_err['b_corr'], imu.gyro_err['b_corr'], gps_m=m,
+    shim = RandnShim(SEED, n, imu.accel_err['b_corr'], imu.gyro_err['b_corr'], gps_m=m, mag=(axis == 9),
                      odo=odo_opt is not None)
     with injected(shim):
         sim.run(R)
@@ -209,6 +209,16 @@ def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0):
         out['ref_gps'] = d.ref_gps.data
         out['gps'] = np.stack([d.gps.data[r] for r in range(R)])
         out.update(err_dict_arrays('gps_', imu.gps_err))
+    if axis == 9:
+        # the WMM field the reference evaluated at the initial position TODAY (geomag.py:23 default date);
+        # stored so that the tests feed the same vector (pathgen.py:164-168)
+        from gnss_ins_sim.geoparams import geomag
+        gm = geomag.GeoMag("WMM.COF")
+        f = gm.GeoMag(ini[0] / D2R, ini[1] / D2R, ini[2])
+        out['geo_mag_n'] = np.array([f.bx, f.by, f.bz]) / 1000.0
+        out['ref_mag'] = d.ref_mag.data
+        out['mag'] = np.stack([d.mag.data[r][k] for r in range(R)])
+        out.update(err_dict_arrays('mag_', imu.mag_err))
     for ai, a in enumerate(algos):
         key = 'algo%d_' % ai
         out[a + '_att'] = np.stack([d.att_euler.data[key + str(r)][k] for r in range(R)])
@@ -249,5 +259,10 @@ if __name__ == '__main__':
     white['gyro_b'] = np.array([10.0, -20.0, 30.0])
     white['accel_b'] = np.array([1e-3, -2e-3, 3e-3])
     t3_case('t3_white_gps_rf0', 0, white, True, {'scale': 1.001, 'stdv': 0.05}, ['fi', 'odo'], 3, fs_gps=10.0)
+    mag9 = dict(DEMO_IMU)
+    mag9.update({'mag_si': np.array([[1.02, 0.01, -0.02], [0.03, 0.97, 0.01], [-0.01, 0.02, 1.05]]),
+                 'mag_hi': np.array([5.0, -8.0, 12.0]), 'mag_std': np.array([0.2, 0.1, 0.3])})
+    for rf in (0, 1):
+        t3_case('t3_mag9_gps_rf%d' % rf, rf, dict(mag9), True, None, ['fi'], 2, fs_gps=10.0, axis=9)
     allan_case()
     t2_long_drive()

@@ -1,0 +1,111 @@
+"""BASELINE config 3: long_drive @200 Hz (n = 193 036 IMU samples, m = 9 652 GPS samples), 9-axis IMU + GPS error
+model, ref_frame = 0.  Parity at the full time horizon against the C oracle (small R), the drop-in Sim with
+GPS + magnetometer series, and a stats-only run at scale."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, PKG, ang_close
+
+pytestmark = pytest.mark.gpu
+D2R = np.pi / 180
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import ginsim
+    c = ginsim.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope='module')
+def long_drive():
+    from ginsim import workloads
+    ini, truth, raw = workloads.truth_from_profile('long_drive', 200.0, 0, fs_gps=10.0, gps=True)
+    g = load_golden('t2_long_drive_rf0')
+    assert raw['imu'].shape[0] == int(g['n']) == 193036 and raw['gps'].shape[0] == int(g['m']) == 9652
+    np.testing.assert_allclose(raw['nav'][g['rows']], g['nav'], rtol=1e-15, atol=1e-13)     # reference truth rows
+    return ini, truth, raw, g
+
+
+def test_noise_free_full_horizon_vs_reference(ctx, long_drive):
+    """Zero-noise IMU over 193 036 steps == the reference's own FreeIntegration rows (golden)."""
+    import ginsim
+    ini, truth, raw, g = long_drive
+    zero = {'b': np.zeros(3), 'b_drift': np.zeros(3), 'b_corr': np.full(3, 100.0), 'arw': np.zeros(3), 'vrw': np.zeros(3)}
+    job = ginsim.MonteCarloJob(ctx, 200.0, 0, truth, zero, zero, ini, runs=2, seed=1, keep_traj=True).run()
+    att, pos, vel = job.trajectories('free', [1])
+    k = g['rows']
+    assert ang_close(att[0][k], g['fi_att'], 1e-9)
+    np.testing.assert_allclose(pos[0][k, :2], g['fi_pos'][:, :2], rtol=0, atol=1e-12)    # lat/lon [rad]
+    np.testing.assert_allclose(pos[0][k, 2], g['fi_pos'][:, 2], rtol=1e-7, atol=1e-6)    # altitude [m]
+    np.testing.assert_allclose(vel[0][k], g['fi_vel'], rtol=1e-7, atol=1e-8)
+    job.release()
+
+
+def test_noisy_full_horizon_vs_c_oracle(ctx, long_drive):
+    """mid-accuracy IMU, 96 runs x 193 036 steps, stats-only: per-run end-point errors == C oracle (same seeds)."""
+    import ginsim
+    from ginsim import workloads
+    from oracle import c_oracle
+    ini, truth, raw, g = long_drive
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    R, seed, off = 96, 4242, 500
+    job = ginsim.MonteCarloJob(ctx, 200.0, 0, truth, acc, gyr, ini, runs=R, seed=seed, run_offset=off).run()
+    dev = job.end_errors('free')
+    end, _, _ = c_oracle.mc_run(seed, off, R, 200.0, 0, truth, acc, gyr, ini)
+    # 193 036 forward-Euler steps amplify rounding (vertical channel is unstable): SURVEY 8(c) allows 1e-7 relative
+    assert ang_close(dev[:, :3], end[:, :3], 1e-8)
+    np.testing.assert_allclose(dev[:, 3:5], end[:, 3:5], rtol=0, atol=1e-11)             # lat/lon error [rad]
+    np.testing.assert_allclose(dev[:, 5], end[:, 5], rtol=1e-6, atol=1e-4)               # altitude error [m] (km-scale)
+    np.testing.assert_allclose(dev[:, 6:9], end[:, 6:9], rtol=1e-6, atol=1e-6)
+    st = job.stats('free')
+    np.testing.assert_allclose(st.std, end.std(0), rtol=1e-5)
+    job.release()
+
+
+def test_sim_nine_axis_gps_series(ctx, long_drive):
+    """Drop-in Sim on config 3's sensor suite (first 60 s of the profile to keep the materialised data small)."""
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration
+    g9 = load_golden('t3_mag9_gps_rf0')
+    text = open(os.path.join(PKG, 'motion_profiles', 'long_drive.csv')).read().split('\n')
+    short = '\n'.join(text[:3] + ['1,0,0,0,0,0,0,60,1'])
+    ini = np.array([float(v) for v in text[1].split(',')])
+    ini[0:2] *= D2R
+    ini[6:9] *= D2R
+    imu = imu_model.IMU(accuracy='mid-accuracy', axis=9, gps=True)
+    with pytest.raises(NotImplementedError, match='geo_mag_n'):
+        ins_sim.Sim([200.0, 10.0, 0.0], short, ref_frame=0, imu=imu).run(1)
+    sim = ins_sim.Sim([200.0, 10.0, 0.0], short, ref_frame=0, imu=imu, algorithm=free_integration.FreeIntegration(ini),
+                      seed=9, geo_mag_n=g9['geo_mag_n'])
+    sim.run(8)
+    sim.results(err_stats_start=-1)
+    d = sim.dmgr
+    assert d.gps.data[3].shape == (600, 6) and d.mag.data[7].shape == (12000, 3) and d.ref_mag.data.shape == (12000, 3)
+    e = np.stack([d.gps.data[r] - d.ref_gps.data for r in range(8)])
+    rm = 6335439.0 * (1 - 0.00669438 * np.sin(ini[0]) ** 2) ** -1.5
+    assert 0.8 < e[:, :, 0].std() * rm / 5.0 < 1.2           # 5 m north sigma expressed in rad
+    assert 0.9 < e[:, :, 2].std() / 7.0 < 1.1 and 0.9 < e[:, :, 3:].std() / 0.05 < 1.1
+    assert 0.9 < (d.mag.data[0] - d.ref_mag.data).std() / 0.01 < 1.1
+    assert sim.err_stats['vel']['std'].shape == (3,)
+
+
+def test_stats_only_at_scale(ctx, long_drive):
+    """16 384 runs x 193 036 samples (3.2e9 sample*MC) without materialising anything: finite, sane statistics."""
+    import ginsim
+    from ginsim import workloads
+    ini, truth, raw, g = long_drive
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    job = ginsim.MonteCarloJob(ctx, 200.0, 0, truth, acc, gyr, ini, runs=16384, seed=7)
+    ctx.timer_begin()
+    job.launch()
+    ms = ctx.timer_end()
+    st = job.stats('free')
+    assert st.count == 16384 and np.all(np.isfinite(st.std)) and np.all(st.std > 0)
+    # yaw error after 965 s: ARW*sqrt(T) = 0.25/60*sqrt(965) deg plus the bias-drift integral -> 0.13..0.5 deg
+    assert 0.13 < st.std[0] / D2R < 0.6, st.std[0] / D2R
+    print('C3 stats-only: %.1f ms for 16384 x 193036 -> %.3e sample*MC/s' % (ms, 16384 * 193036 / ms * 1e3))
+    job.release()

@@ -212,3 +212,27 @@ def test_full_size_properties(ctx):
     np.testing.assert_array_equal(merged.maxabs, st.maxabs)
     np.testing.assert_allclose(st.std, np.std(e, 0), rtol=1e-10)
     np.testing.assert_allclose(st.mean, np.mean(e, 0), rtol=1e-8, atol=1e-14)
+
+
+@pytest.mark.parametrize('name', ['t3_mag9_gps_rf0', 't3_mag9_gps_rf1', 't3_white_gps_rf0'])
+def test_gps_and_magnetometer_error_models_vs_reference(ctx, name):
+    """pathgen.gps_gen / mag_gen on the device == the unmodified reference fed the same normals."""
+    import ginsim
+    g = load_golden(name)
+    R, k, rf = int(g['R']), g['rows'], int(g['ref_frame'])
+    has_mag = 'mag' in g
+    job = ginsim.AuxSensorJob(ctx, R, seed=int(g['seed']), ref_gps=g['ref_gps'],
+                              gps_err={'stdp': g['gps_stdp'], 'stdv': g['gps_stdv']}, ref_frame=rf,
+                              ref_mag=g['ref_mag'] if has_mag else None,
+                              mag_err={'si': g['mag_si'], 'hi': g['mag_hi'], 'std': g['mag_std']} if has_mag else None).run()
+    gps = job.series('gps', np.arange(R))
+    np.testing.assert_allclose(gps[:, :, 0:2], g['gps'][:, :, 0:2], rtol=0, atol=1e-15 if rf == 0 else 1e-8)
+    np.testing.assert_allclose(gps[:, :, 2:6], g['gps'][:, :, 2:6], rtol=0, atol=1e-8)
+    if has_mag:
+        np.testing.assert_allclose(job.series('mag', np.arange(R))[:, k], g['mag'], rtol=0, atol=1e-12)
+    # sharding invariance: run 1 alone (run_offset=1) equals run 1 of the batch
+    one = ginsim.AuxSensorJob(ctx, 1, seed=int(g['seed']), run_offset=1, ref_gps=g['ref_gps'],
+                              gps_err={'stdp': g['gps_stdp'], 'stdv': g['gps_stdv']}, ref_frame=rf).run()
+    np.testing.assert_array_equal(one.series('gps', [0])[0], gps[1])
+    job.release()
+    one.release()

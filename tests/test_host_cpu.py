@@ -159,3 +159,13 @@ def test_two_process_gloo_allreduce_of_stats(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+@pytest.mark.parametrize('rf', [0, 1])
+def test_native_pathgen_magnetometer(rf):
+    import ginsim
+    g = load_golden('t3_mag9_gps_rf%d' % rf)
+    t2 = load_golden('t2_turn_rf%d' % rf)
+    r = ginsim.pathgen(t2['ini_pva'], t2['motion_def'], 100.0, 10.0, t2['mobility'], rf, gps=True, geo_mag_n=g['geo_mag_n'])
+    np.testing.assert_allclose(r['mag'][:, 1:4], g['ref_mag'], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(r['gps'][:, 1:7], g['ref_gps'], rtol=1e-15, atol=1e-13)

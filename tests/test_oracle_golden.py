@@ -133,3 +133,20 @@ def test_allan_matches_reference():
     avar, tau = ins_np.allan_var(x, fs)
     np.testing.assert_allclose(tau, g['tau'], rtol=0, atol=0)
     np.testing.assert_allclose(avar, g['avar'], rtol=1e-12)
+
+
+@pytest.mark.parametrize('rf', [0, 1])
+def test_t3_magnetometer_and_gps_models(rf):
+    """9-axis + GPS: truth magnetometer (pathgen with the stored WMM field), mag_gen with soft/hard iron, gps_gen."""
+    g = load_golden('t3_mag9_gps_rf%d' % rf)
+    t2 = load_golden('t2_turn_rf%d' % rf)
+    r = ins_np.path_gen(t2['ini_pva'], t2['motion_def'], 100.0, 10.0, t2['mobility'], rf, gps=True, geo_mag_n=g['geo_mag_n'])
+    np.testing.assert_allclose(r['mag'][:, 1:4], g['ref_mag'], rtol=0, atol=1e-12)
+    R, k, seed = int(g['R']), g['rows'], int(g['seed'])
+    nz = np.stack([philox.mag_normals(seed, run, 1000) for run in range(R)])
+    mag = ins_np.mag_errors(g['ref_mag'], {'si': g['mag_si'], 'hi': g['mag_hi'], 'std': g['mag_std']}, nz)
+    np.testing.assert_allclose(mag[:, k], g['mag'], rtol=0, atol=1e-12)
+    z = [philox.gps_normals(seed, run, g['ref_gps'].shape[0]) for run in range(R)]
+    gps = ins_np.gps_errors(g['ref_gps'], {'stdp': g['gps_stdp'], 'stdv': g['gps_stdv']}, rf,
+                            np.stack([a for a, _ in z]), np.stack([b for _, b in z]))
+    np.testing.assert_allclose(gps, g['gps'], rtol=1e-14, atol=1e-12)
