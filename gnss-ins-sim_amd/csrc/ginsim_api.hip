@@ -35,6 +35,8 @@ size_t stats_scratch_bytes(int64_t runs);
 int stats_blocks(int64_t runs);
 hipError_t launch_end_stats(const double* end_err, int64_t runs, void* scratch, hipStream_t s);
 void stats_merge_host(const ginsim_stats* parts, int nparts, ginsim_stats* out);
+hipError_t launch_process_stats(const double* traj, const double* ref, int64_t n, int64_t runs, int64_t j0, int pos_ned,
+                                double* out, hipStream_t s);
 struct AllanLevel {
     int64_t n_in, n_out, in_stride, out_stride;
     int64_t nb[9];
@@ -305,6 +307,34 @@ int ginsim_end_stats(ginsim_ctx* c, const double* end_err, int64_t runs, ginsim_
     HIP_TRY(hipMemcpyAsync(host_out, res, sizeof(ginsim_stats), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GINSIM_OK;
+}
+
+int ginsim_process_stats(ginsim_ctx* c, const double* traj, const double* ref, int64_t n, int64_t runs, int64_t first_sample,
+                         int32_t pos_ned, double* host_out) {
+    REQUIRE(c && traj && ref && host_out, "process_stats: NULL argument");
+    REQUIRE(n >= 1 && runs >= 1 && first_sample >= 0 && first_sample < n, "process_stats: bad sizes");
+    HIP_TRY(hipSetDevice(c->device));
+    void* ws = nullptr;
+    const size_t bytes = sizeof(double) * 27 * (size_t)runs;
+    HIP_TRY(scratch(c, 2, bytes, &ws));
+    HIP_TRY(launch_process_stats(traj, ref, n, runs, first_sample, pos_ned, reinterpret_cast<double*>(ws), c->stream));
+    std::vector<double> tmp((size_t)27 * runs);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), ws, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int64_t r = 0; r < runs; ++r)          // [3][9][runs] -> [runs][3][9]
+        for (int k = 0; k < 27; ++k) host_out[r * 27 + k] = tmp[(size_t)k * runs + r];
+    return GINSIM_OK;
+}
+
+int ginsim_end_stats_from_traj(ginsim_ctx* c, const double* traj, const double* ref, int64_t n, int64_t runs, int32_t pos_ned,
+                               ginsim_stats* host_out) {
+    REQUIRE(c && traj && ref && host_out && n >= 1 && runs >= 1, "end_stats_from_traj: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    void* ws = nullptr;
+    HIP_TRY(scratch(c, 2, sizeof(double) * 27 * (size_t)runs, &ws));
+    // a one-sample window: the "mean" plane [9][runs] of the process kernel IS the end-point error
+    HIP_TRY(launch_process_stats(traj, ref, n, runs, n - 1, pos_ned, reinterpret_cast<double*>(ws), c->stream));
+    return ginsim_end_stats(c, reinterpret_cast<double*>(ws) + (size_t)9 * runs, runs, host_out);
 }
 
 int ginsim_stats_merge(const ginsim_stats* parts, int32_t nparts, ginsim_stats* out) {

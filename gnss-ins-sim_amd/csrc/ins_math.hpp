@@ -65,6 +65,19 @@ GINSIM_HD Vec3 lla2ecef(double lat, double lon, double alt) {
     return Vec3{rho * cos(lon), rho * sin(lon), (r * (1.0 - kEsq) + alt) * sl};
 }
 
+// LLA error -> local NED metres: array_error(lla=1), ins_data_manager.py:542-552 with attitude.ecef_to_ned
+// (attitude.py:596-603): err = C_ne(ref lat, lon) . (lla2ecef(x) - lla2ecef(ref)).
+GINSIM_HD Vec3 lla_error_ned(const Vec3& x, const Vec3& ref) {
+    const Vec3 a = lla2ecef(x.x, x.y, x.z), b = lla2ecef(ref.x, ref.y, ref.z);
+    const Vec3 d{a.x - b.x, a.y - b.y, a.z - b.z};
+    double sl, cl, so, co;
+    sincos(ref.x, &sl, &cl);
+    sincos(ref.y, &so, &co);
+    return Vec3{-sl * co * d.x - sl * so * d.y + cl * d.z,
+                -so * d.x + co * d.y,
+                -cl * co * d.x - cl * so * d.y - sl * d.z};
+}
+
 // ZYX Euler attitude with cached trig.
 struct Att {
     double yaw, pit, rol;

@@ -147,9 +147,11 @@ __device__ __forceinline__ void store_end(double* __restrict__ out, int64_t runs
     out[0 * runs + r] = angle_range_pi(s.att.yaw - ref_end[0]);
     out[1 * runs + r] = angle_range_pi(s.att.pit - ref_end[1]);
     out[2 * runs + r] = angle_range_pi(s.att.rol - ref_end[2]);
-    out[3 * runs + r] = s.pos.x - ref_end[3];
-    out[4 * runs + r] = s.pos.y - ref_end[4];
-    out[5 * runs + r] = s.pos.z - ref_end[5];
+    Vec3 ep{s.pos.x - ref_end[3], s.pos.y - ref_end[4], s.pos.z - ref_end[5]};
+    if (kp->end_pos_ned && kp->ref_frame == 0) ep = lla_error_ned(s.pos, Vec3{ref_end[3], ref_end[4], ref_end[5]});
+    out[3 * runs + r] = ep.x;
+    out[4 * runs + r] = ep.y;
+    out[5 * runs + r] = ep.z;
     out[6 * runs + r] = s.vel.x - ref_end[6];
     out[7 * runs + r] = s.vel.y - ref_end[7];
     out[8 * runs + r] = s.vel.z - ref_end[8];

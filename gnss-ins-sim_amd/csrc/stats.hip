@@ -6,6 +6,7 @@
 // (count, mean, M2, max) partials are mergeable, so per-device results combine exactly across GPUs.
 #include <hip/hip_runtime.h>
 #include "ginsim.h"
+#include "ins_math.hpp"
 
 namespace ginsim {
 
@@ -67,6 +68,63 @@ __global__ void stats_final_kernel(const Mom* __restrict__ partial, int blocks, 
     out->mean[c] = t.mean;
     out->m2[c] = t.m2;
     out->maxabs[c] = t.mx;
+}
+
+// Process-error statistics: one lane per run walks the time axis of its trajectory (coalesced across lanes, the
+// truth row is wave-uniform -> scalar loads) with a Welford accumulator per component.  HBM-bound: 72 B per
+// sample*run read once.  out [3][9][runs] = max|e|, mean, M2/n -> std on the host side of the ABI.
+typedef const double __attribute__((address_space(4))) * uniform_ref;
+
+__global__ void __launch_bounds__(256) process_stats_kernel(const double* __restrict__ traj, const double* __restrict__ ref,
+                                                            int64_t n, int64_t runs, int64_t j0, int pos_ned,
+                                                            double* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= runs) return;
+    const int64_t plane = n * runs;
+    const uniform_ref truth = (uniform_ref)(uintptr_t)ref;
+    double mean[9], m2[9], mx[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { mean[c] = 0.0; m2[c] = 0.0; mx[c] = 0.0; }
+    double cnt = 0.0;
+    for (int64_t j = j0; j < n; ++j) {
+        double x[9], t[9], e[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { x[c] = traj[c * plane + j * runs + r]; t[c] = truth[9 * j + c]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) e[c] = angle_range_pi(x[c] - t[c]);
+        if (pos_ned) {
+            const Vec3 d = lla_error_ned(Vec3{x[3], x[4], x[5]}, Vec3{t[3], t[4], t[5]});
+            e[3] = d.x; e[4] = d.y; e[5] = d.z;
+        } else {
+#pragma unroll
+            for (int c = 3; c < 6; ++c) e[c] = x[c] - t[c];
+        }
+#pragma unroll
+        for (int c = 6; c < 9; ++c) e[c] = x[c] - t[c];
+        cnt += 1.0;
+        const double icnt = 1.0 / cnt;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const double d = e[c] - mean[c];
+            mean[c] += d * icnt;
+            m2[c] += d * (e[c] - mean[c]);
+            const double a = fabs(e[c]);
+            mx[c] = a > mx[c] ? a : mx[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        out[(0 * 9 + c) * runs + r] = mx[c];
+        out[(1 * 9 + c) * runs + r] = mean[c];
+        out[(2 * 9 + c) * runs + r] = cnt > 0.0 ? sqrt(m2[c] / cnt) : 0.0;
+    }
+}
+
+hipError_t launch_process_stats(const double* traj, const double* ref, int64_t n, int64_t runs, int64_t j0, int pos_ned,
+                                double* out, hipStream_t s) {
+    hipLaunchKernelGGL(process_stats_kernel, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, s, traj, ref, n, runs, j0,
+                       pos_ned, out);
+    return hipGetLastError();
 }
 
 int stats_blocks(int64_t runs) {

@@ -236,7 +236,7 @@ class MonteCarloJob(object):
 
     def __init__(self, ctx, fs, ref_frame, truth, accel_err, gyro_err, ini, runs, algos=('free',),
                  odo_err=None, earth_rot=True, seed=0, run_offset=0, ini_first=0,
-                 keep_sensors=False, keep_traj=False):
+                 keep_sensors=False, keep_traj=False, end_pos_ned=False):
         self.ctx = ctx
         self.algos = tuple(algos)
         for a in self.algos:
@@ -251,6 +251,7 @@ class MonteCarloJob(object):
         p.fs, p.ref_frame = float(fs), int(ref_frame)
         p.algo_mask = sum(ALGO_BITS[a] for a in self.algos)
         p.earth_rot = int(bool(earth_rot))
+        p.end_pos_ned = int(bool(end_pos_ned))
         if ini is None:
             if self.algos:
                 raise ValueError('initial states are required when an algorithm is integrated')
@@ -264,7 +265,8 @@ class MonteCarloJob(object):
             raise ValueError('the odometer algorithm needs odo_err and truth["ref_odo"]')
         if self.want_odo:
             p.odo_scale, p.odo_stdv = float(odo_err['scale']), float(odo_err['stdv'])
-        end = np.concatenate([truth['ref_att'][-1], truth['ref_pos'][-1], truth['ref_vel'][-1]])
+        self._ref_nav = np.ascontiguousarray(np.concatenate([truth['ref_att'], truth['ref_pos'], truth['ref_vel']], axis=1))
+        end = self._ref_nav[-1]
         p.ref_end[:] = [float(x) for x in end]
         # device-resident inputs
         self._bufs = {}
@@ -313,6 +315,29 @@ class MonteCarloJob(object):
     def stats(self, algo):
         s = _lib.Stats()
         check(lib.ginsim_end_stats(self.ctx.handle, self._bufs['end_' + algo].ptr, self.runs, C.byref(s)))
+        return StatsResult(s)
+
+    def process_stats(self, algo, first_sample=0, pos_ned=False):
+        """Per-run statistics of the error over time (samples >= first_sample): (runs, 3, 9) = max|e|, mean, std.
+        Needs the trajectories (keep_traj=True) and truth['ref_att'/'ref_pos'/'ref_vel']."""
+        if not self.keep_traj:
+            raise ValueError('process-error statistics need the trajectories (keep_traj=True)')
+        if 'ref_nav' not in self._bufs:
+            self._bufs['ref_nav'] = self.ctx.upload(self._ref_nav)
+        out = np.empty((self.runs, 3, 9))
+        check(lib.ginsim_process_stats(self.ctx.handle, self._bufs['traj_' + algo].ptr, self._bufs['ref_nav'].ptr,
+                                       self.n, self.runs, int(first_sample), int(bool(pos_ned)), dptr(out)))
+        return out
+
+    def stats_from_traj(self, algo, pos_ned=False):
+        """End-point statistics recomputed on the device from the kept trajectories (used for extra_opt='ned')."""
+        if not self.keep_traj:
+            raise ValueError('needs the trajectories (keep_traj=True)')
+        if 'ref_nav' not in self._bufs:
+            self._bufs['ref_nav'] = self.ctx.upload(self._ref_nav)
+        s = _lib.Stats()
+        check(lib.ginsim_end_stats_from_traj(self.ctx.handle, self._bufs['traj_' + algo].ptr, self._bufs['ref_nav'].ptr,
+                                             self.n, self.runs, int(bool(pos_ned)), C.byref(s)))
         return StatsResult(s)
 
     def end_errors(self, algo):

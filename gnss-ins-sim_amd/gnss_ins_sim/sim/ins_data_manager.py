@@ -172,7 +172,11 @@ class InsDataMgr(object):
                     for s in stat:
                         stat[s][a] = p[s]
         else:                                                # process error of every run, :761-795
-            stat = self._mc.process_stats(data_name, max(err_stats_start, 0), angle=angle, ned=ned)
+            t = np.asarray(self.time.data)
+            hit = np.where(t >= max(err_stats_start, 0))[0]
+            if hit.shape[0] == 0:
+                print('err_stats_start exceeds max data points.')
+            stat = self._mc.process_stats(data_name, int(hit[0]) if hit.shape[0] else 0, ned=ned)
         if use_output_units:
             for s in stat:
                 if isinstance(stat[s], dict):

@@ -51,17 +51,31 @@ class _McResults(object):
         return self.jobs[self.algo_names.index(name)]
 
     def end_stats(self, name, ned=False):
-        if ned:
-            raise NotImplementedError("extra_opt='ned' end-point statistics are not on the device path yet")
-        if name not in self._stats:
+        key = (name, bool(ned))
+        if key not in self._stats:
             from ginsim import distributed
-            part = self.job_of(name).stats(self.kinds[self.algo_names.index(name)])
-            self._stats[name] = distributed.allreduce_stats(part, self._group, self._device)
-        return self._stats[name]
+            job, kind = self.job_of(name), self.kinds[self.algo_names.index(name)]
+            if ned and not job.keep_traj:
+                raise NotImplementedError("extra_opt='ned' needs the trajectories: run with keep_trajectories=True")
+            part = job.stats_from_traj(kind, pos_ned=True) if ned else job.stats(kind)
+            self._stats[key] = distributed.allreduce_stats(part, self._group, self._device)
+        return self._stats[key]
 
-    def process_stats(self, data_name, start, angle=False, ned=False):
-        raise NotImplementedError('process-error statistics (err_stats_start >= 0) are not on the device path yet; '
-                                  'use err_stats_start=-1 (end-point statistics)')
+    def process_stats(self, data_name, start_sample, ned=False):
+        """{'max'|'avg'|'std': {'<algo>_<run>': (3,)}} for data_name in att_euler/pos/vel (ins_data_manager.py:761-795)."""
+        sl = {'att_euler': slice(0, 3), 'pos': slice(3, 6), 'vel': slice(6, 9)}[data_name]
+        stat = {'max': {}, 'avg': {}, 'std': {}}
+        for name, job, kind in zip(self.algo_names, self.jobs, self.kinds):
+            if not job.keep_traj:
+                raise NotImplementedError('process-error statistics need the trajectories: run with keep_trajectories=True')
+            key = ('proc', name, int(start_sample), bool(ned))
+            if key not in self._stats:
+                self._stats[key] = job.process_stats(kind, start_sample, pos_ned=ned)
+            arr = self._stats[key]
+            for i in range(self.runs_local):
+                k = name + '_' + str(self.first_run + i)
+                stat['max'][k], stat['avg'][k], stat['std'][k] = arr[i, 0, sl].copy(), arr[i, 1, sl].copy(), arr[i, 2, sl].copy()
+        return stat
 
     def run_of_key(self, key):
         return int(str(key).rsplit('_', 1)[-1]) if isinstance(key, str) else int(key)

@@ -121,7 +121,8 @@ typedef struct {
     /* tuning / telemetry (0 / NULL = defaults) */
     uint64_t* wave_trace;     /* device [n_waves][4] or NULL: HW_ID, XCC_ID, s_memtime at wave start and end */
     int32_t   block_threads;  /* workgroup size: 0 (default), 64, 128 or 256 */
-    int32_t   reserved;
+    int32_t   end_pos_ned;    /* ref_frame 0: report the end-point position error in local NED metres (extra_opt='ned',
+                               * ins_data_manager.py:474-488, 542-552) instead of [rad, rad, m] */
 } ginsim_mc_params;
 
 int ginsim_mc_run(ginsim_ctx* ctx, const ginsim_mc_params* p);
@@ -156,6 +157,17 @@ typedef struct {
 } ginsim_stats;             /* 28 doubles; mergeable across devices (Chan et al.) */
 
 int ginsim_end_stats(ginsim_ctx* ctx, const double* end_err /*device [9][runs]*/, int64_t runs, ginsim_stats* host_out);
+
+/* Process-error statistics of every run: InsDataMgr.__process_error_stats (ins_data_manager.py:761-795) over
+ * array_error (:519-553): e[j] = traj[j] - ref[j] for samples j >= first_sample, attitude wrapped to [-pi,pi];
+ * pos_ned != 0 (ref_frame 0, extra_opt='ned'): LLA error -> metres in the local NED frame of the reference (:542-552).
+ * traj: device [9][n][runs]; ref: device [n][9] (att3,pos3,vel3 truth).  host_out [runs][3][9] = max|e|, mean, std(ddof=0). */
+int ginsim_process_stats(ginsim_ctx* ctx, const double* traj, const double* ref, int64_t n, int64_t runs,
+                         int64_t first_sample, int32_t pos_ned, double* host_out);
+/* End-point statistics recomputed from kept trajectories (e.g. with pos_ned after the run): last-sample error of
+ * every run on the device, then the same reduction as ginsim_end_stats. */
+int ginsim_end_stats_from_traj(ginsim_ctx* ctx, const double* traj, const double* ref, int64_t n, int64_t runs,
+                               int32_t pos_ned, ginsim_stats* host_out);
 int ginsim_stats_merge(const ginsim_stats* parts, int32_t nparts, ginsim_stats* out);
 
 /* ---- data access: pull selected runs out of a [ncomp][n][runs] device series into host [nsel][n][ncomp] */

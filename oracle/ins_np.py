@@ -420,6 +420,23 @@ def end_point_errors(att, pos, vel, ref_att, ref_pos, ref_vel):
     return np.concatenate([ea, pos[:, -1] - ref_pos[-1], vel[:, -1] - ref_vel[-1]], axis=1)
 
 
+def lla_error_ned(x, r):
+    """array_error(lla=1) (ins_data_manager.py:542-552): LLA error in metres in the NED frame at r; (...,3)."""
+    d = lla2ecef(x) - lla2ecef(r)
+    sl, cl, so, co = np.sin(r[..., 0]), np.cos(r[..., 0]), np.sin(r[..., 1]), np.cos(r[..., 1])
+    return np.stack([-sl * co * d[..., 0] - sl * so * d[..., 1] + cl * d[..., 2],
+                     -so * d[..., 0] + co * d[..., 1],
+                     -cl * co * d[..., 0] - cl * so * d[..., 1] - sl * d[..., 2]], axis=-1)
+
+
+def process_error_stats(att, pos, vel, ref_att, ref_pos, ref_vel, first_sample, pos_ned=False):
+    """InsDataMgr.__process_error_stats (ins_data_manager.py:761-795) for every run: (R,3,9) = max|e|, mean, std."""
+    ea = angle_range_pi(att - ref_att[None])
+    ep = lla_error_ned(pos, np.broadcast_to(ref_pos[None], pos.shape)) if pos_ned else pos - ref_pos[None]
+    e = np.concatenate([ea, ep, vel - ref_vel[None]], axis=2)[:, first_sample:]
+    return np.stack([np.max(np.abs(e), 1), np.mean(e, 1), np.std(e, 1)], axis=1)
+
+
 def array_stats(e):
     """InsDataMgr.__array_stats (ins_data_manager.py:797-808)."""
     return {'max': np.max(np.abs(e), 0), 'avg': np.average(e, 0), 'std': np.std(e, 0)}

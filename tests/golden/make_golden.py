@@ -233,6 +233,25 @@ def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=
                     out['stat_%s_%s_%s' % (dn, s, g)] = v
             else:
                 out['stat_%s_%s_%s' % (dn, s, 'algo0')] = st[s]
+    # process-error statistics from t = 2 s (ins_data_manager.py:761-795), internal units, one row per run key
+    keys = ['algo%d_%d' % (ai, r) for ai in range(len(algos)) for r in range(R)]
+    out['proc_start_s'] = 2.0
+    for dn, ang in (('att_euler', True), ('pos', False), ('vel', False)):
+        st = d.get_error_stats(dn, err_stats_start=2.0, angle=ang, use_output_units=False)
+        for s in ('max', 'avg', 'std'):
+            out['proc_%s_%s' % (dn, s)] = np.stack([st[s][kk] for kk in keys])
+    if ref_frame == 0:      # extra_opt='ned' (ins_data_manager.py:474-488, 542-552); the error cache must be dropped first
+        d._InsDataMgr__err = {}
+        st = d.get_error_stats('pos', err_stats_start=-1, angle=False, use_output_units=False, extra_opt='ned')
+        for s in ('max', 'avg', 'std'):
+            if isinstance(st[s], dict):
+                for gname, v in st[s].items():
+                    out['ned_end_%s_%s' % (s, gname)] = v
+            else:
+                out['ned_end_%s_algo0' % s] = st[s]
+        st = d.get_error_stats('pos', err_stats_start=2.0, angle=False, use_output_units=False, extra_opt='ned')
+        for s in ('max', 'avg', 'std'):
+            out['ned_proc_%s' % s] = np.stack([st[s][kk] for kk in keys])
     save(name, **out)
 
 

@@ -1,0 +1,114 @@
+"""Process-error statistics (err_stats_start >= 0) and NED position error (extra_opt='ned'):
+oracle vs the reference goldens (CPU) and device vs both (GPU)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+CASES = ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0']
+
+
+def _errs(g):
+    acc = {k[6:]: g[k] for k in g if k.startswith('accel_') and k != 'accel'}
+    gyr = {k[5:]: g[k] for k in g if k.startswith('gyro_') and k != 'gyro'}
+    return acc, gyr
+
+
+def _algos(g):
+    # run keys are 'algo<i>_<r>' in the order the case listed its algorithms
+    order = {'t3_demo_rf1': ['odo', 'free'], 't3_mid_rf0': ['free'], 't3_white_gps_rf0': ['free', 'odo']}
+    return order
+
+
+def _want(g, ai, R):
+    rows = slice(ai * R, (ai + 1) * R)
+    w = np.empty((R, 3, 9))
+    for si, s in enumerate(('max', 'avg', 'std')):
+        w[:, si, 0:3] = g['proc_att_euler_' + s][rows]
+        w[:, si, 3:6] = g['proc_pos_' + s][rows]
+        w[:, si, 6:9] = g['proc_vel_' + s][rows]
+    return w
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_oracle_process_stats_match_reference(name):
+    from oracle import ins_np
+    g = load_golden(name)
+    R, fs, rf = int(g['R']), float(g['fs']), int(g['ref_frame'])
+    acc, gyr = _errs(g)
+    runs = np.arange(R)
+    accel, gyro = ins_np.mc_sensors(int(g['seed']), runs, fs, g['ref_accel'], g['ref_gyro'], acc, gyr)
+    odo = None
+    if 'odo' in g:
+        odo = ins_np.mc_odo(int(g['seed']), runs, g['ref_odo'], {'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])})
+    j0 = int(round(float(g['proc_start_s']) * fs))
+    for ai, a in enumerate(_algos(g)[name]):
+        att, pos, vel = ins_np.free_integration(rf, fs, gyro, accel, g['ini'], odo=odo if a == 'odo' else None)
+        st = ins_np.process_error_stats(att, pos, vel, g['ref_att'], g['ref_pos'], g['ref_vel'], j0)
+        np.testing.assert_allclose(st, _want(g, ai, R), rtol=1e-7, atol=1e-11)
+        if rf == 0:
+            ned = ins_np.process_error_stats(att, pos, vel, g['ref_att'], g['ref_pos'], g['ref_vel'], j0, pos_ned=True)
+            for si, s in enumerate(('max', 'avg', 'std')):
+                np.testing.assert_allclose(ned[:, si, 3:6], g['ned_proc_' + s][ai * R:(ai + 1) * R], rtol=1e-6, atol=1e-8)
+            e_end = ins_np.lla_error_ned(pos[:, -1], np.broadcast_to(g['ref_pos'][-1], (R, 3)))
+            grp = 'algo%d' % ai
+            np.testing.assert_allclose(np.abs(e_end).max(0), g['ned_end_max_' + grp], rtol=1e-6, atol=1e-8)
+            np.testing.assert_allclose(e_end.std(0), g['ned_end_std_' + grp], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CASES)
+def test_device_process_stats_and_ned_match_reference(name):
+    import ginsim
+    g = load_golden(name)
+    ctx = ginsim.default_context()
+    R, fs, rf = int(g['R']), float(g['fs']), int(g['ref_frame'])
+    acc, gyr = _errs(g)
+    truth = {'ref_accel': g['ref_accel'], 'ref_gyro': g['ref_gyro'], 'ref_pos': g['ref_pos'], 'ref_vel': g['ref_vel'],
+             'ref_att': g['ref_att']}
+    odo_err = None
+    if 'odo' in g:
+        truth['ref_odo'] = g['ref_odo']
+        odo_err = {'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])}
+    algos = _algos(g)[name]
+    job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, g['ini'], runs=R, algos=tuple(algos), odo_err=odo_err,
+                               seed=int(g['seed']), keep_traj=True, end_pos_ned=(rf == 0)).run()
+    j0 = int(round(float(g['proc_start_s']) * fs))
+    for ai, a in enumerate(algos):
+        st = job.process_stats(a, j0)
+        np.testing.assert_allclose(st, _want(g, ai, R), rtol=1e-6, atol=1e-10)
+        if rf == 0:
+            ned = job.process_stats(a, j0, pos_ned=True)
+            for si, s in enumerate(('max', 'avg', 'std')):
+                np.testing.assert_allclose(ned[:, si, 3:6], g['ned_proc_' + s][ai * R:(ai + 1) * R], rtol=1e-6, atol=2e-8)
+            end = job.stats(a)              # end-point position error already in NED metres
+            grp = 'algo%d' % ai
+            np.testing.assert_allclose(end.maxabs[3:6], g['ned_end_max_' + grp], rtol=1e-6, atol=2e-8)
+            np.testing.assert_allclose(end.std[3:6], g['ned_end_std_' + grp], rtol=1e-5, atol=2e-8)
+    job.release()
+
+
+@pytest.mark.gpu
+def test_sim_results_process_mode_and_ned():
+    """Sim.results(err_stats_start=2.0) and extra_opt='ned' through the drop-in == the reference's numbers."""
+    import os
+    from conftest import PKG
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration
+    g = load_golden('t3_mid_rf0')
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False)
+    sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=0, imu=imu, algorithm=free_integration.FreeIntegration(g['ini']),
+                      seed=int(g['seed']))
+    sim.run(int(g['R']))
+    sim.results(err_stats_start=2.0, extra_opt='ned')
+    st = sim.err_stats
+    assert sorted(st['vel']['max'].keys()) == ['algo0_0', 'algo0_1', 'algo0_2', 'algo0_3']
+    r2d = 180 / np.pi
+    for r in range(4):
+        np.testing.assert_allclose(st['att_euler']['std']['algo0_%d' % r], g['proc_att_euler_std'][r] * r2d, rtol=1e-6)
+        np.testing.assert_allclose(st['vel']['avg']['algo0_%d' % r], g['proc_vel_avg'][r], rtol=1e-6, atol=1e-10)
+        np.testing.assert_allclose(st['pos']['max']['algo0_%d' % r], g['ned_proc_max'][r], rtol=1e-6, atol=2e-8)
+    assert st['pos']['units'] == "['m', 'm', 'm']"
+    end = sim.dmgr.get_error_stats('pos', err_stats_start=-1, extra_opt='ned')
+    np.testing.assert_allclose(end['max'], g['ned_end_max_algo0'], rtol=1e-6, atol=2e-8)
