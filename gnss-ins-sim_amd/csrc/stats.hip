@@ -58,16 +58,20 @@ __global__ void __launch_bounds__(kStatBlock) stats_partial_kernel(const double*
     }
 }
 
-// one block of 64 lanes, lane c < 9 folds the partials of component c in block order (deterministic)
+// one 64-lane block per component: lanes fold the block partials they own (stride 64, fixed order), then the same
+// butterfly of Chan merges as above -- deterministic, and ~10x shorter than one lane walking all partials
 __global__ void stats_final_kernel(const Mom* __restrict__ partial, int blocks, ginsim_stats* __restrict__ out) {
-    const int c = threadIdx.x;
-    if (c >= 9) return;
-    Mom t = partial[c * blocks];
-    for (int b = 1; b < blocks; ++b) t = merge(t, partial[c * blocks + b]);
-    if (c == 0) out->count = t.n;
-    out->mean[c] = t.mean;
-    out->m2[c] = t.m2;
-    out->maxabs[c] = t.mx;
+    const int c = blockIdx.x;
+    Mom t{0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < blocks; b += 64) t = merge(t, partial[c * blocks + b]);
+#pragma unroll
+    for (int mask = 32; mask >= 1; mask >>= 1) t = merge(t, shfl_xor(t, mask));
+    if (threadIdx.x == 0) {
+        if (c == 0) out->count = t.n;
+        out->mean[c] = t.mean;
+        out->m2[c] = t.m2;
+        out->maxabs[c] = t.mx;
+    }
 }
 
 // Process-error statistics: one lane per run walks the time axis of its trajectory (coalesced across lanes, the
@@ -139,7 +143,7 @@ hipError_t launch_end_stats(const double* end_err, int64_t runs, void* scratch, 
     Mom* partial = reinterpret_cast<Mom*>(scratch);
     ginsim_stats* out = reinterpret_cast<ginsim_stats*>(partial + 9 * blocks);
     hipLaunchKernelGGL(stats_partial_kernel, dim3(blocks, 9), dim3(kStatBlock), 0, s, end_err, runs, partial);
-    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(64), 0, s, partial, blocks, out);
+    hipLaunchKernelGGL(stats_final_kernel, dim3(9), dim3(64), 0, s, partial, blocks, out);
     return hipGetLastError();
 }
 
