@@ -71,6 +71,7 @@ def main():
     ap.add_argument('--fs', type=float, default=100.0)
     ap.add_argument('--ref-frame', type=int, default=1)
     ap.add_argument('--stats-only', action='store_true', help='do not materialise sensors/trajectories')
+    ap.add_argument('--precision', choices=['f64', 'f32'], default='f64', help="f32 = BASELINE config 5's single-precision kernel")
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
     args = ap.parse_args()
 
@@ -101,7 +102,8 @@ def main():
     n = truth['ref_accel'].shape[0]
     keep = not args.stats_only
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, algos=('free',), seed=seed,
-                               keep_sensors=keep, keep_traj=keep)
+                               keep_sensors=keep, keep_traj=keep, precision=args.precision)
+    unit_bytes = BYTES_PER_SAMPLE_MC if args.precision == 'f64' else BYTES_PER_SAMPLE_MC // 2
     group = dist.group.WORLD if world > 1 else None
     device = torch.device('cuda', local_rank)
     nsteps = args.warmup + args.steps
@@ -143,25 +145,25 @@ def main():
 
     if rank == 0:
         total_units = float(world) * R * n * args.steps
-        alg_bytes = (BYTES_PER_SAMPLE_MC if keep else 0) * R * n + 72 * R      # per launch, per GPU
+        alg_bytes = (unit_bytes if keep else 0) * R * n + 72 * R      # per launch, per GPU
         achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
         r2d = 180.0 / np.pi
         out = {
             'metric': 'Monte-Carlo IMU samples integrated/sec', 'value': total_units / elapsed,
             'unit': 'sample*MC/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: %s @%g Hz (n=%d), mid-accuracy 6-axis IMU, ref_frame=%d, '
                                    'free_integration, %d MC runs per GPU, %s' %
                                    (args.profile, fs, n, rf, R,
-                                    'sensors+trajectories materialised (120 B/sample*MC)' if keep else 'stats-only'),
+                                    'sensors+trajectories materialised (%d B/sample*MC)' % unit_bytes if keep else 'stats-only'),
                        'runs_per_gpu': R, 'samples_per_run': n, 'total_runs_per_step': world * R,
                        'parallelism': 'mc-shard x%d, one all-reduce of the 28-double stats record' % world,
                        'device': ctx.name()},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': pmc_traffic('mc_kernel_rf%d_free_%s' % (rf, 'keep' if keep else 'stats')),
-                         'kernel': 'ginsim::mc_kernel<%d,1,false>' % rf, 'kernel_ms_avg': kern_avg_ms,
+                         'traffic': pmc_traffic('mc_kernel_rf%d_free_%s' % (rf, 'keep' if keep else 'stats')) if args.precision == 'f64' else None,
+                         'kernel': ('ginsim::mc_kernel<%d,1,false>' if args.precision == 'f64' else 'ginsim::f32::mc_kernel_f32<%d,1>') % rf, 'kernel_ms_avg': kern_avg_ms,
                          'algorithmic_bytes_per_launch': alg_bytes,
                          'note': 'fp64 transcendental/VALU-bound, not HBM-bound: see DESIGN.md (roofline)'},
             'result': {'att_std_deg': (merged.std[:3] * r2d).tolist(), 'vel_std_mps': merged.std[6:9].tolist(),

@@ -25,6 +25,7 @@ SOURCES = [
     # machine-LICM hoists ~35 fp64 polynomial constants (SGPR pairs) out of the time loop and then spills them
     # to VGPR lanes; without it they are re-materialised with s_mov next to their use (SGPR spills 192 -> 71)
     ('mc_kernel.hip', ['--offload-arch=' + ARCH, '-mllvm', '-disable-machine-licm']),
+    ('mc_kernel_f32.hip', ['--offload-arch=' + ARCH, '-mllvm', '-disable-machine-licm']),
     ('stats.hip', ['--offload-arch=' + ARCH]),
     ('allan.hip', ['--offload-arch=' + ARCH]),
     ('ginsim_api.hip', ['--offload-arch=' + ARCH]),

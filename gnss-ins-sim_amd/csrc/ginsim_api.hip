@@ -25,6 +25,9 @@ void set_error(const char* fmt, ...) {
 }
 
 hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream);
+hipError_t launch_mc_f32(const ginsim_mc_params& p, hipStream_t stream);
+hipError_t launch_gather_runs_f32(const float* series, int C, int64_t n, int64_t runs, const int64_t* ids, int nsel,
+                                  double* out, hipStream_t s);
 hipError_t launch_aux(const ginsim_aux_params& p, hipStream_t s);
 hipError_t launch_rng_probe(uint64_t seed, uint64_t run, uint32_t stream, int64_t count, double* z0, double* z1,
                             uint32_t* words, hipStream_t stream_h);
@@ -280,8 +283,14 @@ int ginsim_mc_run(ginsim_ctx* c, const ginsim_mc_params* p) {
         rc = check_sensor(p->gyro, "gyro");
         if (rc) return rc;
     }
+    REQUIRE(p->precision == 0 || p->precision == 1, "mc_run: precision must be 0 (fp64) or 1 (fp32)");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(launch_mc(*p, c->stream));
+    if (p->precision == 1) {
+        REQUIRE(!p->given_sensors && p->algo_mask != 0, "mc_run: the fp32 kernel supports generate mode with an algorithm only");
+        HIP_TRY(launch_mc_f32(*p, c->stream));
+    } else {
+        HIP_TRY(launch_mc(*p, c->stream));
+    }
     return GINSIM_OK;
 }
 
@@ -356,6 +365,24 @@ int ginsim_gather_runs(ginsim_ctx* c, const double* series, int32_t ncomp, int64
     HIP_TRY(out.alloc(out_bytes));
     HIP_TRY(hipMemcpyAsync(ids.p, run_ids, sizeof(int64_t) * nsel, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_gather_runs(series, ncomp, n, runs, ids.as<int64_t>(), nsel, out.as<double>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(host_out, out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_gather_runs_f32(ginsim_ctx* c, const float* series, int32_t ncomp, int64_t n, int64_t runs,
+                           const int64_t* run_ids, int32_t nsel, double* host_out) {
+    REQUIRE(c && series && run_ids && host_out, "gather_runs_f32: NULL argument");
+    REQUIRE(ncomp >= 1 && n >= 1 && runs >= 1 && nsel >= 1, "gather_runs_f32: bad sizes");
+    for (int i = 0; i < nsel; ++i)
+        REQUIRE(run_ids[i] >= 0 && run_ids[i] < runs, "gather_runs_f32: run id %lld out of range", (long long)run_ids[i]);
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf ids, out;
+    const size_t out_bytes = sizeof(double) * (size_t)nsel * n * ncomp;
+    HIP_TRY(ids.alloc(sizeof(int64_t) * nsel));
+    HIP_TRY(out.alloc(out_bytes));
+    HIP_TRY(hipMemcpyAsync(ids.p, run_ids, sizeof(int64_t) * nsel, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_gather_runs_f32(series, ncomp, n, runs, ids.as<int64_t>(), nsel, out.as<double>(), c->stream));
     HIP_TRY(hipMemcpyAsync(host_out, out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GINSIM_OK;

@@ -39,7 +39,8 @@ class McParams(C.Structure):
                 ('in_accel', C.c_void_p), ('in_gyro', C.c_void_p), ('in_odo', C.c_void_p),
                 ('out_accel', C.c_void_p), ('out_gyro', C.c_void_p), ('out_odo', C.c_void_p),
                 ('out_traj', C.c_void_p * 2), ('out_end', C.c_void_p * 2),
-                ('wave_trace', C.c_void_p), ('block_threads', C.c_int32), ('end_pos_ned', C.c_int32)]
+                ('wave_trace', C.c_void_p), ('block_threads', C.c_int32), ('end_pos_ned', C.c_int32),
+                ('precision', C.c_int32), ('reserved', C.c_int32)]
 
 
 class PathgenParams(C.Structure):
@@ -90,6 +91,8 @@ _SIGS = {
     'ginsim_stats_merge': (C.c_int, [C.POINTER(Stats), C.c_int32, C.POINTER(Stats)]),
     'ginsim_gather_runs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
                                      C.POINTER(C.c_int64), C.c_int32, _PD]),
+    'ginsim_gather_runs_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
+                                         C.POINTER(C.c_int64), C.c_int32, _PD]),
     'ginsim_free_integration': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, _PD, _PD, _PD,
                                           C.c_int64, C.c_int64, _PD, C.c_int32, C.c_int32, C.c_uint64,
                                           _PD, _PD, _PD]),

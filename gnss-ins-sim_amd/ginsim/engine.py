@@ -236,7 +236,7 @@ class MonteCarloJob(object):
 
     def __init__(self, ctx, fs, ref_frame, truth, accel_err, gyro_err, ini, runs, algos=('free',),
                  odo_err=None, earth_rot=True, seed=0, run_offset=0, ini_first=0,
-                 keep_sensors=False, keep_traj=False, end_pos_ned=False):
+                 keep_sensors=False, keep_traj=False, end_pos_ned=False, precision='f64'):
         self.ctx = ctx
         self.algos = tuple(algos)
         for a in self.algos:
@@ -252,6 +252,11 @@ class MonteCarloJob(object):
         p.algo_mask = sum(ALGO_BITS[a] for a in self.algos)
         p.earth_rot = int(bool(earth_rot))
         p.end_pos_ned = int(bool(end_pos_ned))
+        if precision not in ('f64', 'f32'):
+            raise ValueError("precision must be 'f64' or 'f32'")
+        self.precision = precision
+        p.precision = 1 if precision == 'f32' else 0
+        self._esize = 4 if precision == 'f32' else 8
         if ini is None:
             if self.algos:
                 raise ValueError('initial states are required when an algorithm is integrated')
@@ -277,8 +282,10 @@ class MonteCarloJob(object):
         if self.want_odo:
             self._bufs['ref_odo'] = ctx.upload(np.asarray(truth['ref_odo'], dtype=np.float64))
             p.ref_odo = self._bufs['ref_odo'].ptr
+        # per-run position origin for the fp32 displacement series (free_integration.py:96-98 / :127-128)
+        self._ini_table, self._ini_first, self._ref_frame = table, int(ini_first), int(ref_frame)
         # outputs
-        plane = self.n * self.runs * 8
+        plane = self.n * self.runs * self._esize
         if self.keep_sensors:
             self._bufs['accel'] = ctx.malloc(3 * plane)
             self._bufs['gyro'] = ctx.malloc(3 * plane)
@@ -298,9 +305,9 @@ class MonteCarloJob(object):
     def bytes_written(self):
         per_sample = 0
         if self.keep_sensors:
-            per_sample += 48 + (8 if self.want_odo else 0)
+            per_sample += 6 * self._esize + (self._esize if self.want_odo else 0)
         if self.keep_traj:
-            per_sample += 72 * len(self.algos)
+            per_sample += 9 * self._esize * len(self.algos)
         return per_sample * self.n * self.runs + 72 * self.runs * len(self.algos)
 
     def launch(self):
@@ -320,8 +327,8 @@ class MonteCarloJob(object):
     def process_stats(self, algo, first_sample=0, pos_ned=False):
         """Per-run statistics of the error over time (samples >= first_sample): (runs, 3, 9) = max|e|, mean, std.
         Needs the trajectories (keep_traj=True) and truth['ref_att'/'ref_pos'/'ref_vel']."""
-        if not self.keep_traj:
-            raise ValueError('process-error statistics need the trajectories (keep_traj=True)')
+        if not self.keep_traj or self.precision != 'f64':
+            raise ValueError('process-error statistics need fp64 trajectories (keep_traj=True, precision="f64")')
         if 'ref_nav' not in self._bufs:
             self._bufs['ref_nav'] = self.ctx.upload(self._ref_nav)
         out = np.empty((self.runs, 3, 9))
@@ -331,8 +338,8 @@ class MonteCarloJob(object):
 
     def stats_from_traj(self, algo, pos_ned=False):
         """End-point statistics recomputed on the device from the kept trajectories (used for extra_opt='ned')."""
-        if not self.keep_traj:
-            raise ValueError('needs the trajectories (keep_traj=True)')
+        if not self.keep_traj or self.precision != 'f64':
+            raise ValueError('needs fp64 trajectories (keep_traj=True, precision="f64")')
         if 'ref_nav' not in self._bufs:
             self._bufs['ref_nav'] = self.ctx.upload(self._ref_nav)
         s = _lib.Stats()
@@ -347,8 +354,9 @@ class MonteCarloJob(object):
     def _gather(self, ptr, ncomp, run_ids):
         ids = np.ascontiguousarray(np.asarray(run_ids, dtype=np.int64).reshape(-1))
         out = np.empty((ids.size, self.n, ncomp))
-        check(lib.ginsim_gather_runs(self.ctx.handle, ptr, ncomp, self.n, self.runs,
-                                     ids.ctypes.data_as(C.POINTER(C.c_int64)), ids.size, dptr(out)))
+        fn = lib.ginsim_gather_runs_f32 if self.precision == 'f32' else lib.ginsim_gather_runs
+        check(fn(self.ctx.handle, ptr, ncomp, self.n, self.runs, ids.ctypes.data_as(C.POINTER(C.c_int64)), ids.size,
+                 dptr(out)))
         return out
 
     def sensors(self, name, run_ids):
@@ -364,8 +372,16 @@ class MonteCarloJob(object):
         if not self.keep_traj:
             raise ValueError('trajectories were not kept (keep_traj=False)')
         base = self._bufs['traj_' + algo].ptr
-        plane = self.n * self.runs * 8
-        return tuple(self._gather(base + 3 * k * plane, 3, run_ids) for k in range(3))
+        plane = self.n * self.runs * self._esize
+        att, pos, vel = (self._gather(base + 3 * k * plane, 3, run_ids) for k in range(3))
+        if self.precision == 'f32':         # the device series is the displacement from the run's initial position
+            from gnss_ins_sim.geoparams import geoparams
+            ids = np.asarray(run_ids, dtype=np.int64).reshape(-1)
+            for k, r in enumerate(ids):
+                call = self._ini_first + int(r)
+                ini = self._ini_table[call if call < self._ini_table.shape[0] else 0]
+                pos[k] += geoparams.lla2ecef(ini[0:3]) if self._ref_frame == 1 else ini[0:3]
+        return att, pos, vel
 
     def release(self):
         for b in self._bufs.values():

@@ -83,7 +83,7 @@ class _McResults(object):
 
 class Sim(object):
     def __init__(self, fs, motion_def, ref_frame=0, imu=None, mode=None, env=None, algorithm=None, *,
-                 seed=None, keep_trajectories='auto', max_device_bytes=64 * 2 ** 30, device=None, geo_mag_n=None):
+                 seed=None, keep_trajectories='auto', max_device_bytes=64 * 2 ** 30, device=None, geo_mag_n=None, precision='f64'):
         self.name, self.version = NAME, VERSION
         self.fs, self.imu, self.mode, self.env = fs, imu, mode, env
         self.ref_frame = ref_frame if ref_frame in (0, 1) else 0
@@ -98,6 +98,7 @@ class Sim(object):
         self.sum = ''
         self.seed, self.keep_trajectories, self.max_device_bytes, self.device = seed, keep_trajectories, max_device_bytes, device
         self.geo_mag_n = geo_mag_n
+        self.precision = precision      # 'f32': single-precision kernel (tolerances: tests/test_gpu_fp32.py)
         self.mc = None
         if env is not None:
             raise NotImplementedError('vibration models (env) are outside the accelerated hot path; every BASELINE '
@@ -223,7 +224,7 @@ class Sim(object):
                                            g['ini'], runs=count, algos=tuple(g['kinds']), odo_err=self.imu.odo_err,
                                            earth_rot=g['earth_rot'], seed=seed, run_offset=first,
                                            ini_first=g['first'] + first, keep_sensors=bool(keep) and sensor_job is None,
-                                           keep_traj=bool(keep))
+                                           keep_traj=bool(keep), precision=self.precision)
                 job.launch()
                 if sensor_job is None and keep:
                     sensor_job = job

@@ -123,6 +123,11 @@ typedef struct {
     int32_t   block_threads;  /* workgroup size: 0 (default), 64, 128 or 256 */
     int32_t   end_pos_ned;    /* ref_frame 0: report the end-point position error in local NED metres (extra_opt='ned',
                                * ins_data_manager.py:474-488, 542-552) instead of [rad, rad, m] */
+    int32_t   precision;      /* 0: fp64 (default).  1: fp32 kernel -- out_accel/out_gyro/out_odo/out_traj point to FLOAT
+                               * buffers of the same [component][sample][run] shape; the position planes of out_traj hold
+                               * the displacement from the run's initial position (ECEF-based for ref_frame 1, LLA for 0);
+                               * out_end stays double.  Generate mode only. */
+    int32_t   reserved;
 } ginsim_mc_params;
 
 int ginsim_mc_run(ginsim_ctx* ctx, const ginsim_mc_params* p);
@@ -173,6 +178,9 @@ int ginsim_stats_merge(const ginsim_stats* parts, int32_t nparts, ginsim_stats* 
 /* ---- data access: pull selected runs out of a [ncomp][n][runs] device series into host [nsel][n][ncomp] */
 int ginsim_gather_runs(ginsim_ctx* ctx, const double* series, int32_t ncomp, int64_t n, int64_t runs,
                        const int64_t* run_ids /*host*/, int32_t nsel, double* host_out);
+/* same for a float series written by the fp32 kernel (values widened to double on the way out) */
+int ginsim_gather_runs_f32(ginsim_ctx* ctx, const float* series, int32_t ncomp, int64_t n, int64_t runs,
+                           const int64_t* run_ids /*host*/, int32_t nsel, double* host_out);
 
 /* ---- given-data mechanisation with host buffers: the plugin's .run(set_of_input) boundary
  *      (free_integration.py:63-174 / free_integration_odo.py:63-160).  gyro/accel [R][n][3], odo [R][n],
