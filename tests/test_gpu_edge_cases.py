@@ -1,0 +1,163 @@
+"""Edge cases of the hot path: degenerate sizes, ragged batches, multi-column initial states, 64-bit run ids,
+argument validation through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+D2R = np.pi / 180
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import ginsim
+    c = ginsim.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope='module')
+def turn():
+    from ginsim import workloads
+    out = {}
+    for rf in (0, 1):
+        ini, truth, _ = workloads.truth_from_profile('turn_90deg', 100.0, rf)
+        out[rf] = (ini, truth)
+    return out
+
+
+def _cut(truth, n):
+    return {k: (v[:n] if hasattr(v, 'shape') and v.shape and v.shape[0] >= n else v) for k, v in truth.items()}
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 33])
+@pytest.mark.parametrize('rf', [0, 1])
+def test_tiny_sample_counts(ctx, turn, n, rf):
+    """n = 1: only the initial state exists (free_integration.py:96-102); n = 2: one step."""
+    import ginsim
+    from ginsim import workloads
+    from oracle import c_oracle
+    ini, truth = turn[rf]
+    t = _cut(truth, n)
+    acc, gyr = workloads.imu_grade('low-accuracy')
+    job = ginsim.MonteCarloJob(ctx, 100.0, rf, t, acc, gyr, ini, runs=5, algos=('free', 'odo'),
+                               odo_err={'scale': 0.99, 'stdv': 0.1}, seed=8, keep_sensors=True, keep_traj=True).run()
+    for a in ('free', 'odo'):
+        end, traj, sens = c_oracle.mc_run(8, 0, 5, 100.0, rf, t, acc, gyr, ini, algo=a, odo_err={'scale': 0.99, 'stdv': 0.1}, keep=5)
+        att, pos, vel = job.trajectories(a, np.arange(5))
+        assert att.shape == (5, n, 3)
+        np.testing.assert_allclose(vel, traj[:, :, 6:9], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(pos, traj[:, :, 3:6], rtol=1e-14, atol=1e-9)
+        np.testing.assert_allclose(job.end_errors(a)[:, 6:9], end[:, 6:9], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(job.sensors('accel', np.arange(5)), sens[:, :, 0:3], rtol=0, atol=1e-12)
+    job.release()
+
+
+def test_single_run_and_wave_boundaries(ctx, turn):
+    import ginsim
+    from ginsim import workloads
+    ini, truth = turn[1]
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    ref = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=257, seed=3).run().end_errors('free')
+    for R in (1, 63, 64, 65, 255, 256):
+        e = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=R, seed=3).run().end_errors('free')
+        np.testing.assert_array_equal(e, ref[:R])
+    st = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=1, seed=3).run().stats('free')
+    assert st.count == 1 and np.all(st.std == 0) and np.allclose(st.mean, ref[0])
+
+
+def test_run_ids_beyond_32_bits(ctx, turn):
+    import ginsim
+    from ginsim import workloads
+    from oracle import c_oracle
+    ini, truth = turn[1]
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    off = 2 ** 40 + 12345
+    dev = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=70, seed=2 ** 63 + 9, run_offset=off).run().end_errors('free')
+    end, _, _ = c_oracle.mc_run(2 ** 63 + 9, off, 70, 100.0, 1, truth, acc, gyr, ini)
+    np.testing.assert_allclose(dev[:, 6:9], end[:, 6:9], rtol=0, atol=1e-10)
+    low = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=70, seed=2 ** 63 + 9, run_offset=12345).run().end_errors('free')
+    assert np.abs(dev - low).max() > 1e-6          # the high word of the run id really enters the counter
+
+
+@pytest.mark.parametrize('rf', [0, 1])
+def test_multi_column_initial_states_and_run_times(ctx, turn, rf):
+    """free_integration.py:42-61, 85-87: run r uses column r while r < k, else column 0; run_times keeps counting."""
+    import ginsim
+    from ginsim import workloads
+    from oracle import c_oracle
+    ini, truth = turn[rf]
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    k = 5
+    table = np.repeat(ini[:, None], k, axis=1)
+    table[3, :] += np.arange(k) * 0.5           # different initial forward speed per column
+    table[6, :] += np.arange(k) * 1e-3          # and yaw
+    g = np.full((1, k), 9.79)
+    table10 = np.vstack([table, g])
+    for tab in (table, table10):
+        dev = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc, gyr, tab, runs=9, seed=4, ini_first=2).run().end_errors('free')
+        end, _, _ = c_oracle.mc_run(4, 0, 9, 100.0, rf, truth, acc, gyr, tab, ini_first=2)
+        np.testing.assert_allclose(dev[:, 6:9], end[:, 6:9], rtol=0, atol=1e-9)
+        assert np.abs(dev[0, 6:9] - dev[5, 6:9]).max() > 1e-3      # column 2 vs column 0
+
+
+def test_sim_second_run_keeps_counting_columns(ctx, turn):
+    import os
+    from conftest import PKG
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration
+    ini, _ = turn[1]
+    table = np.repeat(ini[:, None], 4, axis=1)
+    table[3, :] += np.arange(4)
+    algo = free_integration.FreeIntegration(table)
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    imu = imu_model.IMU(accuracy='high-accuracy', axis=6, gps=False)
+    ends = []
+    for _ in range(2):
+        sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, algorithm=algo, seed=1)
+        sim.run(3)
+        ends.append(np.stack([sim.dmgr.vel.data['algo0_%d' % r][-1] for r in range(3)]))
+    assert algo.run_times == 6
+    sp = lambda v: np.linalg.norm(v, axis=1)
+    # an initial body-speed error d rotates with the vehicle through the 90-degree turn: |v| = sqrt(10^2 + d^2)
+    np.testing.assert_allclose(sp(ends[0]), np.sqrt(100.0 + np.array([0.0, 1.0, 4.0])), atol=2e-3)     # columns 0,1,2
+    np.testing.assert_allclose(sp(ends[1]), np.sqrt(100.0 + np.array([9.0, 0.0, 0.0])), atol=2e-3)     # column 3, then column 0
+
+
+def test_white_drift_axes_mixed(ctx, turn):
+    """b_corr = inf on some axes only (pathgen.py:591-593)."""
+    import ginsim
+    from oracle import ins_np
+    ini, truth = turn[1]
+    acc = {'b': np.array([1e-3, 0, 0]), 'b_drift': np.array([1e-3, 2e-3, 3e-3]), 'b_corr': np.array([np.inf, 50.0, np.inf]),
+           'vrw': np.array([1e-3, 1e-3, 1e-3])}
+    gyr = {'b': np.zeros(3), 'b_drift': np.array([1e-4, 1e-4, 1e-4]), 'b_corr': np.array([100.0, np.inf, 100.0]),
+           'arw': np.array([1e-4, 1e-4, 1e-4])}
+    job = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=3, seed=6, keep_sensors=True).run()
+    a, g = ins_np.mc_sensors(6, np.arange(3), 100.0, truth['ref_accel'], truth['ref_gyro'], acc, gyr)
+    np.testing.assert_allclose(job.sensors('accel', [0, 1, 2]), a, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(job.sensors('gyro', [0, 1, 2]), g, rtol=0, atol=1e-14)
+
+
+def test_argument_validation(ctx, turn):
+    import ginsim
+    from ginsim import workloads
+    ini, truth = turn[1]
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    with pytest.raises(ValueError):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4, algos=('odo',))          # no odometer model
+    with pytest.raises(ValueError):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4, algos=('kalman',))
+    bad = dict(acc)
+    bad['vrw'] = np.array([np.nan, 0, 0])
+    with pytest.raises(ValueError, match='non-finite'):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, bad, gyr, ini, runs=4).run()
+    job = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4)
+    job.params.ref_frame = 3
+    with pytest.raises(ValueError, match='ref_frame'):
+        job.run()
+    with pytest.raises(ValueError):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4).run().trajectories('free', [0])   # not kept
+    with pytest.raises(ValueError, match='out of range'):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4, keep_traj=True).run().trajectories('free', [4])
