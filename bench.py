@@ -73,6 +73,9 @@ def main():
     ap.add_argument('--stats-only', action='store_true', help='do not materialise sensors/trajectories')
     ap.add_argument('--precision', choices=['f64', 'f32'], default='f64', help="f32 = BASELINE config 5's single-precision kernel")
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for tests)')
+    ap.add_argument('--shared-device', action='store_true',
+                    help='TEST ONLY: every rank uses GPU 0 (exercises the N > 1 control flow on a one-GPU box)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -90,10 +93,15 @@ def main():
     import ginsim
     from ginsim import workloads, distributed
 
+    if args.shared_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
     ctx = ginsim.Context(local_rank)
 
     fs, rf, R, seed = args.fs, args.ref_frame, args.runs_per_gpu, 20260923
@@ -105,7 +113,7 @@ def main():
                                keep_sensors=keep, keep_traj=keep, precision=args.precision)
     unit_bytes = BYTES_PER_SAMPLE_MC if args.precision == 'f64' else BYTES_PER_SAMPLE_MC // 2
     group = dist.group.WORLD if world > 1 else None
-    device = torch.device('cuda', local_rank)
+    device = torch.device('cuda', local_rank) if args.backend == 'nccl' else torch.device('cpu')
     nsteps = args.warmup + args.steps
     if 2 * nsteps > 8192:
         sys.exit('too many steps for the event pool')

@@ -1,0 +1,95 @@
+"""N > 1 on real hardware.  The GPU box has ONE device, so two ranks share GPU 0 and exchange over gloo; the code
+path (sharding by global run id, per-rank launch, one all-reduce of the statistics record, merge) is the one the
+8-GPU RCCL run takes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, PKG
+
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _bench(nproc, extra):
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr',
+           '127.0.0.1', '--master-port', str(_port()), os.path.join(REPO, 'bench.py'), '--gpus', str(nproc)] + extra
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(REPO, 'bench.py')] + extra
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1]
+    return json.loads(line)
+
+
+def test_bench_two_ranks_share_the_work():
+    common = ['--steps', '2', '--warmup', '1', '--runs-per-gpu', '8192', '--cpu-baseline-seconds', '0']
+    one = _bench(1, common)
+    two = _bench(2, common + ['--backend', 'gloo', '--shared-device'])
+    assert two['n_gpus'] == 2 and two['scaling'] == 'weak' and two['config']['total_runs_per_step'] == 16384
+    assert two['result']['runs'] == 16384 and one['result']['runs'] == 8192
+    # merged statistics of 16 384 runs vs 8 192 runs of the same distribution
+    np.testing.assert_allclose(two['result']['att_std_deg'], one['result']['att_std_deg'], rtol=0.05)
+    assert two['value'] > 0 and 'roofline' in two and 'cpu_baseline' not in two
+
+
+_SIM_WORKER = r'''
+import os, sys
+sys.path[:0] = [%(pkg)r, %(repo)r]
+import numpy as np, torch.distributed as dist
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=int(sys.argv[1]), world_size=2)
+os.environ['LOCAL_RANK'] = '0'
+from gnss_ins_sim.sim import imu_model, ins_sim
+from demo_algorithms import free_integration
+csv = os.path.join(%(pkg)r, 'motion_profiles', 'turn_90deg.csv')
+ini = np.genfromtxt(csv, delimiter=',', skip_header=1, max_rows=1)
+ini[0:2] *= np.pi / 180; ini[6:9] *= np.pi / 180
+imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False)
+sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, algorithm=free_integration.FreeIntegration(ini), seed=77)
+sim.run(1001)
+sim.results(err_stats_start=-1)
+keys = list(sim.dmgr.accel.data.keys())
+np.save(sys.argv[2], np.concatenate([sim.err_stats['vel']['std'], sim.err_stats['att_euler']['max'], [keys[0], keys[-1], len(keys)]]))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_sim_shards_runs_across_ranks(tmp_path):
+    """Sim under torch.distributed (2 ranks): each rank holds its shard, statistics are those of all 1001 runs."""
+    script = tmp_path / 'w.py'
+    script.write_text(_SIM_WORKER % {'pkg': PKG, 'repo': REPO, 'port': _port()})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(tmp_path / ('r%d.npy' % r))], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    a, b = np.load(tmp_path / 'r0.npy'), np.load(tmp_path / 'r1.npy')
+    np.testing.assert_array_equal(a[:6], b[:6])                 # every rank ends with the same merged statistics
+    assert (a[6], a[7], a[8]) == (0, 500, 501) and (b[6], b[7], b[8]) == (501, 1000, 500)
+    # reference: one process, all runs
+    sys.path[:0] = [PKG]
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    ini = np.genfromtxt(csv, delimiter=',', skip_header=1, max_rows=1)
+    ini[0:2] *= np.pi / 180
+    ini[6:9] *= np.pi / 180
+    sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False),
+                      algorithm=free_integration.FreeIntegration(ini), seed=77)
+    sim.run(1001)
+    sim.results(err_stats_start=-1)
+    np.testing.assert_allclose(a[:3], sim.err_stats['vel']['std'], rtol=1e-10)
+    np.testing.assert_array_equal(a[3:6], sim.err_stats['att_euler']['max'])
