@@ -16,6 +16,45 @@ namespace ginsim {
 
 #define GINSIM_FM __device__ __forceinline__
 
+// A loop-invariant fp64 constant held in a VGPR pair.  v_fma_f64 cannot take a 64-bit literal, so every
+// polynomial coefficient lives in registers: left to the compiler they become SGPR pairs that are either hoisted
+// out of the time loop and spilled to VGPR lanes (v_readlane per use) or re-materialised with two s_mov_b32 per
+// use (~220 scalar moves per step, which a lone wavefront on its SIMD cannot hide).  The empty asm makes the
+// value opaque, so it is materialised once and stays in vector registers.
+GINSIM_FM double vconst(double k) {
+    int lo = __double2loint(k), hi = __double2hiint(k);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return __hiloint2double(hi, lo);
+}
+
+struct MathConsts {
+    double lg[10];          // 1/3 .. 1/21 (atanh series)
+    double ln2_hi, ln2_lo;
+    double sc[7];           // sin: -1/3!, 1/5!, ... -1/15!
+    double cc[8];           // cos: -1/2!, 1/4!, ... 1/16!
+    double pio2_hi, pio2_lo;
+    // OPAQUE = true pins the 29 constants in VGPRs (58 registers); false leaves them to the compiler (SGPR literals),
+    // which is what the two-algorithm kernels need to stay under 256 VGPRs without scratch spills.
+    template <bool OPAQUE>
+    GINSIM_FM void init() {
+        auto vconst = [](double x) { return OPAQUE ? ginsim::vconst(x) : x; };
+#pragma unroll
+        for (int k = 0; k < 10; ++k) lg[k] = vconst(1.0 / (2 * k + 3));
+        ln2_hi = vconst(6.93147180369123816490e-01);
+        ln2_lo = vconst(1.90821492927058770002e-10);
+        const double s[7] = {-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0, -1.0 / 39916800.0, 1.0 / 6227020800.0,
+                             -1.0 / 1307674368000.0};
+        const double c[8] = {-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0, 1.0 / 479001600.0,
+                             -1.0 / 87178291200.0, 1.0 / 20922789888000.0};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sc[k] = vconst(s[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cc[k] = vconst(c[k]);
+        pio2_hi = vconst(1.57079632679489655800e+00);
+        pio2_lo = vconst(6.12323399573676603587e-17);
+    }
+};
+
 // 1/x to ~1 ulp: hardware v_rcp_f64 estimate + two Newton steps.
 GINSIM_FM double rcp_nr(double x) {
     double y = __builtin_amdgcn_rcp(x);
@@ -117,6 +156,63 @@ GINSIM_FM void rotate_sincos(double d, double& s, double& c) {
     const double s0 = s, c0 = c;
     s = __builtin_fma(c0, sd, __builtin_fma(s0, cm1, s0));      // s + s (cos d - 1) + c sin d
     c = __builtin_fma(-s0, sd, __builtin_fma(c0, cm1, c0));     // c + c (cos d - 1) - s sin d
+}
+
+// ---- the same functions with their coefficients taken from VGPR-resident constants (hot loop) -------------
+GINSIM_FM double log_u01(double u, const MathConsts& k) {
+    uint32_t hx = (uint32_t)__double2hiint(u) + (0x3ff00000u - 0x3fe6a09eu);
+    const int e = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    const double m = __hiloint2double((int)hx, __double2loint(u));
+    const double num = m - 1.0, den = m + 1.0;
+    const double y = rcp_nr(den);
+    double s = num * y;
+    s = __builtin_fma(__builtin_fma(-den, s, num), y, s);
+    const double t = s * s;
+    double p = k.lg[9];
+#pragma unroll
+    for (int i = 8; i >= 0; --i) p = __builtin_fma(p, t, k.lg[i]);
+    const double s2 = s + s;
+    const double lnm = __builtin_fma(s2 * t, p, s2);
+    const double ed = (double)e;
+    return __builtin_fma(ed, k.ln2_hi, __builtin_fma(ed, k.ln2_lo, lnm));
+}
+
+GINSIM_FM void sincospi_02(double x, double& s, double& c, const MathConsts& k) {
+    const double x2 = x + x;
+    const double kd = __builtin_rint(x2);
+    const double r = x2 - kd;
+    const int q = (int)kd;
+    const double th = __builtin_fma(r, k.pio2_hi, r * k.pio2_lo);
+    const double t = th * th;
+    double ps = k.sc[6];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) ps = __builtin_fma(ps, t, k.sc[i]);
+    const double sq = __builtin_fma(th * t, ps, th);
+    double pc = k.cc[7];
+#pragma unroll
+    for (int i = 6; i >= 0; --i) pc = __builtin_fma(pc, t, k.cc[i]);
+    const double cq = __builtin_fma(t, pc, 1.0);
+    const bool swap = (q & 1) != 0;
+    const double ss = swap ? cq : sq;
+    const double cs = swap ? sq : cq;
+    s = __hiloint2double(__double2hiint(ss) ^ ((q & 2) << 30), __double2loint(ss));
+    c = __hiloint2double(__double2hiint(cs) ^ (((q + 1) & 2) << 30), __double2loint(cs));
+}
+
+GINSIM_FM void rotate_sincos(double d, double& s, double& c, const MathConsts& k) {
+    const double t = d * d;
+    double ps = k.sc[4];
+#pragma unroll
+    for (int i = 3; i >= 0; --i) ps = __builtin_fma(ps, t, k.sc[i]);
+    const double sd = __builtin_fma(d * t, ps, d);
+    double pc = k.cc[5];
+#pragma unroll
+    for (int i = 4; i >= 0; --i) pc = __builtin_fma(pc, t, k.cc[i]);
+    const double cm1 = t * pc;
+    const double s0 = s, c0 = c;
+    s = __builtin_fma(c0, sd, __builtin_fma(s0, cm1, s0));
+    c = __builtin_fma(-s0, sd, __builtin_fma(c0, cm1, c0));
 }
 
 }  // namespace ginsim

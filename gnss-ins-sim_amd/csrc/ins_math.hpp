@@ -110,7 +110,7 @@ struct Att {
     // the step (angle-addition with short sin/cos(d) series, fastmath.hpp) instead of re-evaluated, and are
     // re-evaluated exactly when `resync` is set (every kTrigResync steps, wave-uniform), when the pitch folds
     // over +-pi/2, or when a step exceeds 0.25 rad.  +-2pi wraps leave the trig untouched.
-    GINSIM_HD void step(const Vec3& w, double dt, bool resync) {
+    GINSIM_HD void step(const Vec3& w, double dt, bool resync, const MathConsts& mk) {
         const double q = w.z * cr + w.y * sr;
         const double icp = rcp_nr(cp);
         const double dy = q * icp * dt;
@@ -131,9 +131,9 @@ struct Att {
             if (r > kPi) r -= kTwoPi; else if (r < -kPi) r += kTwoPi;
             set(y, p, r);
         } else {
-            rotate_sincos(dy, sy, cy);
-            rotate_sincos(dp, sp, cp);
-            rotate_sincos(dr, sr, cr);
+            rotate_sincos(dy, sy, cy, mk);
+            rotate_sincos(dp, sp, cp, mk);
+            rotate_sincos(dr, sr, cr, mk);
             if (y > kPi) y -= kTwoPi; else if (y < -kPi) y += kTwoPi;
             if (r > kPi) r -= kTwoPi; else if (r < -kPi) r += kTwoPi;
             yaw = y; pit = p; rol = r;

@@ -68,7 +68,7 @@ __device__ __forceinline__ void nav_init(Nav& s, const double* __restrict__ ini,
 //                 ODO == true : free_integration_odo.py:96-105 (RF 1) / :118-152 (RF 0).
 template <int RF, bool ODO>
 __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& accel, double odo, double dt,
-                                         int earth_rot, bool resync) {
+                                         int earth_rot, bool resync, const MathConsts& mk) {
     if (RF == 1) {
         const Vec3 v_prev = s.vel;
         if (!ODO) {
@@ -78,7 +78,7 @@ __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& a
             s.vb.y += (accel.y + gb.y * s.g) * dt - wxv.y * dt;
             s.vb.z += (accel.z + gb.z * s.g) * dt - wxv.z * dt;
         }
-        s.att.step(gyro, dt, resync);
+        s.att.step(gyro, dt, resync, mk);
         if (ODO) {
             const Vec3 f = s.att.fwd_in_nav();
             s.vel = Vec3{f.x * odo, f.y * odo, f.z * odo};
@@ -106,14 +106,14 @@ __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& a
             const Vec3 cor = cross3(Vec3{2.0 * w_ie.x + w_en.x, 2.0 * w_ie.y + w_en.y, 2.0 * w_ie.z + w_en.z}, v);
             v_new = Vec3{v.x + (an.x - cor.x) * dt, v.y + (an.y - cor.y) * dt, v.z + (an.z + g - cor.z) * dt};
         }
-        s.att.step(w_nb, dt, resync);
+        s.att.step(w_nb, dt, resync, mk);
         if (ODO) {
             const Vec3 f = s.att.fwd_in_nav();
             v_new = Vec3{f.x * odo, f.y * odo, f.z * odo};
         }
         const double dlat = v.x * irm * dt;
         if (resync || !(fabs(dlat) <= 0.25)) sincos(s.pos.x + dlat, &s.sl, &s.cl);
-        else rotate_sincos(dlat, s.sl, s.cl);
+        else rotate_sincos(dlat, s.sl, s.cl, mk);
         s.pos.x += dlat;
         s.pos.y += v.y * irn * icl * dt;
         s.pos.z += -v.z * dt;
@@ -213,6 +213,8 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
+    MathConsts mk;
+    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO))>();
 
     if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
     if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
@@ -236,17 +238,17 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
             const bool need_odo = ODO || a.out_odo;
             if (need_acc && need_gyr) {             // the common case: six streams in one phased batch
                 double z0[6], z1[6];
-                normal_pairs<6>(key, S_ACC_D_XY, jj, z0, z1);
+                normal_pairs<6>(key, S_ACC_D_XY, jj, z0, z1, mk);
                 const params_ptr kp = kernarg_params();
                 acc = sense3(as_uniform(a.ref_accel), j, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
                 gyr = sense3(as_uniform(a.ref_gyro), j, &kp->gyro, dg, Vec3{z0[3], z1[3], z0[4]}, Vec3{z1[4], z0[5], z1[5]});
             } else if (need_acc) {
                 double z0[3], z1[3];
-                normal_pairs<3>(key, S_ACC_D_XY, jj, z0, z1);
+                normal_pairs<3>(key, S_ACC_D_XY, jj, z0, z1, mk);
                 acc = sense3(as_uniform(a.ref_accel), j, &kernarg_params()->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             } else if (need_gyr) {
                 double z0[3], z1[3];
-                normal_pairs<3>(key, S_GYR_D_XY, jj, z0, z1);
+                normal_pairs<3>(key, S_GYR_D_XY, jj, z0, z1, mk);
                 gyr = sense3(as_uniform(a.ref_gyro), j, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             }
             if (need_acc && a.out_accel) store3(a.out_accel, plane, off, acc);
@@ -262,11 +264,11 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
         }
         const bool resync = ((j + 1) & (kTrigResync - 1)) == 0;
         if (FREE) {
-            nav_step<RF, false>(fi, gyr, acc, 0.0, dt, a.earth_rot, resync);
+            nav_step<RF, false>(fi, gyr, acc, 0.0, dt, a.earth_rot, resync, mk);
             if (a.out_traj[0]) store9(a.out_traj[0], plane, off + runs, fi);
         }
         if (ODO) {
-            nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot, resync);
+            nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot, resync, mk);
             if (a.out_traj[1]) store9(a.out_traj[1], plane, off + runs, od);
         }
     }

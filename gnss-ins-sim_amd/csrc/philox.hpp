@@ -70,6 +70,30 @@ __device__ __forceinline__ void normal_pair(const RngKey& key, uint32_t stream, 
 // polynomial's fp64 constants are live at a time; interleaving the transforms kept ~35 constants (70 SGPRs) live
 // and spilled SGPRs to VGPR lanes (~240 v_readlane/v_writelane per step in the first build).
 template <int N>
+__device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, uint32_t j, double (&z0)[N], double (&z1)[N],
+                                             const MathConsts& mk) {
+    double u1[N], u2[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const u32x4 w = philox4x32_10(j, first + k, key.r0, key.r1, key.k0, key.k1);
+        u1[k] = uniform53(w.x, w.y);
+        u2[k] = uniform53(w.z, w.w);
+    }
+    double r[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = -2.0 * log_u01(u1[k], mk);
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = sqrt(r[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double s, c;
+        sincospi_02(u2[k] + u2[k], s, c, mk);
+        z0[k] = r[k] * c;
+        z1[k] = r[k] * s;
+    }
+}
+
+template <int N>
 __device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, uint32_t j, double (&z0)[N], double (&z1)[N]) {
     double u1[N], u2[N];
 #pragma unroll
