@@ -292,7 +292,8 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
     const int tb = p.block_threads > 0 ? p.block_threads : kBlock;
     const int64_t waves = (p.runs + kWave - 1) / kWave;
     const int per_cu = waves <= 1024 ? 1 : 2;
-    const size_t lds = p.block_threads > 0 ? 0 : (per_cu == 1 ? kLdsPerCu / 2 + 1024 : kLdsPerCu / 4 + 1024);
+    // strictly more than 1/(k+1) of the LDS so that k+1 workgroups do not fit: 81 KB (k = 1), 54 KB (k = 2)
+    const size_t lds = p.block_threads > 0 ? 0 : kLdsPerCu / (per_cu + 1) + 1024;
     const dim3 grid((unsigned)((p.runs + tb - 1) / tb)), block(tb);
     if (p.given_sensors)
         hipLaunchKernelGGL((mc_kernel<RF, ALGOS, true>), grid, block, lds, stream, p);

@@ -344,9 +344,9 @@ template <int RF, int ALGOS>
 static hipError_t launch2_f32(const ginsim_mc_params& p, hipStream_t stream) {
     const int tb = 256;
     const int64_t waves = (p.runs + 63) / 64;
-    // fp32 needs fewer registers: allow up to 4 workgroups per CU (16 wavefronts) before serialising
-    const int per_cu = waves <= 1024 ? 1 : (waves <= 2048 ? 2 : 4);
-    const size_t lds = (160 * 1024) / (per_cu * 2) + 1024;
+    // exactly k workgroups per CU (k + 1 do not fit the LDS reservation): 148 VGPRs allow 3 wavefronts per SIMD
+    const int per_cu = waves <= 1024 ? 1 : (waves <= 2048 ? 2 : 3);
+    const size_t lds = (160 * 1024) / (per_cu + 1) + 1024;
     hipLaunchKernelGGL((f32::mc_kernel_f32<RF, ALGOS>), dim3((unsigned)((p.runs + tb - 1) / tb)), dim3(tb), lds, stream, p);
     return hipGetLastError();
 }

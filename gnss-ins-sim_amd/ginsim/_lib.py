@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libginsim.so')
+LIB_PATH = os.environ.get('GINSIM_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libginsim.so')   # GINSIM_LIB: A/B builds
 
 ALGO_FREE = 1
 ALGO_ODO = 2
