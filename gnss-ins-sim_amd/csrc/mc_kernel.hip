@@ -169,16 +169,18 @@ __device__ __forceinline__ uniform_ptr as_uniform(const double* p) {
 
 // Sensor sample j of one 3-axis sensor: truth + bias + drift + white  (pathgen.py:500, 562), and the
 // Gauss-Markov update d[j+1] = a d[j] + b N[j] (pathgen.py:589-590).
-__device__ __forceinline__ Vec3 sense3(uniform_ptr ref, int64_t j, model_ptr m, Vec3& drift, const Vec3& zd,
+__device__ __forceinline__ Vec3 load3(uniform_ptr ref, int64_t j) { return Vec3{ref[3 * j], ref[3 * j + 1], ref[3 * j + 2]}; }
+
+__device__ __forceinline__ Vec3 sense3(const Vec3& truth, model_ptr m, Vec3& drift, const Vec3& zd,
                                        const Vec3& zw) {
     const double bx = m->gm_b[0] * zd.x, by = m->gm_b[1] * zd.y, bz = m->gm_b[2] * zd.z;
     const double dx = m->white_drift[0] ? bx : drift.x;
     const double dy = m->white_drift[1] ? by : drift.y;
     const double dz = m->white_drift[2] ? bz : drift.z;
     Vec3 o;
-    o.x = ref[3 * j + 0] + m->bias[0] + dx + m->white[0] * zw.x;
-    o.y = ref[3 * j + 1] + m->bias[1] + dy + m->white[1] * zw.y;
-    o.z = ref[3 * j + 2] + m->bias[2] + dz + m->white[2] * zw.z;
+    o.x = truth.x + m->bias[0] + dx + m->white[0] * zw.x;
+    o.y = truth.y + m->bias[1] + dy + m->white[1] * zw.y;
+    o.z = truth.z + m->bias[2] + dz + m->white[2] * zw.z;
     drift.x = __builtin_fma(m->gm_a[0], drift.x, bx);
     drift.y = __builtin_fma(m->gm_a[1], drift.y, by);
     drift.z = __builtin_fma(m->gm_a[2], drift.z, bz);
@@ -233,6 +235,8 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
             // the last sample only exists as sensor output; skip it when nothing stores it
             if (last && !a.out_accel && !a.out_gyro && !a.out_odo) break;
             const uint32_t jj = (uint32_t)j;
+            // wave-uniform truth of this step: requested here, ~800 instructions before the sensor sums use it
+            const Vec3 cur_a = load3(as_uniform(a.ref_accel), j), cur_g = load3(as_uniform(a.ref_gyro), j);
             const bool need_acc = FREE || a.out_accel;
             const bool need_gyr = FREE || ODO || a.out_gyro;
             const bool need_odo = ODO || a.out_odo;
@@ -240,16 +244,16 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
                 double z0[6], z1[6];
                 normal_pairs<6>(key, S_ACC_D_XY, jj, z0, z1, mk);
                 const params_ptr kp = kernarg_params();
-                acc = sense3(as_uniform(a.ref_accel), j, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
-                gyr = sense3(as_uniform(a.ref_gyro), j, &kp->gyro, dg, Vec3{z0[3], z1[3], z0[4]}, Vec3{z1[4], z0[5], z1[5]});
+                acc = sense3(cur_a, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
+                gyr = sense3(cur_g, &kp->gyro, dg, Vec3{z0[3], z1[3], z0[4]}, Vec3{z1[4], z0[5], z1[5]});
             } else if (need_acc) {
                 double z0[3], z1[3];
                 normal_pairs<3>(key, S_ACC_D_XY, jj, z0, z1, mk);
-                acc = sense3(as_uniform(a.ref_accel), j, &kernarg_params()->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
+                acc = sense3(cur_a, &kernarg_params()->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             } else if (need_gyr) {
                 double z0[3], z1[3];
                 normal_pairs<3>(key, S_GYR_D_XY, jj, z0, z1, mk);
-                gyr = sense3(as_uniform(a.ref_gyro), j, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
+                gyr = sense3(cur_g, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             }
             if (need_acc && a.out_accel) store3(a.out_accel, plane, off, acc);
             if (need_gyr && a.out_gyro) store3(a.out_gyro, plane, off, gyr);
