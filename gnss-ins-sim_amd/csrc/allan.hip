@@ -30,6 +30,9 @@ struct AllanLevel {
     int32_t nchunks;
 };
 
+#ifndef GINSIM_ALLAN_UNROLL
+#define GINSIM_ALLAN_UNROLL 2
+#endif
 constexpr int kMaxChunksPerBlock = 8;
 constexpr int kPer = 10;                // entries owned by a thread: 254 threads cover 2536 >= kChunk + kHalo
 
@@ -47,7 +50,7 @@ __device__ __forceinline__ double pair_sum(const double* __restrict__ pre, int t
     const double* p1 = pre + pad(i0 + J);
     const double* p2 = pre + pad(i0 + 2 * J);
     double a = 0.0;
-#pragma unroll
+#pragma unroll GINSIM_ALLAN_UNROLL
     for (int it = 0; it * kAllanBlock < bins; ++it) {
         const int b = it * kAllanBlock + tid;
         const bool in_chunk = ((it + 1) * kAllanBlock <= bins) || (b < bins);
@@ -60,21 +63,54 @@ __device__ __forceinline__ double pair_sum(const double* __restrict__ pre, int t
     return a;
 }
 
+// factors whose bins do not line up with the 10-entry ownership of a thread: from the LDS prefix
 template <bool CHECK>
-__device__ __forceinline__ void all_pairs(const double* __restrict__ pre, int tid, int64_t c, const AllanLevel& lv, double (&acc)[9]) {
-    acc[0] += pair_sum<1, CHECK>(pre, tid, c * (kChunk / 1), lv.nb[0]);
-    acc[1] += pair_sum<2, CHECK>(pre, tid, c * (kChunk / 2), lv.nb[1]);
+__device__ __forceinline__ void lds_pairs(const double* __restrict__ pre, int tid, int64_t c, const AllanLevel& lv, double (&acc)[9]) {
     acc[2] += pair_sum<3, CHECK>(pre, tid, c * (kChunk / 3), lv.nb[2]);
     acc[3] += pair_sum<4, CHECK>(pre, tid, c * (kChunk / 4), lv.nb[3]);
-    acc[4] += pair_sum<5, CHECK>(pre, tid, c * (kChunk / 5), lv.nb[4]);
     acc[5] += pair_sum<6, CHECK>(pre, tid, c * (kChunk / 6), lv.nb[5]);
     acc[6] += pair_sum<7, CHECK>(pre, tid, c * (kChunk / 7), lv.nb[6]);
     acc[7] += pair_sum<8, CHECK>(pre, tid, c * (kChunk / 8), lv.nb[7]);
     acc[8] += pair_sum<9, CHECK>(pre, tid, c * (kChunk / 9), lv.nb[8]);
 }
 
+// factors 1, 2 and 5 divide 10: their bins are aligned with the thread's own entries v[0..9]; v[10..14] are the
+// first five entries of the next thread (the halo for the last owner).  60 % of all bin pairs, no LDS traffic.
+template <bool CHECK>
+__device__ __forceinline__ void reg_pairs(const double (&v)[15], int tid, int64_t c, const AllanLevel& lv, double (&acc)[9]) {
+    const int64_t g1 = c * kChunk + 10 * tid, g2 = c * (kChunk / 2) + 5 * tid, g5 = c * (kChunk / 5) + 2 * tid;
+    double a1 = 0.0, a2 = 0.0, a5 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        double d = v[q + 1] - v[q];
+        if (CHECK) d = (g1 + q + 1 < lv.nb[0]) ? d : 0.0;
+        a1 = __builtin_fma(d, d, a1);
+    }
+    double s2[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s2[k] = v[2 * k] + v[2 * k + 1];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        double d = s2[k + 1] - s2[k];
+        if (CHECK) d = (g2 + k + 1 < lv.nb[1]) ? d : 0.0;
+        a2 = __builtin_fma(d, d, a2);
+    }
+    double s5[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s5[k] = ((v[5 * k] + v[5 * k + 1]) + (v[5 * k + 2] + v[5 * k + 3])) + v[5 * k + 4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        double d = s5[k + 1] - s5[k];
+        if (CHECK) d = (g5 + k + 1 < lv.nb[4]) ? d : 0.0;
+        a5 = __builtin_fma(d, d, a5);
+    }
+    acc[0] += a1;
+    acc[1] += a2;
+    acc[4] += a5;
+}
+
 #ifndef GINSIM_ALLAN_WAVES
-#define GINSIM_ALLAN_WAVES 2
+#define GINSIM_ALLAN_WAVES 3
 #endif
 
 // coalesced read of one chunk into registers: lane l takes entries q*256 + l (512 contiguous bytes per wave-load)
@@ -118,9 +154,9 @@ allan_level_kernel(const double* __restrict__ in, double* __restrict__ out, doub
         }
         if (c + 1 < c_end) load_chunk(x, (c + 1) * kChunk, lv.n_in, tid, nxt, nxt_first);
         __syncthreads();
-        double v[kPer];
+        double v[15];       // own ten entries and the first five of the next owner
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) v[q] = (first + q < kChunk + kHalo) ? pre[first + q] : 0.0;
+        for (int q = 0; q < 15; ++q) v[q] = (first + q < kAllanBlock * kPer) ? pre[first + q] : 0.0;
         if (lv.n_out > 0 && first < kChunk) {   // level k+1: sums of 10 (aligned: 2520 = 252 * 10), unshifted
             const int64_t g = c * (kChunk / 10) + tid;
             if (g < lv.n_out) {
@@ -155,8 +191,12 @@ allan_level_kernel(const double* __restrict__ in, double* __restrict__ out, doub
         bool interior = true;
 #pragma unroll
         for (int j = 1; j <= 9; ++j) interior = interior && ((c + 1) * (kChunk / j) + 1 <= lv.nb[j - 1]);
-        if (interior) all_pairs<false>(pre, tid, c, lv, acc);
-        else all_pairs<true>(pre, tid, c, lv, acc);
+        if (first < kChunk) {                   // owners of chunk entries (threads 252..255 only hold the halo)
+            if (interior) reg_pairs<false>(v, tid, c, lv, acc);
+            else reg_pairs<true>(v, tid, c, lv, acc);
+        }
+        if (interior) lds_pairs<false>(pre, tid, c, lv, acc);
+        else lds_pairs<true>(pre, tid, c, lv, acc);
         __syncthreads();                        // pre[] and wave_tot[] are rewritten by the next chunk
     }
 #pragma unroll
