@@ -259,13 +259,13 @@ __device__ __forceinline__ void load_model(const ginsim_sensor_model& m, Model& 
     }
 }
 
-__device__ __forceinline__ V3 sense3(uniform_ptr ref, int64_t j, const Model& m, float (&drift)[3], const float* zd, const float* zw) {
+__device__ __forceinline__ V3 sense3(const double (&truth)[3], const Model& m, float (&drift)[3], const float* zd, const float* zw) {
     float o[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float bz = m.b[i] * zd[i];
         const float d = m.wd[i] ? bz : drift[i];
-        o[i] = (float)ref[3 * j + i] + m.bias[i] + d + m.w[i] * zw[i];
+        o[i] = (float)truth[i] + m.bias[i] + d + m.w[i] * zw[i];
         drift[i] = fmaf(m.a[i], drift[i], bz);
     }
     return V3{o[0], o[1], o[2]};
@@ -305,6 +305,9 @@ __global__ void __launch_bounds__(256) mc_kernel_f32(const ginsim_mc_params a) {
         const bool last = (j == n - 1);
         if (last && !o_acc && !o_gyr && !o_odo) break;
         const uint32_t jj = (uint32_t)j;
+        // wave-uniform truth of this step, requested before the noise is generated (scalar-load latency hidden)
+        const double ta[3] = {ref_a[3 * j], ref_a[3 * j + 1], ref_a[3 * j + 2]};
+        const double tg[3] = {ref_g[3 * j], ref_g[3 * j + 1], ref_g[3 * j + 2]};
         // 12 normals from streams 0..2 (4 each): accel drift xyz + white x | accel white yz + gyro drift xy | gyro drift z + white xyz
         float z0[4], z1[4], z2[4];
         normals4(key, S_ACC_D_XY, jj, z0);
@@ -312,8 +315,8 @@ __global__ void __launch_bounds__(256) mc_kernel_f32(const ginsim_mc_params a) {
         normals4(key, S_ACC_W_YZ, jj, z2);
         const float zda[3] = {z0[0], z0[1], z0[2]}, zwa[3] = {z0[3], z1[0], z1[1]};
         const float zdg[3] = {z1[2], z1[3], z2[0]}, zwg[3] = {z2[1], z2[2], z2[3]};
-        const V3 acc = sense3(ref_a, j, ma, da, zda, zwa);
-        const V3 gyr = sense3(ref_g, j, mg, dg, zdg, zwg);
+        const V3 acc = sense3(ta, ma, da, zda, zwa);
+        const V3 gyr = sense3(tg, mg, dg, zdg, zwg);
         if (o_acc) { o_acc[off] = acc.x; o_acc[plane + off] = acc.y; o_acc[2 * plane + off] = acc.z; }
         if (o_gyr) { o_gyr[off] = gyr.x; o_gyr[plane + off] = gyr.y; o_gyr[2 * plane + off] = gyr.z; }
         float odo = 0.f;

@@ -12,8 +12,21 @@ for p in (PKG, REPO):
         sys.path.insert(0, p)
 
 
+def _ensure_built():
+    """The shared libraries are git-ignored build products: a fresh checkout builds them on first use
+    (hipcc cross-compiles gfx950 without a GPU; ~1 min).  Existing up-to-date libraries are left alone."""
+    lib = os.path.join(PKG, 'lib', 'libginsim.so')
+    if not os.path.exists(lib):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('ginsim_build', os.path.join(PKG, 'build.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    _ensure_built()
 
 
 def load_golden(name):
