@@ -14,6 +14,7 @@
 //   FreeIntegration.run (odometer variant)     demo_algorithms/free_integration_odo.py:63-160
 //   array_error + end-point pick               gnss_ins_sim/sim/ins_data_manager.py:519-541, 737
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "ginsim.h"
 #include "ins_math.hpp"
 #include "philox.hpp"
@@ -281,6 +282,129 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
     if (trace) trace[3] = __builtin_amdgcn_s_memtime();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wave-specialised variant for SMALL batches (<= 1024 wavefronts of runs, i.e. one wavefront per SIMD with the kernel
+// above -- BASELINE config 2).  A lone wavefront cannot hide its own dependent-instruction and s_waitcnt latencies
+// (76 % VALU-active at 65 536 runs against ~100 % with two resident wavefronts at 262 144 runs), and there are no
+// more runs to give the SIMD a second wavefront.  So the work of one step is split across TWO wavefronts per 64 runs:
+//
+//   waves 4-7 of a 512-thread workgroup (producers): Philox + Box-Muller for streams 0..3 of tile i (8 of the 12
+//                                                    normals of a step) -> LDS ring  z[2][T][8][256]
+//   waves 0-3 (consumers)                          : read tile i-1 from LDS, generate streams 4..5 themselves (the
+//                                                    other 4 normals), sensor sums, mechanisation, all stores
+//
+// ~560 VALU instructions per step on either side; one __syncthreads() per tile of T = 4 steps; the instruction total
+// is unchanged, the SIMD just always has a second wavefront to issue from.  Results are bit-identical to mc_kernel
+// (same normals, same arithmetic order on the consumer side).  Measured at 65 536 runs: 2.70 -> 2.52 ms
+// materialised, 2.36 -> 2.09 ms stats-only; at 262 144 runs it is 3 % slower than the plain kernel, hence the policy.
+// (Moving the whole accelerometer to the producer -- 5 LDS slots instead of 8 -- measured no better.)
+constexpr int kSplitTile = 4;
+constexpr int kSplitRuns = 256;
+constexpr size_t kSplitLds = sizeof(double) * 2 * kSplitTile * 8 * kSplitRuns;      // 128 KiB -> one workgroup per CU
+
+template <int RF, int ALGOS>
+__global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a) {
+    extern __shared__ double zring[];
+    constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
+    constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
+    const int lane = threadIdx.x & (kSplitRuns - 1);
+    const bool producer = threadIdx.x >= kSplitRuns;
+    const int64_t r = (int64_t)blockIdx.x * kSplitRuns + lane;
+    const bool active = r < a.runs;
+    const int64_t n = a.n, runs = a.runs, plane = n * runs;
+    const bool keep_last = a.out_accel || a.out_gyro || a.out_odo;      // the last sample only exists as sensor output
+    const int64_t n_noise = keep_last ? n : n - 1;
+    const int64_t ntiles = (n_noise + kSplitTile - 1) / kSplitTile;
+    const uint64_t grun = a.run_offset + (uint64_t)r;
+    const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
+    MathConsts mk;
+    mk.init<true>();
+
+    if (producer) {
+        for (int64_t i = 0; i <= ntiles; ++i) {
+            if (i < ntiles && active) {
+                double* zb = zring + (i & 1) * (kSplitTile * 8 * kSplitRuns) + lane;
+#pragma unroll
+                for (int t = 0; t < kSplitTile; ++t) {
+                    const int64_t j = i * kSplitTile + t;
+                    if (j < n_noise) {
+                        double z0[4], z1[4];
+                        normal_pairs<4>(key, S_ACC_D_XY, (uint32_t)j, z0, z1, mk);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            zb[(t * 8 + k) * kSplitRuns] = z0[k];
+                            zb[(t * 8 + 4 + k) * kSplitRuns] = z1[k];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    const double dt = 1.0 / a.fs;
+    const uint64_t call = a.ini_first + (uint64_t)r;
+    const double* ini = a.ini + 10 * ((active && call < (uint64_t)a.n_ini) ? call : 0);
+    Nav fi, od;
+    if (FREE) nav_init<RF>(fi, ini, a.ini_has_g);
+    if (ODO) nav_init<RF>(od, ini, a.ini_has_g);
+    Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
+    if (active) {
+        if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
+        if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
+    }
+    for (int64_t i = 0; i <= ntiles; ++i) {
+        if (i >= 1 && active) {
+            const double* zb = zring + ((i - 1) & 1) * (kSplitTile * 8 * kSplitRuns) + lane;
+#pragma unroll 1
+            for (int t = 0; t < kSplitTile; ++t) {
+                const int64_t j = (i - 1) * kSplitTile + t;
+                if (j >= n_noise) break;
+                const int64_t off = j * runs + r;
+                const bool last = (j == n - 1);
+                const Vec3 cur_a = load3(as_uniform(a.ref_accel), j), cur_g = load3(as_uniform(a.ref_gyro), j);
+                double p0[4], p1[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    p0[k] = zb[(t * 8 + k) * kSplitRuns];
+                    p1[k] = zb[(t * 8 + 4 + k) * kSplitRuns];
+                }
+                double y0[2], y1[2];
+                normal_pairs<2>(key, S_GYR_DZ_WX, (uint32_t)j, y0, y1, mk);
+                const params_ptr kp = kernarg_params();
+                const Vec3 acc = sense3(cur_a, &kp->accel, da, Vec3{p0[0], p1[0], p0[1]}, Vec3{p1[1], p0[2], p1[2]});
+                const Vec3 gyr = sense3(cur_g, &kp->gyro, dg, Vec3{p0[3], p1[3], y0[0]}, Vec3{y1[0], y0[1], y1[1]});
+                if (a.out_accel) store3(a.out_accel, plane, off, acc);
+                if (a.out_gyro) store3(a.out_gyro, plane, off, gyr);
+                double odo = 0.0;
+                if (ODO || a.out_odo) {
+                    double z0, z1;
+                    normal_pair(key, S_ODO, (uint32_t)j, z0, z1);
+                    const params_ptr kq = kernarg_params();
+                    odo = kq->odo_scale * as_uniform(a.ref_odo)[j] + kq->odo_stdv * z0;
+                    if (a.out_odo) a.out_odo[off] = odo;
+                }
+                if (last) break;
+                const bool resync = ((j + 1) & (kTrigResync - 1)) == 0;
+                if (FREE) {
+                    nav_step<RF, false>(fi, gyr, acc, 0.0, dt, a.earth_rot, resync, mk);
+                    if (a.out_traj[0]) store9(a.out_traj[0], plane, off + runs, fi);
+                }
+                if (ODO) {
+                    nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot, resync, mk);
+                    if (a.out_traj[1]) store9(a.out_traj[1], plane, off + runs, od);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        if (FREE && a.out_end[0]) store_end(a.out_end[0], runs, r, fi);
+        if (ODO && a.out_end[1]) store_end(a.out_end[1], runs, r, od);
+    }
+}
+
 // Launch geometry.  The kernel is VALU-bound and every wavefront of a launch does the same amount of work,
 // so the only thing that matters is that wavefronts are spread evenly over the 1024 SIMDs.  Measured on
 // MI355X: with 64-thread workgroups the dispatcher, depending on what ran before, doubles up ~6 % of the
@@ -291,10 +415,29 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
 constexpr int kBlock = 256;
 constexpr size_t kLdsPerCu = 160 * 1024;
 
+static int split_policy() {        // GINSIM_SPLIT=0 / 1 forces the plain / wave-specialised kernel (A/B measurements)
+    static const int v = [] { const char* e = getenv("GINSIM_SPLIT"); return e ? atoi(e) : -1; }();
+    return v;
+}
+
 template <int RF, int ALGOS>
 static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
     const int tb = p.block_threads > 0 ? p.block_threads : kBlock;
     const int64_t waves = (p.runs + kWave - 1) / kWave;
+    if ((ALGOS & GINSIM_ALGO_FREE) && !p.given_sensors && p.block_threads == 0 && !p.wave_trace && p.n >= 2) {
+        const int pol = split_policy();
+        if (pol == 1 || (pol < 0 && waves <= 1024)) {
+            static bool once = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
+                return true;
+            }();
+            (void)once;
+            hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS>), dim3((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns)), dim3(512),
+                               kSplitLds, stream, p);
+            return hipGetLastError();
+        }
+    }
     const int per_cu = waves <= 1024 ? 1 : 2;
     // strictly more than 1/(k+1) of the LDS so that k+1 workgroups do not fit: 81 KB (k = 1), 54 KB (k = 2)
     const size_t lds = p.block_threads > 0 ? 0 : kLdsPerCu / (per_cu + 1) + 1024;
