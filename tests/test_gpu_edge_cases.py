@@ -161,3 +161,32 @@ def test_argument_validation(ctx, turn):
         ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4).run().trajectories('free', [0])   # not kept
     with pytest.raises(ValueError, match='out of range'):
         ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4, keep_traj=True).run().trajectories('free', [4])
+
+
+@pytest.mark.parametrize('rf,algos,keep', [(1, ('free',), True), (0, ('free', 'odo'), False), (1, ('free', 'odo'), True)])
+def test_plain_and_wave_specialised_kernels_agree_bitwise(ctx, turn, rf, algos, keep):
+    """Batches of <= 1024 wavefronts use the producer/consumer kernel, larger ones the one-wave-per-run-group kernel.
+    Same runs through both must give identical bits (66 560 runs = 1040 wavefronts vs two halves of 520)."""
+    import ginsim
+    from ginsim import workloads
+    ini, truth = turn[rf]
+    t = {k: (v[:60] if hasattr(v, 'shape') and v.shape and v.shape[0] == 1000 else v) for k, v in truth.items()}
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    kw = dict(algos=algos, odo_err={'scale': 0.999, 'stdv': 0.1}, seed=12, keep_sensors=keep, keep_traj=keep)
+    R = 66560
+    big = ginsim.MonteCarloJob(ctx, 100.0, rf, t, acc, gyr, ini, runs=R, **kw).run()
+    halves = [ginsim.MonteCarloJob(ctx, 100.0, rf, t, acc, gyr, ini, runs=R // 2, run_offset=h * (R // 2), ini_first=h * (R // 2), **kw).run()
+              for h in range(2)]
+    for a in algos:
+        e = big.end_errors(a)
+        np.testing.assert_array_equal(np.vstack([h.end_errors(a) for h in halves]), e)
+        if keep:
+            pick = [0, 33279, 33280, R - 1]
+            for x, y in zip(big.trajectories(a, pick), [np.concatenate([halves[0].trajectories(a, [0, 33279])[k],
+                                                                        halves[1].trajectories(a, [0, 33279])[k]]) for k in range(3)]):
+                np.testing.assert_array_equal(x, y)
+    if keep:
+        np.testing.assert_array_equal(big.sensors('gyro', [5, 40000]),
+                                      np.concatenate([halves[0].sensors('gyro', [5]), halves[1].sensors('gyro', [40000 - 33280])]))
+    for j in [big] + halves:
+        j.release()
