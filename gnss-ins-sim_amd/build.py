@@ -24,8 +24,10 @@ COMMON = ['-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(REPO, 'include'), '-
 SOURCES = [
     # machine-LICM hoists ~35 fp64 polynomial constants (SGPR pairs) out of the time loop and then spills them
     # to VGPR lanes; without it they are re-materialised with s_mov next to their use (SGPR spills 192 -> 71)
-    ('mc_kernel.hip', ['--offload-arch=' + ARCH, '-mllvm', '-disable-machine-licm']),
-    ('mc_kernel_f32.hip', ['--offload-arch=' + ARCH, '-mllvm', '-disable-machine-licm']),
+    # -ffp-contract=on: fused multiply-adds only where one source expression spells a*b+c, decided in the front
+    # end, so the plain and the wave-specialised kernels (same inlined functions) give identical bits
+    ('mc_kernel.hip', ['--offload-arch=' + ARCH, '-mllvm', '-disable-machine-licm', '-ffp-contract=on']),
+    ('mc_kernel_f32.hip', ['--offload-arch=' + ARCH, '-mllvm', '-disable-machine-licm', '-ffp-contract=on']),
     ('stats.hip', ['--offload-arch=' + ARCH]),
     ('allan.hip', ['--offload-arch=' + ARCH]),
     ('ginsim_api.hip', ['--offload-arch=' + ARCH]),

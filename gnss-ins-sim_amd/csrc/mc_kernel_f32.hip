@@ -14,6 +14,7 @@
 // Restates the same reference functions as mc_kernel.hip (pathgen.py:441-594, free_integration.py:63-174,
 // free_integration_odo.py:63-160, ins_data_manager.py:537-541).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "ginsim.h"
 #include "ins_math.hpp"
 #include "philox.hpp"
@@ -341,12 +342,151 @@ __global__ void __launch_bounds__(256) mc_kernel_f32(const ginsim_mc_params a) {
     if (ODO && a.out_end[1]) store_end(a.out_end[1], runs, r, od);
 }
 
+// Wave-specialised variant for batches of <= 1024 wavefronts (see mc_kernel_split in mc_kernel.hip for the rationale):
+// waves 4-7 produce the normals of streams 0 and 1 (8 of the 12 per step) into an LDS ring, waves 0-3 consume them,
+// generate stream 2 themselves and do sensors, mechanisation and stores.  Bit-identical to mc_kernel_f32.
+constexpr int kSplitTileF = 8;
+constexpr int kSplitRunsF = 256;
+constexpr size_t kSplitLdsF = sizeof(float) * 2 * kSplitTileF * 8 * kSplitRunsF;       // 128 KiB
+
+template <int RF, int ALGOS>
+__global__ void __launch_bounds__(512) mc_kernel_f32_split(const ginsim_mc_params a) {
+    extern __shared__ float zringf[];
+    constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
+    constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
+    const int lane = threadIdx.x & (kSplitRunsF - 1);
+    const bool producer = threadIdx.x >= kSplitRunsF;
+    const int64_t r = (int64_t)blockIdx.x * kSplitRunsF + lane;
+    const bool active = r < a.runs;
+    const int64_t n = a.n, runs = a.runs, plane = n * runs;
+    float* o_acc = reinterpret_cast<float*>(a.out_accel);
+    float* o_gyr = reinterpret_cast<float*>(a.out_gyro);
+    float* o_odo = reinterpret_cast<float*>(a.out_odo);
+    float* o_fi = reinterpret_cast<float*>(a.out_traj[0]);
+    float* o_od = reinterpret_cast<float*>(a.out_traj[1]);
+    const bool keep_last = o_acc || o_gyr || o_odo;
+    const int64_t n_noise = keep_last ? n : n - 1;
+    const int64_t ntiles = (n_noise + kSplitTileF - 1) / kSplitTileF;
+    const uint64_t grun = a.run_offset + (uint64_t)r;
+    const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
+
+    if (producer) {
+        for (int64_t i = 0; i <= ntiles; ++i) {
+            if (i < ntiles && active) {
+                float* zb = zringf + (i & 1) * (kSplitTileF * 8 * kSplitRunsF) + lane;
+#pragma unroll
+                for (int t = 0; t < kSplitTileF; ++t) {
+                    const int64_t j = i * kSplitTileF + t;
+                    if (j < n_noise) {
+                        float z0[4], z1[4];
+                        normals4(key, S_ACC_D_XY, (uint32_t)j, z0);
+                        normals4(key, S_ACC_DZ_WX, (uint32_t)j, z1);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            zb[(t * 8 + k) * kSplitRunsF] = z0[k];
+                            zb[(t * 8 + 4 + k) * kSplitRunsF] = z1[k];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    const float dt = (float)(1.0 / a.fs);
+    const uint64_t call = a.ini_first + (uint64_t)r;
+    const double* ini = a.ini + 10 * ((active && call < (uint64_t)a.n_ini) ? call : 0);
+    Nav fi, od;
+    if (FREE) nav_init<RF>(fi, ini, a.ini_has_g);
+    if (ODO) nav_init<RF>(od, ini, a.ini_has_g);
+    Model ma, mg;
+    load_model(a.accel, ma);
+    load_model(a.gyro, mg);
+    const float odo_scale = (float)a.odo_scale, odo_stdv = (float)a.odo_stdv;
+    float da[3] = {0.f, 0.f, 0.f}, dg[3] = {0.f, 0.f, 0.f};
+    const uniform_ptr ref_a = (uniform_ptr)(uintptr_t)a.ref_accel, ref_g = (uniform_ptr)(uintptr_t)a.ref_gyro,
+                      ref_o = (uniform_ptr)(uintptr_t)a.ref_odo;
+    if (active) {
+        if (FREE && o_fi) store9(o_fi, plane, r, fi);
+        if (ODO && o_od) store9(o_od, plane, r, od);
+    }
+    for (int64_t i = 0; i <= ntiles; ++i) {
+        if (i >= 1 && active) {
+            const float* zb = zringf + ((i - 1) & 1) * (kSplitTileF * 8 * kSplitRunsF) + lane;
+#pragma unroll 1
+            for (int t = 0; t < kSplitTileF; ++t) {
+                const int64_t j = (i - 1) * kSplitTileF + t;
+                if (j >= n_noise) break;
+                const int64_t off = j * runs + r;
+                const bool last = (j == n - 1);
+                const double ta[3] = {ref_a[3 * j], ref_a[3 * j + 1], ref_a[3 * j + 2]};
+                const double tg[3] = {ref_g[3 * j], ref_g[3 * j + 1], ref_g[3 * j + 2]};
+                float z0[4], z1[4], z2[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    z0[k] = zb[(t * 8 + k) * kSplitRunsF];
+                    z1[k] = zb[(t * 8 + 4 + k) * kSplitRunsF];
+                }
+                normals4(key, S_ACC_W_YZ, (uint32_t)j, z2);
+                const float zda[3] = {z0[0], z0[1], z0[2]}, zwa[3] = {z0[3], z1[0], z1[1]};
+                const float zdg[3] = {z1[2], z1[3], z2[0]}, zwg[3] = {z2[1], z2[2], z2[3]};
+                const V3 acc = sense3(ta, ma, da, zda, zwa);
+                const V3 gyr = sense3(tg, mg, dg, zdg, zwg);
+                if (o_acc) { o_acc[off] = acc.x; o_acc[plane + off] = acc.y; o_acc[2 * plane + off] = acc.z; }
+                if (o_gyr) { o_gyr[off] = gyr.x; o_gyr[plane + off] = gyr.y; o_gyr[2 * plane + off] = gyr.z; }
+                float odo = 0.f;
+                if (ODO || o_odo) {
+                    float z3[4];
+                    normals4(key, S_ODO, (uint32_t)j, z3);
+                    odo = odo_scale * (float)ref_o[j] + odo_stdv * z3[0];
+                    if (o_odo) o_odo[off] = odo;
+                }
+                if (last) break;
+                const bool resync = ((j + 1) & (kTrigResync - 1)) == 0;
+                if (FREE) {
+                    nav_step<RF, false>(fi, gyr, acc, 0.f, dt, a.earth_rot, resync);
+                    if (o_fi) store9(o_fi, plane, off + runs, fi);
+                }
+                if (ODO) {
+                    nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot, resync);
+                    if (o_od) store9(o_od, plane, off + runs, od);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        if (FREE && a.out_end[0]) store_end(a.out_end[0], runs, r, fi);
+        if (ODO && a.out_end[1]) store_end(a.out_end[1], runs, r, od);
+    }
+}
+
 }  // namespace f32
+
+static int split_policy_f32() {
+    static const int v = [] { const char* e = getenv("GINSIM_SPLIT"); return e ? atoi(e) : -1; }();
+    return v;
+}
 
 template <int RF, int ALGOS>
 static hipError_t launch2_f32(const ginsim_mc_params& p, hipStream_t stream) {
     const int tb = 256;
     const int64_t waves = (p.runs + 63) / 64;
+    if ((ALGOS & GINSIM_ALGO_FREE) && p.n >= 2) {
+        const int pol = split_policy_f32();
+        if (pol == 1 || (pol < 0 && waves <= 1024)) {
+            static bool once = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&f32::mc_kernel_f32_split<RF, ALGOS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)f32::kSplitLdsF);
+                return true;
+            }();
+            (void)once;
+            hipLaunchKernelGGL((f32::mc_kernel_f32_split<RF, ALGOS>), dim3((unsigned)((p.runs + 255) / 256)), dim3(512),
+                               f32::kSplitLdsF, stream, p);
+            return hipGetLastError();
+        }
+    }
     // exactly k workgroups per CU (k + 1 do not fit the LDS reservation): 148 VGPRs allow 3 wavefronts per SIMD
     const int per_cu = waves <= 1024 ? 1 : (waves <= 2048 ? 2 : 3);
     const size_t lds = (160 * 1024) / (per_cu + 1) + 1024;

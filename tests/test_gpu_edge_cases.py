@@ -163,8 +163,10 @@ def test_argument_validation(ctx, turn):
         ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4, keep_traj=True).run().trajectories('free', [4])
 
 
-@pytest.mark.parametrize('rf,algos,keep', [(1, ('free',), True), (0, ('free', 'odo'), False), (1, ('free', 'odo'), True)])
-def test_plain_and_wave_specialised_kernels_agree_bitwise(ctx, turn, rf, algos, keep):
+@pytest.mark.parametrize('rf,algos,keep,precision', [(1, ('free',), True, 'f64'), (0, ('free', 'odo'), False, 'f64'),
+                                                     (1, ('free', 'odo'), True, 'f64'), (1, ('free',), True, 'f32'),
+                                                     (0, ('free', 'odo'), True, 'f32')])
+def test_plain_and_wave_specialised_kernels_agree_bitwise(ctx, turn, rf, algos, keep, precision):
     """Batches of <= 1024 wavefronts use the producer/consumer kernel, larger ones the one-wave-per-run-group kernel.
     Same runs through both must give identical bits (66 560 runs = 1040 wavefronts vs two halves of 520)."""
     import ginsim
@@ -172,7 +174,8 @@ def test_plain_and_wave_specialised_kernels_agree_bitwise(ctx, turn, rf, algos, 
     ini, truth = turn[rf]
     t = {k: (v[:60] if hasattr(v, 'shape') and v.shape and v.shape[0] == 1000 else v) for k, v in truth.items()}
     acc, gyr = workloads.imu_grade('mid-accuracy')
-    kw = dict(algos=algos, odo_err={'scale': 0.999, 'stdv': 0.1}, seed=12, keep_sensors=keep, keep_traj=keep)
+    kw = dict(algos=algos, odo_err={'scale': 0.999, 'stdv': 0.1}, seed=12, keep_sensors=keep, keep_traj=keep,
+              precision=precision)
     R = 66560
     big = ginsim.MonteCarloJob(ctx, 100.0, rf, t, acc, gyr, ini, runs=R, **kw).run()
     halves = [ginsim.MonteCarloJob(ctx, 100.0, rf, t, acc, gyr, ini, runs=R // 2, run_offset=h * (R // 2), ini_first=h * (R // 2), **kw).run()
