@@ -171,7 +171,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic('mc_kernel_rf%d_free_%s' % (rf, 'keep' if keep else 'stats')) if args.precision == 'f64' else None,
-                         'kernel': ('ginsim::mc_kernel<%d,1,false>' if args.precision == 'f64' else 'ginsim::f32::mc_kernel_f32<%d,1>') % rf, 'kernel_ms_avg': kern_avg_ms,
+                         'kernel': job.kernel_name(), 'kernel_ms_avg': kern_avg_ms,
                          'algorithmic_bytes_per_launch': alg_bytes,
                          'note': 'fp64 transcendental/VALU-bound, not HBM-bound: see DESIGN.md (roofline)'},
             'result': {'att_std_deg': (merged.std[:3] * r2d).tolist(), 'vel_std_mps': merged.std[6:9].tolist(),

@@ -64,6 +64,26 @@ GINSIM_FM double rcp_nr(double x) {
     return __builtin_fma(y, e, y);
 }
 
+// 1/x to ~2^-46 (one Newton step on the 2^-23 hardware estimate): enough where a residual correction of the quotient
+// follows (q = a y; q += (a - x q) y is then ~1 ulp).
+GINSIM_FM double rcp_n1(double x) {
+    const double y = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+}
+
+// sqrt(x) for finite x >= 0 well inside the normal range (here x = -2 ln u <= 75.5); x below 2^-200 (only u = 1) is
+// lifted to 2^-200, i.e. returns 2^-100 instead of 0.  v_rsq_f64 estimate, one Goldschmidt step, one residual
+// correction: <= 1 ulp.  The compiler's sqrt() adds range scaling, a second correction and an inf/0 select (17 VALU).
+GINSIM_FM double sqrt_pos(double x) {
+    x = __builtin_fmax(x, 0x1.0p-200);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    return __builtin_fma(__builtin_fma(-g, g, x), h, g);
+}
+
 // Natural log for 0 < u <= 1 (normal, not denormal: u >= 2^-54 by construction of uniform53).
 //   u = m * 2^e, m in [sqrt(1/2), sqrt(2));  ln u = e ln2 + 2 atanh(s),  s = (m-1)/(m+1),  |s| <= 0.1716
 // The exponent/mantissa split is done on the high word with integer arithmetic only (no compare/select):
@@ -74,7 +94,7 @@ GINSIM_FM double log_u01(double u) {
     hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
     const double m = __hiloint2double((int)hx, __double2loint(u));
     const double num = m - 1.0, den = m + 1.0;
-    const double y = rcp_nr(den);
+    const double y = rcp_n1(den);
     double s = num * y;
     s = __builtin_fma(__builtin_fma(-den, s, num), y, s);   // one correction step: s = num/den to ~1 ulp
     const double t = s * s;
@@ -119,8 +139,8 @@ GINSIM_FM void sincos_q(double th, double& s, double& c) {
 }
 
 // sin(pi x), cos(pi x) for 0 <= x <= 2.  2x = k + r, k integer, |r| <= 1/2 (exact), angle = k pi/2 + r pi/2.
-GINSIM_FM void sincospi_02(double x, double& s, double& c) {
-    const double x2 = x + x;
+// The argument is x2 = 2x, the angle in quarter turns (what uniform53q delivers).
+GINSIM_FM void sincos_quarters(double x2, double& s, double& c) {
     const double kd = __builtin_rint(x2);
     const double r = x2 - kd;                                   // exact
     const int k = (int)kd;
@@ -165,7 +185,7 @@ GINSIM_FM double log_u01(double u, const MathConsts& k) {
     hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
     const double m = __hiloint2double((int)hx, __double2loint(u));
     const double num = m - 1.0, den = m + 1.0;
-    const double y = rcp_nr(den);
+    const double y = rcp_n1(den);
     double s = num * y;
     s = __builtin_fma(__builtin_fma(-den, s, num), y, s);
     const double t = s * s;
@@ -178,8 +198,7 @@ GINSIM_FM double log_u01(double u, const MathConsts& k) {
     return __builtin_fma(ed, k.ln2_hi, __builtin_fma(ed, k.ln2_lo, lnm));
 }
 
-GINSIM_FM void sincospi_02(double x, double& s, double& c, const MathConsts& k) {
-    const double x2 = x + x;
+GINSIM_FM void sincos_quarters(double x2, double& s, double& c, const MathConsts& k) {
     const double kd = __builtin_rint(x2);
     const double r = x2 - kd;
     const int q = (int)kd;

@@ -26,6 +26,8 @@ void set_error(const char* fmt, ...) {
 
 hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream);
 hipError_t launch_mc_f32(const ginsim_mc_params& p, hipStream_t stream);
+int mc_variant(const ginsim_mc_params& p);
+int mc_variant_f32(const ginsim_mc_params& p);
 hipError_t launch_gather_runs_f32(const float* series, int C, int64_t n, int64_t runs, const int64_t* ids, int nsel,
                                   double* out, hipStream_t s);
 hipError_t launch_aux(const ginsim_aux_params& p, hipStream_t s);
@@ -254,6 +256,12 @@ static int check_sensor(const ginsim_sensor_model& m, const char* what) {
         const double v[4] = {m.bias[i], m.gm_a[i], m.gm_b[i], m.white[i]};
         for (double x : v) REQUIRE(x == x && x - x == 0.0, "mc_run: %s model has a non-finite coefficient", what);
     }
+    return GINSIM_OK;
+}
+
+int ginsim_mc_variant(const ginsim_mc_params* p, int32_t* variant) {
+    REQUIRE(p && variant, "mc_variant: NULL argument");
+    *variant = p->precision == 1 ? mc_variant_f32(*p) : mc_variant(*p);
     return GINSIM_OK;
 }
 

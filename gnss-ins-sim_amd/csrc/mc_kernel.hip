@@ -298,42 +298,53 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
 // (same normals, same arithmetic order on the consumer side).  Measured at 65 536 runs: 2.70 -> 2.52 ms
 // materialised, 2.36 -> 2.09 ms stats-only; at 262 144 runs it is 3 % slower than the plain kernel, hence the policy.
 // (Moving the whole accelerometer to the producer -- 5 LDS slots instead of 8 -- measured no better.)
-constexpr int kSplitTile = 4;
 constexpr int kSplitRuns = 256;
-constexpr size_t kSplitLds = sizeof(double) * 2 * kSplitTile * 8 * kSplitRuns;      // 128 KiB -> one workgroup per CU
+// NP producer groups per workgroup of 256*(NP+1) threads.  NP = 1: streams 0..3 produced, 4..5 by the consumer, tile
+// of 4 steps (128 KiB ring).  NP = 2: streams 0..2 and 3..5 produced by two groups, the consumer generates nothing,
+// tile of 3 steps (144 KiB ring).  Either way the ring allows exactly one workgroup per CU.  Only NP = 1 is
+// instantiated: NP = 2 (three wavefronts per SIMD) measured the same 2.40 ms at 65 536 runs -- with two wavefronts the
+// SIMD is already issue-bound -- and 10 % slower for ref_frame 0.
+constexpr int split_pairs(int np) { return np == 1 ? 4 : 3; }          // Philox blocks (normal pairs) per producer and step
+constexpr int split_tile(int np) { return np == 1 ? 4 : 3; }
+constexpr int split_slots(int np) { return 2 * np * split_pairs(np); }
+constexpr size_t split_lds(int np) { return sizeof(double) * 2 * split_tile(np) * split_slots(np) * kSplitRuns; }
 
-template <int RF, int ALGOS>
-__global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a) {
+template <int RF, int ALGOS, int NP>
+__global__ void __launch_bounds__(256 * (NP + 1)) mc_kernel_split(const ginsim_mc_params a) {
     extern __shared__ double zring[];
     constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
     constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
+    constexpr int PP = split_pairs(NP), TILE = split_tile(NP), SLOTS = split_slots(NP);
+    constexpr int OWN = 6 - NP * PP;                  // pairs left to the consumer
+    constexpr int kStage = TILE * SLOTS * kSplitRuns;
     const int lane = threadIdx.x & (kSplitRuns - 1);
-    const bool producer = threadIdx.x >= kSplitRuns;
+    const int role = threadIdx.x / kSplitRuns;        // 0 consumer, 1..NP producers
     const int64_t r = (int64_t)blockIdx.x * kSplitRuns + lane;
     const bool active = r < a.runs;
     const int64_t n = a.n, runs = a.runs, plane = n * runs;
     const bool keep_last = a.out_accel || a.out_gyro || a.out_odo;      // the last sample only exists as sensor output
     const int64_t n_noise = keep_last ? n : n - 1;
-    const int64_t ntiles = (n_noise + kSplitTile - 1) / kSplitTile;
+    const int64_t ntiles = (n_noise + TILE - 1) / TILE;
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     MathConsts mk;
     mk.init<true>();
 
-    if (producer) {
+    if (role != 0) {
+        const uint32_t first = (uint32_t)((role - 1) * PP);
         for (int64_t i = 0; i <= ntiles; ++i) {
             if (i < ntiles && active) {
-                double* zb = zring + (i & 1) * (kSplitTile * 8 * kSplitRuns) + lane;
+                double* zb = zring + (i & 1) * kStage + 2 * first * kSplitRuns + lane;
 #pragma unroll
-                for (int t = 0; t < kSplitTile; ++t) {
-                    const int64_t j = i * kSplitTile + t;
+                for (int t = 0; t < TILE; ++t) {
+                    const int64_t j = i * TILE + t;
                     if (j < n_noise) {
-                        double z0[4], z1[4];
-                        normal_pairs<4>(key, S_ACC_D_XY, (uint32_t)j, z0, z1, mk);
+                        double z0[PP], z1[PP];
+                        normal_pairs<PP>(key, first, (uint32_t)j, z0, z1, mk);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            zb[(t * 8 + k) * kSplitRuns] = z0[k];
-                            zb[(t * 8 + 4 + k) * kSplitRuns] = z1[k];
+                        for (int k = 0; k < PP; ++k) {
+                            zb[(t * SLOTS + 2 * k) * kSplitRuns] = z0[k];
+                            zb[(t * SLOTS + 2 * k + 1) * kSplitRuns] = z1[k];
                         }
                     }
                 }
@@ -356,25 +367,29 @@ __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a)
     }
     for (int64_t i = 0; i <= ntiles; ++i) {
         if (i >= 1 && active) {
-            const double* zb = zring + ((i - 1) & 1) * (kSplitTile * 8 * kSplitRuns) + lane;
+            const double* zb = zring + ((i - 1) & 1) * kStage + lane;
 #pragma unroll 1
-            for (int t = 0; t < kSplitTile; ++t) {
-                const int64_t j = (i - 1) * kSplitTile + t;
+            for (int t = 0; t < TILE; ++t) {
+                const int64_t j = (i - 1) * TILE + t;
                 if (j >= n_noise) break;
                 const int64_t off = j * runs + r;
                 const bool last = (j == n - 1);
                 const Vec3 cur_a = load3(as_uniform(a.ref_accel), j), cur_g = load3(as_uniform(a.ref_gyro), j);
-                double p0[4], p1[4];
+                double p0[6], p1[6];                  // z0 / z1 of streams 0..5
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    p0[k] = zb[(t * 8 + k) * kSplitRuns];
-                    p1[k] = zb[(t * 8 + 4 + k) * kSplitRuns];
+                for (int k = 0; k < NP * PP; ++k) {
+                    p0[k] = zb[(t * SLOTS + 2 * k) * kSplitRuns];
+                    p1[k] = zb[(t * SLOTS + 2 * k + 1) * kSplitRuns];
                 }
-                double y0[2], y1[2];
-                normal_pairs<2>(key, S_GYR_DZ_WX, (uint32_t)j, y0, y1, mk);
+                if constexpr (OWN > 0) {
+                    double y0[OWN], y1[OWN];
+                    normal_pairs<OWN>(key, (uint32_t)(NP * PP), (uint32_t)j, y0, y1, mk);
+#pragma unroll
+                    for (int k = 0; k < OWN; ++k) { p0[NP * PP + k] = y0[k]; p1[NP * PP + k] = y1[k]; }
+                }
                 const params_ptr kp = kernarg_params();
                 const Vec3 acc = sense3(cur_a, &kp->accel, da, Vec3{p0[0], p1[0], p0[1]}, Vec3{p1[1], p0[2], p1[2]});
-                const Vec3 gyr = sense3(cur_g, &kp->gyro, dg, Vec3{p0[3], p1[3], y0[0]}, Vec3{y1[0], y0[1], y1[1]});
+                const Vec3 gyr = sense3(cur_g, &kp->gyro, dg, Vec3{p0[3], p1[3], p0[4]}, Vec3{p1[4], p0[5], p1[5]});
                 if (a.out_accel) store3(a.out_accel, plane, off, acc);
                 if (a.out_gyro) store3(a.out_gyro, plane, off, gyr);
                 double odo = 0.0;
@@ -420,21 +435,29 @@ static int split_policy() {        // GINSIM_SPLIT=0 / 1 forces the plain / wave
     return v;
 }
 
+// 1 = wave-specialised kernel (mc_kernel_split), 0 = one wavefront does everything for its 64 runs (mc_kernel)
+int mc_variant(const ginsim_mc_params& p) {
+    if (!(p.algo_mask & GINSIM_ALGO_FREE) || p.given_sensors || p.block_threads != 0 || p.wave_trace || p.n < 2) return 0;
+    const int pol = split_policy();
+    if (pol >= 0) return pol != 0;
+    return (p.runs + kWave - 1) / kWave <= 1024 ? 1 : 0;
+}
+
 template <int RF, int ALGOS>
 static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
     const int tb = p.block_threads > 0 ? p.block_threads : kBlock;
     const int64_t waves = (p.runs + kWave - 1) / kWave;
-    if ((ALGOS & GINSIM_ALGO_FREE) && !p.given_sensors && p.block_threads == 0 && !p.wave_trace && p.n >= 2) {
-        const int pol = split_policy();
-        if (pol == 1 || (pol < 0 && waves <= 1024)) {
+    if constexpr ((ALGOS & GINSIM_ALGO_FREE) != 0) {
+        const int v = mc_variant(p);
+        const dim3 sgrid((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns));
+        if (v == 1) {
             static bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds(1));
                 return true;
             }();
             (void)once;
-            hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS>), dim3((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns)), dim3(512),
-                               kSplitLds, stream, p);
+            hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, 1>), sgrid, dim3(512), split_lds(1), stream, p);
             return hipGetLastError();
         }
     }

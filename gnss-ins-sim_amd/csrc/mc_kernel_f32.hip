@@ -469,13 +469,18 @@ static int split_policy_f32() {
     return v;
 }
 
+int mc_variant_f32(const ginsim_mc_params& p) {
+    if (!(p.algo_mask & GINSIM_ALGO_FREE) || p.n < 2) return 0;
+    const int pol = split_policy_f32();
+    return pol == 1 || (pol < 0 && (p.runs + 63) / 64 <= 1024);
+}
+
 template <int RF, int ALGOS>
 static hipError_t launch2_f32(const ginsim_mc_params& p, hipStream_t stream) {
     const int tb = 256;
     const int64_t waves = (p.runs + 63) / 64;
-    if ((ALGOS & GINSIM_ALGO_FREE) && p.n >= 2) {
-        const int pol = split_policy_f32();
-        if (pol == 1 || (pol < 0 && waves <= 1024)) {
+    if constexpr ((ALGOS & GINSIM_ALGO_FREE) != 0) {
+        if (mc_variant_f32(p)) {
             static bool once = [] {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&f32::mc_kernel_f32_split<RF, ALGOS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)f32::kSplitLdsF);

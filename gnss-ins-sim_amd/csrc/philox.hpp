@@ -21,14 +21,17 @@ enum : uint32_t {
 
 struct u32x4 { uint32_t x, y, z, w; };
 
-__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                                        uint32_t k0, uint32_t k1) {
+// a ^ b ^ c in one v_bitop3_b32 (truth table 0x96); the compiler emits two v_xor_b32 when c is a scalar register
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -39,13 +42,19 @@ __host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1
     return u32x4{c0, c1, c2, c3};
 }
 
-// (0,1) uniform with 53 significant bits from two words: ((hi:lo >> 11) + 0.5) * 2^-53
-__host__ __device__ __forceinline__ double uniform53(uint32_t lo, uint32_t hi) {
+// (0,1] uniform with 53 significant bits from two words: u = ((hi:lo >> 11) + 0.5) * 2^-53, rounded once (the largest
+// of the 2^53 values rounds to 1.0).  v + 0.5 rounds exactly like the scaled sum and the power of two is exact, so
+// add + ldexp (two inline constants) gives the bits of fma(v, 2^-53, 2^-54) without materialising the constants.
+template <int EXP2>
+__device__ __forceinline__ double uniform53_scaled(uint32_t lo, uint32_t hi) {
     const uint32_t top = hi >> 11;                         // 21 bits
     const uint32_t low = (hi << 21) | (lo >> 11);          // 32 bits (one v_alignbit_b32)
     const double v = __builtin_fma((double)top, 4294967296.0, (double)low);     // exact, < 2^53
-    return __builtin_fma(v, 0x1.0p-53, 0x1.0p-54);          // == (v + 0.5) * 2^-53, same rounding
+    return __builtin_amdgcn_ldexp(v + 0.5, EXP2);
 }
+__device__ __forceinline__ double uniform53(uint32_t lo, uint32_t hi) { return uniform53_scaled<-53>(lo, hi); }
+// 4 u: the Box-Muller angle 2 pi u in quarter turns (exactly 4 * uniform53)
+__device__ __forceinline__ double uniform53q(uint32_t lo, uint32_t hi) { return uniform53_scaled<-51>(lo, hi); }
 
 struct RngKey {
     uint32_t k0, k1;    // seed
@@ -56,10 +65,10 @@ struct RngKey {
 __device__ __forceinline__ void normal_pair(const RngKey& key, uint32_t stream, uint32_t j, double& z0, double& z1) {
     const u32x4 w = philox4x32_10(j, stream, key.r0, key.r1, key.k0, key.k1);
     const double u1 = uniform53(w.x, w.y);
-    const double u2 = uniform53(w.z, w.w);
-    const double r = sqrt(-2.0 * log_u01(u1));
+    const double q2 = uniform53q(w.z, w.w);
+    const double r = sqrt_pos(-2.0 * log_u01(u1));
     double s, c;
-    sincospi_02(2.0 * u2, s, c);
+    sincos_quarters(q2, s, c);
     z0 = r * c;
     z1 = r * s;
 }
@@ -77,17 +86,17 @@ __device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, 
     for (int k = 0; k < N; ++k) {
         const u32x4 w = philox4x32_10(j, first + k, key.r0, key.r1, key.k0, key.k1);
         u1[k] = uniform53(w.x, w.y);
-        u2[k] = uniform53(w.z, w.w);
+        u2[k] = uniform53q(w.z, w.w);
     }
     double r[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) r[k] = -2.0 * log_u01(u1[k], mk);
 #pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = sqrt(r[k]);
+    for (int k = 0; k < N; ++k) r[k] = sqrt_pos(r[k]);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         double s, c;
-        sincospi_02(u2[k] + u2[k], s, c, mk);
+        sincos_quarters(u2[k], s, c, mk);
         z0[k] = r[k] * c;
         z1[k] = r[k] * s;
     }
@@ -100,17 +109,17 @@ __device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, 
     for (int k = 0; k < N; ++k) {
         const u32x4 w = philox4x32_10(j, first + k, key.r0, key.r1, key.k0, key.k1);
         u1[k] = uniform53(w.x, w.y);
-        u2[k] = uniform53(w.z, w.w);
+        u2[k] = uniform53q(w.z, w.w);
     }
     double r[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) r[k] = -2.0 * log_u01(u1[k]);
 #pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = sqrt(r[k]);
+    for (int k = 0; k < N; ++k) r[k] = sqrt_pos(r[k]);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         double s, c;
-        sincospi_02(u2[k] + u2[k], s, c);
+        sincos_quarters(u2[k], s, c);
         z0[k] = r[k] * c;
         z1[k] = r[k] * s;
     }

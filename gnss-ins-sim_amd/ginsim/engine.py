@@ -314,6 +314,17 @@ class MonteCarloJob(object):
         """Enqueue the fused kernel on the context's stream (asynchronous)."""
         check(lib.ginsim_mc_run(self.ctx.handle, C.byref(self.params)))
 
+    def kernel_name(self):
+        """Name of the kernel launch() dispatches for these parameters (as rocprofv3 reports it, without arguments)."""
+        v = C.c_int32(0)
+        check(lib.ginsim_mc_variant(C.byref(self.params), C.byref(v)))
+        p = self.params
+        if p.precision == 1:
+            return 'ginsim::f32::mc_kernel_f32%s<%d, %d>' % ('_split' if v.value else '', p.ref_frame, p.algo_mask)
+        if v.value:
+            return 'ginsim::mc_kernel_split<%d, %d, 1>' % (p.ref_frame, p.algo_mask)
+        return 'ginsim::mc_kernel<%d, %d, %s>' % (p.ref_frame, p.algo_mask, 'true' if p.given_sensors else 'false')
+
     def run(self):
         self.launch()
         self.ctx.sync()
