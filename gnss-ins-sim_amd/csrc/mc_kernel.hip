@@ -303,18 +303,18 @@ constexpr int kSplitRuns = 256;
 // of 4 steps (128 KiB ring).  NP = 2: streams 0..2 and 3..5 produced by two groups, the consumer generates nothing,
 // tile of 3 steps (144 KiB ring).  Either way the ring allows exactly one workgroup per CU.  Only NP = 1 is
 // instantiated: NP = 2 (three wavefronts per SIMD) measured the same 2.40 ms at 65 536 runs -- with two wavefronts the
-// SIMD is already issue-bound -- and 10 % slower for ref_frame 0.
+// SIMD is already issue-bound -- and 10 % slower for ref_frame 0.  TILE = 2 (64 KiB ring, two workgroups per CU) for
+// batches above 1024 wavefronts measured 5 % slower than mc_kernel (7.43 against 7.06 ms at 262 144 runs).
 constexpr int split_pairs(int np) { return np == 1 ? 4 : 3; }          // Philox blocks (normal pairs) per producer and step
-constexpr int split_tile(int np) { return np == 1 ? 4 : 3; }
 constexpr int split_slots(int np) { return 2 * np * split_pairs(np); }
-constexpr size_t split_lds(int np) { return sizeof(double) * 2 * split_tile(np) * split_slots(np) * kSplitRuns; }
+constexpr size_t split_lds(int np, int tile) { return sizeof(double) * 2 * tile * split_slots(np) * kSplitRuns; }
 
-template <int RF, int ALGOS, int NP>
+template <int RF, int ALGOS, int NP, int TILE>
 __global__ void __launch_bounds__(256 * (NP + 1)) mc_kernel_split(const ginsim_mc_params a) {
     extern __shared__ double zring[];
     constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
     constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
-    constexpr int PP = split_pairs(NP), TILE = split_tile(NP), SLOTS = split_slots(NP);
+    constexpr int PP = split_pairs(NP), SLOTS = split_slots(NP);
     constexpr int OWN = 6 - NP * PP;                  // pairs left to the consumer
     constexpr int kStage = TILE * SLOTS * kSplitRuns;
     const int lane = threadIdx.x & (kSplitRuns - 1);
@@ -452,12 +452,12 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
         const dim3 sgrid((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns));
         if (v == 1) {
             static bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, 1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds(1));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, 1, 4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds(1, 4));
                 return true;
             }();
             (void)once;
-            hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, 1>), sgrid, dim3(512), split_lds(1), stream, p);
+            hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, 1, 4>), sgrid, dim3(512), split_lds(1, 4), stream, p);
             return hipGetLastError();
         }
     }

@@ -5,9 +5,9 @@
 //     velocity components) are Kahan-compensated so that 1e5 forward-Euler steps do not random-walk in the last bit;
 //   * POSITION is accumulated in fp64 (3 adds per step): ECEF (4.7e6 m) and LLA radians do not fit fp32 (ulp 0.5 m /
 //     6e-8 rad), and the series written to HBM is the fp32 DISPLACEMENT from the initial position;
-//   * noise: the same Philox4x32-10 counter stream, but each 32-bit word feeds one 24-bit uniform
-//     u = ((w >> 8) + 0.5) 2^-24, so one Philox block gives two Box-Muller pairs (4 normals) evaluated with the
-//     hardware v_log_f32 / v_sin_f32 / v_cos_f32 units.  |z| <= 5.9 sigma.  This is a different (coarser) noise
+//   * noise: the same Philox4x32-10 counter stream, but each 32-bit word feeds one 23-bit uniform
+//     u = (2 (w >> 9) + 1) 2^-24, so one Philox block gives two Box-Muller pairs (4 normals) evaluated with the
+//     hardware v_log_f32 / v_sin_f32 / v_cos_f32 units.  |z| <= 5.77 sigma.  This is a different (coarser) noise
 //     stream than the fp64 path; run-by-run comparison with fp64 is therefore done noise-free and in given-data
 //     form, and with noise the comparison is statistical (tests/test_gpu_fp32.py states the tolerances).
 //
@@ -80,7 +80,7 @@ struct Att {
     // attitude.euler_update_zyx (attitude.py:679-721) in fp32
     __device__ __forceinline__ void step(const V3& w, float dt, bool do_resync) {
         const float q = w.z * cr + w.y * sr;
-        const float icp = __frcp_rn(cp);
+        const float icp = __builtin_amdgcn_rcpf(cp);
         const float dy = q * icp * dt;
         const float dp = (w.y * cr - w.z * sr) * dt;
         const float dr = (w.x + q * (sp * icp)) * dt;
@@ -101,14 +101,21 @@ struct Att {
     }
 };
 
-// four standard normals from one Philox block (two Box-Muller pairs on the hardware transcendental units)
+// (0,1) uniform on the grid (2k+1) 2^-24, k < 2^23, from the top 23 bits of a word: v_alignbit_b32 drops them under
+// the exponent of 1.0f (a float in [1,2)), one subtraction moves it to (0,1).  Symmetric about 1/2; the smallest
+// value 2^-24 bounds |z| at 5.77 sigma.
+__device__ __forceinline__ float uniform23(uint32_t w) {
+    return __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, w, 9)) - 0x1.fffffep-1f;      // - (1 - 2^-24)
+}
+
+// four standard normals from one Philox block (two Box-Muller pairs on the hardware transcendental units:
+// v_log_f32, v_sqrt_f32 -- 1 ulp, the argument -2 ln u is in [1.2e-7, 33.3] -- and v_sin_f32 / v_cos_f32)
 __device__ __forceinline__ void normals4(const RngKey& key, uint32_t stream, uint32_t j, float (&z)[4]) {
     const u32x4 w = philox4x32_10(j, stream, key.r0, key.r1, key.k0, key.k1);
-    const float u0 = ((float)(w.x >> 8) + 0.5f) * 0x1.0p-24f, u1 = ((float)(w.y >> 8) + 0.5f) * 0x1.0p-24f;
-    const float u2 = ((float)(w.z >> 8) + 0.5f) * 0x1.0p-24f, u3 = ((float)(w.w >> 8) + 0.5f) * 0x1.0p-24f;
+    const float u0 = uniform23(w.x), u1 = uniform23(w.y), u2 = uniform23(w.z), u3 = uniform23(w.w);
     // -2 ln u = -2 ln2 log2 u ; v_sin_f32 / v_cos_f32 take the angle in revolutions
-    const float r0 = __builtin_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u0));
-    const float r1 = __builtin_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u2));
+    const float r0 = __builtin_amdgcn_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u0));
+    const float r1 = __builtin_amdgcn_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u2));
     z[0] = r0 * __builtin_amdgcn_cosf(u1);
     z[1] = r0 * __builtin_amdgcn_sinf(u1);
     z[2] = r1 * __builtin_amdgcn_cosf(u3);
@@ -182,7 +189,7 @@ __device__ __forceinline__ void nav_step(Nav& s, const V3& gyro, const V3& accel
         const float gm = (float)kG0 * (1.0f + (float)kGk * s2) * iw *
                          (1.0f - (float)(2.0 / kRe) * (1.0f + (float)(kFlat + kGm) - 2.0f * (float)kFlat * s2) * h +
                           (float)(3.0 / (kRe * kRe)) * (h * h));
-        const float irm = __frcp_rn(rm + h), irn = __frcp_rn(rn + h), icl = __frcp_rn(s.cl);
+        const float irm = __builtin_amdgcn_rcpf(rm + h), irn = __builtin_amdgcn_rcpf(rn + h), icl = __builtin_amdgcn_rcpf(s.cl);
         const V3 v = s.vel;
         const V3 w_en{v.y * irn, -v.x * irm, -v.y * s.sl * icl * irn};
         V3 w_ie{0.f, 0.f, 0.f};
