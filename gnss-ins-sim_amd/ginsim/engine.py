@@ -232,11 +232,16 @@ class MonteCarloJob(object):
 
     truth: dict with 'ref_accel' (n,3), 'ref_gyro' (n,3), 'ref_att'/'ref_pos'/'ref_vel' (n,3) and, for
     the odometer algorithm, 'ref_odo' (n,).  algos: subset of ('free', 'odo').
+
+    given: None (sensors are generated), or a dict of DeviceBuffers {'gyro', 'accel'[, 'odo']} holding sensor series
+    that are already on the device in the engine's [component][sample][run] fp64 layout -- e.g. the 'gyro'/'accel'
+    buffers another job materialised -- which are then integrated as they are (the plugin's run(set_of_input)
+    boundary for a whole batch; accel_err / gyro_err may be None).
     """
 
     def __init__(self, ctx, fs, ref_frame, truth, accel_err, gyro_err, ini, runs, algos=('free',),
                  odo_err=None, earth_rot=True, seed=0, run_offset=0, ini_first=0,
-                 keep_sensors=False, keep_traj=False, end_pos_ned=False, precision='f64'):
+                 keep_sensors=False, keep_traj=False, end_pos_ned=False, precision='f64', given=None):
         self.ctx = ctx
         self.algos = tuple(algos)
         for a in self.algos:
@@ -246,6 +251,15 @@ class MonteCarloJob(object):
         self.runs = int(runs)
         self.keep_sensors, self.keep_traj = bool(keep_sensors), bool(keep_traj)
         self.want_odo = 'odo' in self.algos or (odo_err is not None and 'ref_odo' in truth)
+        if given is not None:
+            if precision != 'f64' or keep_sensors or not self.algos:
+                raise ValueError('given sensors: fp64, at least one algorithm, nothing to keep but trajectories')
+            need = ['gyro'] + (['accel'] if 'free' in self.algos else []) + (['odo'] if 'odo' in self.algos else [])
+            for k in need:
+                size = (1 if k == 'odo' else 3) * self.n * self.runs * 8
+                if k not in given or given[k].nbytes < size:
+                    raise ValueError('given sensors: %r missing or smaller than %d bytes' % (k, size))
+            self.want_odo = False
         p = self.params = _lib.McParams()
         p.n, p.runs, p.run_offset, p.seed = self.n, self.runs, int(run_offset), int(seed) & (2 ** 64 - 1)
         p.fs, p.ref_frame = float(fs), int(ref_frame)
@@ -264,9 +278,16 @@ class MonteCarloJob(object):
         else:
             table, has_g = ini_table(ini)
         p.n_ini, p.ini_first, p.ini_has_g, p.given_sensors = table.shape[0], int(ini_first), int(has_g), 0
-        p.accel = sensor_model(accel_err, 'vrw', fs)
-        p.gyro = sensor_model(gyro_err, 'arw', fs)
-        if 'odo' in self.algos and (odo_err is None or 'ref_odo' not in truth):
+        if given is None:
+            p.accel = sensor_model(accel_err, 'vrw', fs)
+            p.gyro = sensor_model(gyro_err, 'arw', fs)
+        else:
+            p.given_sensors = 1
+            p.in_gyro = given['gyro'].ptr
+            p.in_accel = given['accel'].ptr if 'accel' in given else None
+            p.in_odo = given['odo'].ptr if 'odo' in given else None
+            self._given = given         # keeps the buffers alive
+        if given is None and 'odo' in self.algos and (odo_err is None or 'ref_odo' not in truth):
             raise ValueError('the odometer algorithm needs odo_err and truth["ref_odo"]')
         if self.want_odo:
             p.odo_scale, p.odo_stdv = float(odo_err['scale']), float(odo_err['stdv'])
@@ -302,6 +323,12 @@ class MonteCarloJob(object):
                 p.out_traj[s] = self._bufs['traj_' + a].ptr
 
     # bytes the launch writes to HBM (the algorithmic traffic of SURVEY 8(d))
+    def buffer(self, name):
+        """Device buffer of a materialised series ('accel', 'gyro', 'odo', 'traj_free', ...), e.g. to feed given=."""
+        if name not in self._bufs:
+            raise ValueError('%r was not kept by this job' % (name,))
+        return self._bufs[name]
+
     def bytes_written(self):
         per_sample = 0
         if self.keep_sensors:

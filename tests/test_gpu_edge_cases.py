@@ -193,3 +193,30 @@ def test_plain_and_wave_specialised_kernels_agree_bitwise(ctx, turn, rf, algos, 
                                       np.concatenate([halves[0].sensors('gyro', [5]), halves[1].sensors('gyro', [40000 - 33280])]))
     for j in [big] + halves:
         j.release()
+
+
+@pytest.mark.parametrize('rf,algos', [(1, ('free',)), (0, ('free', 'odo'))])
+def test_device_resident_given_sensors_replay_bitwise(ctx, turn, rf, algos):
+    """Sensors materialised by one job, integrated again by a given-sensors job (the plugin boundary for a whole batch,
+    ins_algo_manager.py:90): the mechanisation alone must reproduce the fused kernel's trajectories bit for bit."""
+    import ginsim
+    from ginsim import workloads
+    ini, truth = turn[rf]
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    R = 1500
+    gen = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc, gyr, ini, runs=R, algos=algos, odo_err={'scale': 0.999, 'stdv': 0.1},
+                               seed=3, keep_sensors=True, keep_traj=True).run()
+    given = {k: gen.buffer(k) for k in (('gyro', 'accel', 'odo') if 'odo' in algos else ('gyro', 'accel'))}
+    rep = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, None, None, ini, runs=R, algos=algos, keep_traj=True, given=given).run()
+    assert 'true' in rep.kernel_name()
+    pick = [0, 1, 63, 64, 777, R - 1]
+    for a in algos:
+        np.testing.assert_array_equal(rep.end_errors(a), gen.end_errors(a))
+        for x, y in zip(rep.trajectories(a, pick), gen.trajectories(a, pick)):
+            np.testing.assert_array_equal(x, y)
+        s1, s2 = rep.stats(a), gen.stats(a)
+        np.testing.assert_array_equal(s1.pack(), s2.pack())
+    with pytest.raises(ValueError, match='given sensors'):
+        ginsim.MonteCarloJob(ctx, 100.0, rf, truth, None, None, ini, runs=R, algos=algos, given={'gyro': given['gyro']} if 'free' in algos else {})
+    rep.release()
+    gen.release()
