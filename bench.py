@@ -51,6 +51,28 @@ def cpu_baseline(fs, rf, ini, truth, acc, gyr, seed, budget_s):
                       '(OpenMP over runs, %.1f s)' % (runs, n, dt)}
 
 
+def mechanisation_only(ginsim, ctx, job, fs, rf, truth, ini, R, n, reps=10):
+    """Outside the timed region: FreeIntegration.run alone for the whole batch -- the given-sensors kernel reads the
+    accel/gyro series the last step materialised (48 B) and writes att/pos/vel (72 B) per sample*MC.  This is the
+    HBM-bound piece of the path; the fused kernel above is fp64-VALU-bound."""
+    rep = ginsim.MonteCarloJob(ctx, fs, rf, truth, None, None, ini, runs=R, keep_traj=True,
+                               given={'gyro': job.buffer('gyro'), 'accel': job.buffer('accel')})
+    rep.run()
+    ms = []
+    for _ in range(reps):
+        ctx.timer_begin()
+        rep.launch()
+        ms.append(ctx.timer_end())
+    same = bool((rep.end_errors('free') == job.end_errors('free')).all())
+    name = rep.kernel_name()
+    rep.release()
+    avg = sum(ms) / len(ms)
+    b = 120 * R * n + 72 * R
+    return {'kernel': name, 'kernel_ms_avg': avg, 'algorithmic_bytes_per_launch': b, 'achieved': b / avg / 1e6, 'unit': 'GB/s',
+            'peak': HBM_PEAK_GBS, 'frac': b / avg / 1e6 / HBM_PEAK_GBS, 'sample_MC_per_s': R * n / avg * 1e3,
+            'bit_identical_to_fused_kernel': same}
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
     path = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
@@ -177,6 +199,8 @@ def main():
             'result': {'att_std_deg': (merged.std[:3] * r2d).tolist(), 'vel_std_mps': merged.std[6:9].tolist(),
                        'runs': merged.count},
         }
+        if world == 1 and keep and args.precision == 'f64':
+            out['mechanisation_only'] = mechanisation_only(ginsim, ctx, job, fs, rf, truth, ini, R, n)
         if world == 1 and args.cpu_baseline_seconds > 0:
             out['cpu_baseline'] = cpu_baseline(fs, rf, ini, truth, acc, gyr, seed, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,41 @@
+// Launch interface of the Allan-variance kernels (allan.hip) for the C ABI glue (ginsim_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ginsim {
+
+struct AllanLevel {
+    int64_t n_in;           // entries of this level per series
+    int64_t n_out;          // entries of the next level per series (n_in / 10), 0 = do not emit
+    int64_t in_stride;      // series stride of the input (entries)
+    int64_t out_stride;     // series stride of the output
+    int64_t nb[9];          // valid bins for j = 1..9 at this level (0 = factor not evaluated)
+    int32_t chunks_per_block;   // chunks folded into one wavefront's accumulators before they are written out
+    int32_t nchunks;
+};
+
+// levels that fit one chunk, finished by one wavefront per series in a single launch
+struct AllanTail {
+    int32_t nlevels, first;     // tail levels first .. first + nlevels - 1
+    int64_t in_stride;          // series stride of the first tail level's input
+    int64_t nseries;
+    int64_t n_in[4];
+    int64_t nb[4][9];
+};
+
+struct AllanFold {
+    int32_t nlevels;
+    int32_t nparts[8];
+    int64_t offset[8];          // first record of the level in partial[] (records of 9 doubles)
+};
+
+int allan_chunk_entries();
+int allan_chunks(int64_t n_in);
+int allan_chunks_per_block(int64_t total_chunks);
+int allan_parts(const AllanLevel& lv);
+hipError_t launch_allan_level(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries, hipStream_t st);
+hipError_t launch_allan_fold(const double* partial, double* sums, const AllanFold& f, int64_t nseries, hipStream_t st);
+hipError_t launch_allan_tail(const double* in, double* sums, const AllanTail& t, hipStream_t st);
+
+}  // namespace ginsim

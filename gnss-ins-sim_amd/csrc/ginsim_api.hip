@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "ginsim.h"
+#include "allan.hpp"
 
 namespace ginsim {
 
@@ -42,15 +43,7 @@ hipError_t launch_end_stats(const double* end_err, int64_t runs, void* scratch, 
 void stats_merge_host(const ginsim_stats* parts, int nparts, ginsim_stats* out);
 hipError_t launch_process_stats(const double* traj, const double* ref, int64_t n, int64_t runs, int64_t j0, int pos_ned,
                                 double* out, hipStream_t s);
-struct AllanLevel {
-    int64_t n_in, n_out, in_stride, out_stride;
-    int64_t nb[9];
-    int32_t chunks_per_block, nchunks;
-};
-hipError_t launch_allan_level(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries,
-                              double* sums, hipStream_t st);
-int allan_chunks(int64_t n_in);
-int allan_chunks_per_block(int64_t total_chunks);
+
 
 }  // namespace ginsim
 
@@ -475,9 +468,39 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
     HIP_TRY(hipSetDevice(c->device));
     const int levels = decades;
     const int64_t n1 = n / 10;
+    // levels of more than one chunk: one launch each, per-wavefront partial sums, ONE fold launch at the end;
+    // levels of at most one chunk (the last three or four): one launch for all of them
+    std::vector<AllanLevel> lvs(levels);
+    AllanFold fold;
+    fold.nlevels = 0;
+    int64_t records = 0;
+    {
+        int64_t n_in = n, stride_in = series_stride, pow10 = 1;
+        for (int k = 0; k < levels; ++k) {
+            AllanLevel& lv = lvs[k];
+            lv.n_in = n_in;
+            lv.n_out = (k + 1 < levels) ? n_in / 10 : 0;
+            lv.in_stride = stride_in;
+            lv.out_stride = lv.n_out;
+            for (int j = 1; j <= 9; ++j) lv.nb[j - 1] = (j * pow10 <= mmax) ? n / (j * pow10) : 0;
+            lv.nchunks = allan_chunks(n_in);
+            lv.chunks_per_block = allan_chunks_per_block((int64_t)lv.nchunks * nseries);
+            if (n_in > allan_chunk_entries()) {
+                REQUIRE(k < 8, "allan: series too long");
+                fold.nparts[k] = allan_parts(lv);
+                fold.offset[k] = records;
+                records += (int64_t)fold.nparts[k] * nseries;
+                fold.nlevels = k + 1;
+            }
+            stride_in = lv.n_out;
+            n_in = lv.n_out;
+            pow10 *= 10;
+        }
+    }
+    REQUIRE(levels - fold.nlevels <= 4, "allan: internal level plan");
     struct Region { void* p; double* d() const { return reinterpret_cast<double*>(p); } } ping, pong, partial, sums;
     const size_t b_ping = sizeof(double) * (size_t)nseries * (n1 + 1), b_pong = sizeof(double) * (size_t)nseries * (n1 / 10 + 1);
-    const size_t b_part = sizeof(double) * 9 * (size_t)nseries * allan_chunks(n), b_sums = sizeof(double) * 9 * (size_t)nseries * levels;
+    const size_t b_part = sizeof(double) * 9 * (size_t)(records + 1), b_sums = sizeof(double) * 9 * (size_t)nseries * levels;
     void* region = nullptr;
     HIP_TRY(scratch(c, 1, b_ping + b_pong + b_part + b_sums + 1024, &region));
     ping.p = region;
@@ -485,22 +508,23 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
     partial.p = reinterpret_cast<char*>(pong.p) + ((b_pong + 255) & ~(size_t)255);
     sums.p = reinterpret_cast<char*>(partial.p) + ((b_part + 255) & ~(size_t)255);
     const double* in = x;
-    int64_t stride_in = series_stride, n_in = n, pow10 = 1;
-    for (int k = 0; k < levels; ++k) {
-        AllanLevel lv;
-        lv.n_in = n_in;
-        lv.n_out = (k + 1 < levels) ? n_in / 10 : 0;
-        lv.in_stride = stride_in;
-        lv.out_stride = lv.n_out;
-        for (int j = 1; j <= 9; ++j) lv.nb[j - 1] = (j * pow10 <= mmax) ? n / (j * pow10) : 0;
-        lv.nchunks = allan_chunks(n_in);
-        lv.chunks_per_block = allan_chunks_per_block((int64_t)lv.nchunks * nseries);
+    for (int k = 0; k < fold.nlevels; ++k) {
         double* out = (k % 2 == 0) ? ping.d() : pong.d();
-        HIP_TRY(launch_allan_level(in, out, partial.d(), lv, nseries, sums.d() + (size_t)9 * nseries * k, c->stream));
+        HIP_TRY(launch_allan_level(in, out, partial.d() + 9 * fold.offset[k], lvs[k], nseries, c->stream));
         in = out;
-        stride_in = lv.n_out;
-        n_in = lv.n_out;
-        pow10 *= 10;
+    }
+    HIP_TRY(launch_allan_fold(partial.d(), sums.d(), fold, nseries, c->stream));
+    if (fold.nlevels < levels) {
+        AllanTail t;
+        t.first = fold.nlevels;
+        t.nlevels = levels - fold.nlevels;
+        t.in_stride = lvs[t.first].in_stride;
+        t.nseries = nseries;
+        for (int l = 0; l < t.nlevels; ++l) {
+            t.n_in[l] = lvs[t.first + l].n_in;
+            for (int j = 0; j < 9; ++j) t.nb[l][j] = lvs[t.first + l].nb[j];
+        }
+        HIP_TRY(launch_allan_tail(in, sums.d(), t, c->stream));
     }
     std::vector<double> h((size_t)9 * nseries * levels);
     HIP_TRY(hipMemcpyAsync(h.data(), sums.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
