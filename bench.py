@@ -69,7 +69,8 @@ def mechanisation_only(ginsim, ctx, job, fs, rf, truth, ini, R, n, reps=10):
     avg = sum(ms) / len(ms)
     b = 120 * R * n + 72 * R
     return {'kernel': name, 'kernel_ms_avg': avg, 'algorithmic_bytes_per_launch': b, 'achieved': b / avg / 1e6, 'unit': 'GB/s',
-            'peak': HBM_PEAK_GBS, 'frac': b / avg / 1e6 / HBM_PEAK_GBS, 'sample_MC_per_s': R * n / avg * 1e3,
+            'peak': HBM_PEAK_GBS, 'frac': b / avg / 1e6 / HBM_PEAK_GBS, 'traffic': pmc_traffic('mc_kernel_rf%d_free_given' % rf),
+            'sample_MC_per_s': R * n / avg * 1e3,
             'bit_identical_to_fused_kernel': same}
 
 

@@ -50,6 +50,31 @@ measure('C5 fp32 stats-only', 'turn_90deg', 100.0, 1, 65536, False, precision='f
 measure('C5 fp32 262144 runs materialised', 'turn_90deg', 100.0, 1, 262144, True, precision='f32')
 measure('C3 long_drive 262144 runs stats-only', 'long_drive', 200.0, 0, 262144, False, reps=2, gps=True)
 measure('C3 long_drive 262144 runs stats-only fp32', 'long_drive', 200.0, 0, 262144, False, precision='f32', reps=2, gps=True)
+
+
+def measure_given(name, rf, R):
+    """FreeIntegration.run alone for a whole batch: given-sensors kernel on device-resident series (48 B read + 72 B written)."""
+    ini, truth, _ = workloads.truth_from_profile('turn_90deg', 100.0, rf)
+    n = truth['ref_accel'].shape[0]
+    gen = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc, gyr, ini, runs=R, seed=1, keep_sensors=True).run()
+    rep = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, None, None, ini, runs=R, keep_traj=True,
+                               given={'gyro': gen.buffer('gyro'), 'accel': gen.buffer('accel')}).run()
+    ts = []
+    for _ in range(8):
+        ctx.timer_begin(); rep.launch(); ts.append(ctx.timer_end())
+    ms = float(np.median(ts))
+    alg = 120 * R * n + 72 * R
+    row = {'config': name, 'profile': 'turn_90deg', 'fs': 100.0, 'ref_frame': rf, 'runs': R, 'samples_per_run': n, 'precision': 'f64',
+           'kernel': rep.kernel_name(), 'kernel_ms_median': ms, 'kernel_ms_min': float(min(ts)), 'sample_MC_per_s': R * n / ms * 1e3,
+           'algorithmic_bytes': alg, 'achieved_GBps': alg / ms / 1e6, 'frac_of_hbm_peak': alg / ms / 1e6 / 8000.0}
+    print(json.dumps(row), flush=True)
+    out['rows'].append(row)
+    rep.release(); gen.release()
+
+
+measure_given('mechanisation only (given sensors on device), C2 shape', 1, 65536)
+measure_given('mechanisation only (given sensors on device), 131072 runs', 1, 131072)
+measure_given('mechanisation only (given sensors on device), ref_frame 0', 0, 65536)
 # Allan (C5)
 S, n, fs = 192, 1440000, 400.0
 x = np.random.default_rng(0).normal(size=(S, n))

@@ -15,4 +15,5 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/prof_pmc_write -o bench -- $B 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_pmc_fetch -o bench -- $B > $OUT/prof_pmc_fetch.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/prof_pmc_sq -o bench -- $B > $OUT/prof_pmc_sq.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace -d $OUT/prof_pmc_grbm -o bench -- $B > $OUT/prof_pmc_grbm.log 2>&1
-find $OUT -name "*.csv" | head -40
+rocprofv3 --kernel-trace --stats -d $OUT/prof_allan -o bench -- python $ROOT/tools/bench_allan.py > $OUT/prof_allan.log 2>&1
+ls $OUT

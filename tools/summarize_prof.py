@@ -34,6 +34,18 @@ if con:
             w.writerow([r[0], r[1], int(r[2]), int(r[3]), int(r[4]), int(r[5]), '%.2f' % (100.0 * r[2] / total)] + list(r[6:]))
     print(open(os.path.join(DST, tag + '_kernel_trace_stats.csv')).read())
 
+con = db('prof_allan')
+if con:
+    rows = list(con.execute("select name, grid_x, grid_y, count(*), avg(end-start), min(end-start), max(end-start), max(vgpr_count), max(lds_size) "
+                            "from kernels where name like '%allan%' group by name, grid_x, grid_y order by avg(end-start) desc"))
+    with open(os.path.join(DST, tag + '_allan_kernel_trace.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['# rocprofv3 --kernel-trace --stats -- python tools/bench_allan.py  (192 series x 1 440 000 samples, 11 calls)'])
+        w.writerow(['kernel', 'grid_x', 'grid_y', 'calls', 'avg_ns', 'min_ns', 'max_ns', 'vgpr', 'lds_bytes'])
+        for r in rows:
+            w.writerow([r[0], r[1], r[2], r[3], int(r[4]), int(r[5]), int(r[6]), r[7], r[8]])
+    print(open(os.path.join(DST, tag + '_allan_kernel_trace.csv')).read())
+
 pmc = {}
 for d in sorted(os.listdir(SRC)):
     if not d.startswith('prof_pmc'):
@@ -60,7 +72,7 @@ for k, c in pmc.items():
         # half of the bytes of a coalesced stream -> doubled.  WRITE_SIZE matched the known byte count exactly here.
         fetch_b = 2.0 * c['FETCH_SIZE'][1] * 1024
         write_b = c['WRITE_SIZE'][1] * 1024
-        key = 'mc_kernel_rf1_free_keep'
+        key = 'mc_kernel_rf1_free_given' if ', true>' in k else 'mc_kernel_rf1_free_keep'
         traffic[key] = {'kernel': k, 'hbm_bytes_per_launch': fetch_b + write_b, 'fetch_bytes_corrected': fetch_b,
                         'write_bytes': write_b, 'source': 'profiles/%s_pmc_counters.csv' % tag}
 with open(os.path.join(DST, 'pmc_traffic.json'), 'w') as f:
@@ -70,5 +82,8 @@ for k in pmc:
     if 'mc_kernel' in k:
         c = pmc[k]
         if 'SQ_WAVE_CYCLES' in c:
+            print(k)
+            if 'GRBM_GUI_ACTIVE' in c:
+                print('  GRBM_GUI_ACTIVE (summed over the 8 XCDs) per launch: %.4g' % c['GRBM_GUI_ACTIVE'][1])
             print('VALU active / wave cycles: %.3f ; busy cycles %.4g ; VALU insts/wave %.4g' % (
                 c['SQ_ACTIVE_INST_VALU'][1] / c['SQ_WAVE_CYCLES'][1], c['SQ_BUSY_CYCLES'][1], c['SQ_INSTS_VALU'][1] / c['SQ_WAVES'][1]))
