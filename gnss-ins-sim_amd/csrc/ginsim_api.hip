@@ -56,6 +56,9 @@ struct ginsim_ctx {
     std::vector<hipEvent_t> pool;   // lazily created, indexed by slot
     void* ws[4] = {nullptr, nullptr, nullptr, nullptr};   // grow-only scratch regions (stats / allan)
     size_t ws_bytes[4] = {0, 0, 0, 0};
+    ginsim_stats* stat_slots = nullptr;                   // pinned host records of ginsim_end_stats_begin/_finish
+    hipEvent_t stat_ev[8] = {};
+    bool stat_pending[8] = {};
 };
 
 // grow-only scratch owned by the context: avoids a hipMalloc/hipFree pair (~100 us each) per call
@@ -151,6 +154,9 @@ int ginsim_destroy(ginsim_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     for (void* w : c->ws)
         if (w) (void)hipFree(w);
+    for (hipEvent_t e : c->stat_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stat_slots) (void)hipHostFree(c->stat_slots);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return GINSIM_OK;
@@ -316,6 +322,31 @@ int ginsim_end_stats(ginsim_ctx* c, const double* end_err, int64_t runs, ginsim_
     const char* res = reinterpret_cast<char*>(ws) + stats_scratch_bytes(runs) - sizeof(ginsim_stats);
     HIP_TRY(hipMemcpyAsync(host_out, res, sizeof(ginsim_stats), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_end_stats_begin(ginsim_ctx* c, const double* end_err, int64_t runs, int32_t slot) {
+    REQUIRE(c && end_err && runs >= 1 && slot >= 0 && slot < 8, "end_stats_begin: bad arguments");
+    REQUIRE(!c->stat_pending[slot], "end_stats_begin: slot %d is still pending (call ginsim_end_stats_finish first)", slot);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->stat_slots) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->stat_slots), 8 * sizeof(ginsim_stats), hipHostMallocDefault));
+    if (!c->stat_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&c->stat_ev[slot], hipEventDisableTiming));
+    void* ws = nullptr;
+    HIP_TRY(scratch(c, 0, stats_scratch_bytes(runs), &ws));
+    HIP_TRY(launch_end_stats(end_err, runs, ws, c->stream));
+    const char* res = reinterpret_cast<char*>(ws) + stats_scratch_bytes(runs) - sizeof(ginsim_stats);
+    HIP_TRY(hipMemcpyAsync(&c->stat_slots[slot], res, sizeof(ginsim_stats), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->stat_ev[slot], c->stream));
+    c->stat_pending[slot] = true;
+    return GINSIM_OK;
+}
+
+int ginsim_end_stats_finish(ginsim_ctx* c, int32_t slot, ginsim_stats* host_out) {
+    REQUIRE(c && host_out && slot >= 0 && slot < 8, "end_stats_finish: bad arguments");
+    REQUIRE(c->stat_pending[slot], "end_stats_finish: nothing was begun in slot %d", slot);
+    HIP_TRY(hipEventSynchronize(c->stat_ev[slot]));
+    *host_out = c->stat_slots[slot];
+    c->stat_pending[slot] = false;
     return GINSIM_OK;
 }
 

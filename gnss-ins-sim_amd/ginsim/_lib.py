@@ -86,6 +86,8 @@ _SIGS = {
     'ginsim_mc_run': (C.c_int, [C.c_void_p, C.POINTER(McParams)]),
     'ginsim_mc_variant': (C.c_int, [C.POINTER(McParams), C.POINTER(C.c_int32)]),
     'ginsim_end_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Stats)]),
+    'ginsim_end_stats_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    'ginsim_end_stats_finish': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     'ginsim_process_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _PD]),
     'ginsim_end_stats_from_traj': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                              C.POINTER(Stats)]),

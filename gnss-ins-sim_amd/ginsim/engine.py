@@ -362,6 +362,16 @@ class MonteCarloJob(object):
         check(lib.ginsim_end_stats(self.ctx.handle, self._bufs['end_' + algo].ptr, self.runs, C.byref(s)))
         return StatsResult(s)
 
+    def stats_begin(self, algo, slot=0):
+        """Enqueue the end-point reduction of the last launch() into pinned slot 0..7 without waiting for it."""
+        check(lib.ginsim_end_stats_begin(self.ctx.handle, self._bufs['end_' + algo].ptr, self.runs, int(slot)))
+
+    def stats_finish(self, slot=0):
+        """Wait for stats_begin(slot) only (later launches on the stream keep running) and return its record."""
+        s = _lib.Stats()
+        check(lib.ginsim_end_stats_finish(self.ctx.handle, int(slot), C.byref(s)))
+        return StatsResult(s)
+
     def process_stats(self, algo, first_sample=0, pos_ned=False):
         """Per-run statistics of the error over time (samples >= first_sample): (runs, 3, 9) = max|e|, mean, std.
         Needs the trajectories (keep_traj=True) and truth['ref_att'/'ref_pos'/'ref_vel']."""

@@ -168,6 +168,13 @@ typedef struct {
 
 int ginsim_end_stats(ginsim_ctx* ctx, const double* end_err /*device [9][runs]*/, int64_t runs, ginsim_stats* host_out);
 
+/* The same reduction without blocking the host: _begin enqueues the reduction and the copy of the record into pinned
+ * host slot `slot` (0..7) on the context's stream; _finish waits for that slot only and returns the record.  A caller
+ * can enqueue the next ginsim_mc_run between the two, so the host-side merge / multi-GPU exchange of batch k overlaps
+ * the integration of batch k+1. */
+int ginsim_end_stats_begin(ginsim_ctx* ctx, const double* end_err, int64_t runs, int32_t slot);
+int ginsim_end_stats_finish(ginsim_ctx* ctx, int32_t slot, ginsim_stats* host_out);
+
 /* Process-error statistics of every run: InsDataMgr.__process_error_stats (ins_data_manager.py:761-795) over
  * array_error (:519-553): e[j] = traj[j] - ref[j] for samples j >= first_sample, attitude wrapped to [-pi,pi];
  * pos_ned != 0 (ref_frame 0, extra_opt='ned'): LLA error -> metres in the local NED frame of the reference (:542-552).

@@ -220,3 +220,35 @@ def test_device_resident_given_sensors_replay_bitwise(ctx, turn, rf, algos):
         ginsim.MonteCarloJob(ctx, 100.0, rf, truth, None, None, ini, runs=R, algos=algos, given={'gyro': given['gyro']} if 'free' in algos else {})
     rep.release()
     gen.release()
+
+
+def test_async_stats_slots_match_blocking_reduction(ctx, turn):
+    """ginsim_end_stats_begin/_finish: the record of batch k is picked up after batch k+1 was enqueued (the overlap
+    bench.py uses) and equals the blocking reduction of the same batch."""
+    import ginsim
+    from ginsim import workloads
+    ini, truth = turn[1]
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    job = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=3000, seed=9)
+    blocking = []
+    for k in range(3):
+        job.params.run_offset = 3000 * k
+        blocking.append(job.run().stats('free').pack())
+    got = []
+    for k in range(3):
+        job.params.run_offset = 3000 * k
+        job.launch()
+        if k:
+            got.append(job.stats_finish((k - 1) & 1).pack())
+        job.stats_begin('free', k & 1)
+    got.append(job.stats_finish(0).pack())
+    np.testing.assert_array_equal(np.array(got), np.array(blocking))
+    with pytest.raises(ValueError, match='nothing was begun'):
+        job.stats_finish(3)
+    job.stats_begin('free', 5)
+    with pytest.raises(ValueError, match='still pending'):
+        job.stats_begin('free', 5)
+    job.stats_finish(5)
+    with pytest.raises(ValueError):
+        job.stats_begin('free', 8)
+    job.release()
