@@ -28,32 +28,58 @@ GINSIM_FM double vconst(double k) {
 }
 
 struct MathConsts {
-    double lg[10];          // 1/3 .. 1/21 (atanh series)
+    double l[6];            // log1p series after r: -1/2, 1/3, -1/4, 1/5, -1/6, 1/7
     double ln2_hi, ln2_lo;
-    double sc[7];           // sin: -1/3!, 1/5!, ... -1/15!
-    double cc[8];           // cos: -1/2!, 1/4!, ... 1/16!
-    double pio2_hi, pio2_lo;
-    // OPAQUE = true pins the 29 constants in VGPRs (58 registers); false leaves them to the compiler (SGPR literals),
+    double sc[5];           // sin: -1/3!, 1/5!, -1/7!, 1/9!, -1/11!   (Box-Muller uses 3, rotate_sincos 5)
+    double cc[6];           // cos: -1/2!, 1/4!, ... 1/12!             (Box-Muller uses 3, rotate_sincos 6)
+    double ang_bias, ang_scale;     // 0.5 - 2^44 and 2 pi 2^-53: centred remainder of the 53-bit angle -> radians
+    // OPAQUE = true pins the 21 constants in VGPRs (42 registers); false leaves them to the compiler (SGPR literals),
     // which is what the two-algorithm kernels need to stay under 256 VGPRs without scratch spills.
     template <bool OPAQUE>
     GINSIM_FM void init() {
         auto vconst = [](double x) { return OPAQUE ? ginsim::vconst(x) : x; };
+        const double lc[6] = {-0.5, 1.0 / 3.0, -0.25, 0.2, -1.0 / 6.0, 1.0 / 7.0};
 #pragma unroll
-        for (int k = 0; k < 10; ++k) lg[k] = vconst(1.0 / (2 * k + 3));
+        for (int k = 0; k < 6; ++k) l[k] = vconst(lc[k]);
         ln2_hi = vconst(6.93147180369123816490e-01);
         ln2_lo = vconst(1.90821492927058770002e-10);
-        const double s[7] = {-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0, -1.0 / 39916800.0, 1.0 / 6227020800.0,
-                             -1.0 / 1307674368000.0};
-        const double c[8] = {-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0, 1.0 / 479001600.0,
-                             -1.0 / 87178291200.0, 1.0 / 20922789888000.0};
+        const double s[5] = {-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0, -1.0 / 39916800.0};
+        const double c[6] = {-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0, 1.0 / 479001600.0};
 #pragma unroll
-        for (int k = 0; k < 7; ++k) sc[k] = vconst(s[k]);
+        for (int k = 0; k < 5; ++k) sc[k] = vconst(s[k]);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) cc[k] = vconst(c[k]);
-        pio2_hi = vconst(1.57079632679489655800e+00);
-        pio2_lo = vconst(6.12323399573676603587e-17);
+        for (int k = 0; k < 6; ++k) cc[k] = vconst(c[k]);
+        ang_bias = vconst(0.5 - 17592186044416.0);
+        ang_scale = vconst(6.283185307179586476925 * 0x1.0p-53);
     }
 };
+
+// Box-Muller lookup tables, built by every workgroup in LDS (6 KB):
+//   lg[k] = {1/c_k, ln c_k}, c_k the centre of the k-th of 128 mantissa bins of m in [sqrt(1/2), sqrt(2)) (c = 1 exactly
+//           for the bin that contains 1, so that ln u -> 0 without cancellation as u -> 1);
+//   sc[i] = {sin a_i, cos a_i}, a_i = 2 pi (i + 1/2) / 256: the centre of the i-th of 256 sectors of the turn.
+// With them log needs a degree-7 series in |r| <= 2^-8 instead of a reciprocal, a quotient correction and a degree-21
+// series, and sin/cos need two three-term series in |b| <= pi/256 and four FMAs instead of a quadrant reduction, two
+// degree-15/16 series and the swap / sign selects.
+constexpr int kLogBins = 128, kAngBins = 256;
+struct NormalTables {
+    const double2* lg;
+    const double2* sc;
+};
+
+GINSIM_FM void fill_normal_tables(double2* tab, int tid, int nthreads) {
+    for (int k = tid; k < kLogBins; k += nthreads) {
+        const int h0 = (k << 13) + 0x3fe6a09e;
+        const double m_lo = __hiloint2double(h0, 0), m_hi = __hiloint2double(h0 + 0x2000, 0);
+        const double c = (m_lo <= 1.0 && 1.0 < m_hi) ? 1.0 : 0.5 * (m_lo + m_hi);
+        tab[k] = double2{1.0 / c, log(c)};
+    }
+    for (int i = tid; i < kAngBins; i += nthreads) {
+        double sn, cs;
+        sincospi((double)(2 * i + 1) * (1.0 / 256.0), &sn, &cs);
+        tab[kLogBins + i] = double2{sn, cs};
+    }
+}
 
 // 1/x to ~1 ulp: hardware v_rcp_f64 estimate + two Newton steps.
 GINSIM_FM double rcp_nr(double x) {
@@ -85,75 +111,42 @@ GINSIM_FM double sqrt_pos(double x) {
 }
 
 // Natural log for 0 < u <= 1 (normal, not denormal: u >= 2^-54 by construction of uniform53).
-//   u = m * 2^e, m in [sqrt(1/2), sqrt(2));  ln u = e ln2 + 2 atanh(s),  s = (m-1)/(m+1),  |s| <= 0.1716
-// The exponent/mantissa split is done on the high word with integer arithmetic only (no compare/select):
+//   u = m 2^e, m in [sqrt(1/2), sqrt(2));  ln u = e ln2 + ln c_k + log1p(r),  r = m / c_k - 1,  |r| <= 2^-8
+// The exponent/mantissa split and the bin index are integer arithmetic on the high word (no compare/select):
 // adding (0x3ff00000 - 0x3fe6a09e) moves the sqrt(1/2) boundary onto an exponent boundary.
-GINSIM_FM double log_u01(double u) {
+GINSIM_FM double log_u01(double u, const MathConsts& k, const NormalTables& tab) {
     uint32_t hx = (uint32_t)__double2hiint(u) + (0x3ff00000u - 0x3fe6a09eu);
     const int e = (int)(hx >> 20) - 0x3ff;
+    const double2 t = tab.lg[(hx >> 13) & (kLogBins - 1)];
     hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
     const double m = __hiloint2double((int)hx, __double2loint(u));
-    const double num = m - 1.0, den = m + 1.0;
-    const double y = rcp_n1(den);
-    double s = num * y;
-    s = __builtin_fma(__builtin_fma(-den, s, num), y, s);   // one correction step: s = num/den to ~1 ulp
-    const double t = s * s;
-    // atanh(s)/s = sum t^k/(2k+1); t <= 0.02944 -> k = 10 leaves 2e-17
-    double p = 1.0 / 21.0;
-    p = __builtin_fma(p, t, 1.0 / 19.0);
-    p = __builtin_fma(p, t, 1.0 / 17.0);
-    p = __builtin_fma(p, t, 1.0 / 15.0);
-    p = __builtin_fma(p, t, 1.0 / 13.0);
-    p = __builtin_fma(p, t, 1.0 / 11.0);
-    p = __builtin_fma(p, t, 1.0 / 9.0);
-    p = __builtin_fma(p, t, 1.0 / 7.0);
-    p = __builtin_fma(p, t, 1.0 / 5.0);
-    p = __builtin_fma(p, t, 1.0 / 3.0);
-    const double s2 = s + s;
-    const double lnm = __builtin_fma(s2 * t, p, s2);          // 2s + 2s t p
+    const double r = __builtin_fma(m, t.x, -1.0);
+    double p = k.l[5];
+#pragma unroll
+    for (int i = 4; i >= 0; --i) p = __builtin_fma(p, r, k.l[i]);
     const double ed = (double)e;
-    // ln2 split so that ed * ln2_hi is exact for |e| < 2^10
-    return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lnm));
+    // (e ln2_hi + ln c) + (r + e ln2_lo + r^2 p): the first sum is exact to 1 ulp (ln2_hi has 21 trailing zero bits)
+    const double small = __builtin_fma(r * r, p, __builtin_fma(ed, k.ln2_lo, r));
+    return __builtin_fma(ed, k.ln2_hi, t.y) + small;
 }
 
-// sin/cos of theta for |theta| <= pi/4 (Taylor, truncation < 5e-17 / 2e-18)
-GINSIM_FM void sincos_q(double th, double& s, double& c) {
-    const double t = th * th;
-    double ps = -1.0 / 1307674368000.0;                        // -1/15!
-    ps = __builtin_fma(ps, t, 1.0 / 6227020800.0);             //  1/13!
-    ps = __builtin_fma(ps, t, -1.0 / 39916800.0);              // -1/11!
-    ps = __builtin_fma(ps, t, 1.0 / 362880.0);                 //  1/9!
-    ps = __builtin_fma(ps, t, -1.0 / 5040.0);
-    ps = __builtin_fma(ps, t, 1.0 / 120.0);
-    ps = __builtin_fma(ps, t, -1.0 / 6.0);
-    s = __builtin_fma(th * t, ps, th);
-    double pc = 1.0 / 20922789888000.0;                        //  1/16!
-    pc = __builtin_fma(pc, t, -1.0 / 87178291200.0);           // -1/14!
-    pc = __builtin_fma(pc, t, 1.0 / 479001600.0);              //  1/12!
-    pc = __builtin_fma(pc, t, -1.0 / 3628800.0);               // -1/10!
-    pc = __builtin_fma(pc, t, 1.0 / 40320.0);
-    pc = __builtin_fma(pc, t, -1.0 / 720.0);
-    pc = __builtin_fma(pc, t, 1.0 / 24.0);
-    pc = __builtin_fma(pc, t, -0.5);
-    c = __builtin_fma(t, pc, 1.0);
-}
-
-// sin(pi x), cos(pi x) for 0 <= x <= 2.  2x = k + r, k integer, |r| <= 1/2 (exact), angle = k pi/2 + r pi/2.
-// The argument is x2 = 2x, the angle in quarter turns (what uniform53q delivers).
-GINSIM_FM void sincos_quarters(double x2, double& s, double& c) {
-    const double kd = __builtin_rint(x2);
-    const double r = x2 - kd;                                   // exact
-    const int k = (int)kd;
-    // theta = r * pi/2 with a two-term constant so the product carries ~1 ulp of the angle
-    const double th = __builtin_fma(r, 1.57079632679489655800e+00, r * 6.12323399573676603587e-17);
-    double sq, cq;
-    sincos_q(th, sq, cq);
-    const bool swap = (k & 1) != 0;
-    const double ss = swap ? cq : sq;
-    const double cc = swap ? sq : cq;
-    // negate through the sign bit: sin flips for k in {2,3}, cos for k in {1,2} (mod 4)
-    s = __hiloint2double(__double2hiint(ss) ^ ((k & 2) << 30), __double2loint(ss));
-    c = __hiloint2double(__double2hiint(cc) ^ (((k + 1) & 2) << 30), __double2loint(cc));
+// sin and cos of the Box-Muller angle 2 pi (A + 1/2) 2^-53, A the 53-bit integer (hi:lo) >> 11 of two Philox words:
+// sector i = top 8 bits of A, b = centred remainder in radians (|b| <= pi/256), angle = a_i + b.
+GINSIM_FM void sincos_turn53(uint32_t lo, uint32_t hi, double& s, double& c, const MathConsts& k, const NormalTables& tab) {
+    const double2 t = tab.sc[hi >> 24];
+    const uint32_t mid = (hi >> 11) & 0x1fffu;                // bits 44..32 of A
+    const uint32_t low = (hi << 21) | (lo >> 11);             // bits 31..0 (one v_alignbit_b32)
+    const double rho = __builtin_fma((double)mid, 4294967296.0, (double)low);      // A mod 2^45, exact
+    const double b = (rho + k.ang_bias) * k.ang_scale;        // the sum is exact (< 2^44, 46 significant bits)
+    const double tt = b * b;
+    double ps = __builtin_fma(tt, k.sc[2], k.sc[1]);
+    ps = __builtin_fma(tt, ps, k.sc[0]);
+    const double sb = __builtin_fma(b * tt, ps, b);           // sin b
+    double pc = __builtin_fma(tt, k.cc[2], k.cc[1]);
+    pc = __builtin_fma(tt, pc, k.cc[0]);
+    const double cm = tt * pc;                                // cos b - 1
+    s = t.x + __builtin_fma(t.y, sb, t.x * cm);
+    c = t.y + __builtin_fma(-t.x, sb, t.y * cm);
 }
 
 // Rotate (s,c) = (sin a, cos a) by a small angle d: returns sin/cos(a+d).  Valid for |d| <= 0.25 rad
@@ -178,47 +171,7 @@ GINSIM_FM void rotate_sincos(double d, double& s, double& c) {
     c = __builtin_fma(-s0, sd, __builtin_fma(c0, cm1, c0));     // c + c (cos d - 1) - s sin d
 }
 
-// ---- the same functions with their coefficients taken from VGPR-resident constants (hot loop) -------------
-GINSIM_FM double log_u01(double u, const MathConsts& k) {
-    uint32_t hx = (uint32_t)__double2hiint(u) + (0x3ff00000u - 0x3fe6a09eu);
-    const int e = (int)(hx >> 20) - 0x3ff;
-    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
-    const double m = __hiloint2double((int)hx, __double2loint(u));
-    const double num = m - 1.0, den = m + 1.0;
-    const double y = rcp_n1(den);
-    double s = num * y;
-    s = __builtin_fma(__builtin_fma(-den, s, num), y, s);
-    const double t = s * s;
-    double p = k.lg[9];
-#pragma unroll
-    for (int i = 8; i >= 0; --i) p = __builtin_fma(p, t, k.lg[i]);
-    const double s2 = s + s;
-    const double lnm = __builtin_fma(s2 * t, p, s2);
-    const double ed = (double)e;
-    return __builtin_fma(ed, k.ln2_hi, __builtin_fma(ed, k.ln2_lo, lnm));
-}
-
-GINSIM_FM void sincos_quarters(double x2, double& s, double& c, const MathConsts& k) {
-    const double kd = __builtin_rint(x2);
-    const double r = x2 - kd;
-    const int q = (int)kd;
-    const double th = __builtin_fma(r, k.pio2_hi, r * k.pio2_lo);
-    const double t = th * th;
-    double ps = k.sc[6];
-#pragma unroll
-    for (int i = 5; i >= 0; --i) ps = __builtin_fma(ps, t, k.sc[i]);
-    const double sq = __builtin_fma(th * t, ps, th);
-    double pc = k.cc[7];
-#pragma unroll
-    for (int i = 6; i >= 0; --i) pc = __builtin_fma(pc, t, k.cc[i]);
-    const double cq = __builtin_fma(t, pc, 1.0);
-    const bool swap = (q & 1) != 0;
-    const double ss = swap ? cq : sq;
-    const double cs = swap ? sq : cq;
-    s = __hiloint2double(__double2hiint(ss) ^ ((q & 2) << 30), __double2loint(ss));
-    c = __hiloint2double(__double2hiint(cs) ^ (((q + 1) & 2) << 30), __double2loint(cs));
-}
-
+// ---- the same rotation with its coefficients taken from VGPR-resident constants (hot loop) -------------
 GINSIM_FM void rotate_sincos(double d, double& s, double& c, const MathConsts& k) {
     const double t = d * d;
     double ps = k.sc[4];

@@ -198,6 +198,12 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
         trace[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
         trace[2] = __builtin_amdgcn_s_memtime();
     }
+    __shared__ double2 ntab[GIVEN ? 1 : kLogBins + kAngBins];
+    if (!GIVEN) {
+        fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+        __syncthreads();
+    }
+    const NormalTables tab{ntab, ntab + (GIVEN ? 0 : kLogBins)};
     if (r >= a.runs) return;
     constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
     constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
@@ -243,24 +249,24 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
             const bool need_odo = ODO || a.out_odo;
             if (need_acc && need_gyr) {             // the common case: six streams in one phased batch
                 double z0[6], z1[6];
-                normal_pairs<6>(key, S_ACC_D_XY, jj, z0, z1, mk);
+                normal_pairs<6>(key, S_ACC_D_XY, jj, z0, z1, mk, tab);
                 const params_ptr kp = kernarg_params();
                 acc = sense3(cur_a, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
                 gyr = sense3(cur_g, &kp->gyro, dg, Vec3{z0[3], z1[3], z0[4]}, Vec3{z1[4], z0[5], z1[5]});
             } else if (need_acc) {
                 double z0[3], z1[3];
-                normal_pairs<3>(key, S_ACC_D_XY, jj, z0, z1, mk);
+                normal_pairs<3>(key, S_ACC_D_XY, jj, z0, z1, mk, tab);
                 acc = sense3(cur_a, &kernarg_params()->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             } else if (need_gyr) {
                 double z0[3], z1[3];
-                normal_pairs<3>(key, S_GYR_D_XY, jj, z0, z1, mk);
+                normal_pairs<3>(key, S_GYR_D_XY, jj, z0, z1, mk, tab);
                 gyr = sense3(cur_g, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             }
             if (need_acc && a.out_accel) store3(a.out_accel, plane, off, acc);
             if (need_gyr && a.out_gyro) store3(a.out_gyro, plane, off, gyr);
             if (need_odo) {
                 double z0, z1;
-                normal_pair(key, S_ODO, jj, z0, z1);
+                normal_pair(key, S_ODO, jj, z0, z1, mk, tab);
                 const params_ptr kq = kernarg_params();
                 odo = kq->odo_scale * as_uniform(a.ref_odo)[j] + kq->odo_stdv * z0;     // pathgen.py:639-640
                 if (a.out_odo) a.out_odo[off] = odo;
@@ -329,6 +335,10 @@ __global__ void __launch_bounds__(256 * (NP + 1)) mc_kernel_split(const ginsim_m
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     MathConsts mk;
     mk.init<true>();
+    __shared__ double2 ntab[kLogBins + kAngBins];
+    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const NormalTables tab{ntab, ntab + kLogBins};
 
     if (role != 0) {
         const uint32_t first = (uint32_t)((role - 1) * PP);
@@ -340,7 +350,7 @@ __global__ void __launch_bounds__(256 * (NP + 1)) mc_kernel_split(const ginsim_m
                     const int64_t j = i * TILE + t;
                     if (j < n_noise) {
                         double z0[PP], z1[PP];
-                        normal_pairs<PP>(key, first, (uint32_t)j, z0, z1, mk);
+                        normal_pairs<PP>(key, first, (uint32_t)j, z0, z1, mk, tab);
 #pragma unroll
                         for (int k = 0; k < PP; ++k) {
                             zb[(t * SLOTS + 2 * k) * kSplitRuns] = z0[k];
@@ -383,7 +393,7 @@ __global__ void __launch_bounds__(256 * (NP + 1)) mc_kernel_split(const ginsim_m
                 }
                 if constexpr (OWN > 0) {
                     double y0[OWN], y1[OWN];
-                    normal_pairs<OWN>(key, (uint32_t)(NP * PP), (uint32_t)j, y0, y1, mk);
+                    normal_pairs<OWN>(key, (uint32_t)(NP * PP), (uint32_t)j, y0, y1, mk, tab);
 #pragma unroll
                     for (int k = 0; k < OWN; ++k) { p0[NP * PP + k] = y0[k]; p1[NP * PP + k] = y1[k]; }
                 }
@@ -395,7 +405,7 @@ __global__ void __launch_bounds__(256 * (NP + 1)) mc_kernel_split(const ginsim_m
                 double odo = 0.0;
                 if (ODO || a.out_odo) {
                     double z0, z1;
-                    normal_pair(key, S_ODO, (uint32_t)j, z0, z1);
+                    normal_pair(key, S_ODO, (uint32_t)j, z0, z1, mk, tab);
                     const params_ptr kq = kernarg_params();
                     odo = kq->odo_scale * as_uniform(a.ref_odo)[j] + kq->odo_stdv * z0;
                     if (a.out_odo) a.out_odo[off] = odo;
@@ -489,13 +499,19 @@ hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------------
 // Auxiliary sensors: one thread per (sample, run), run fastest.  gps_gen: pathgen.py:621-624; mag_gen: :658-661.
 __global__ void __launch_bounds__(256) aux_gps_kernel(const ginsim_aux_params a) {
+    __shared__ double2 ntab[kLogBins + kAngBins];
+    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const NormalTables tab{ntab, ntab + kLogBins};
+    MathConsts mk;
+    mk.init<false>();
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.m * a.runs) return;
     const int64_t r = idx % a.runs, k = idx / a.runs;
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     double z0[3], z1[3];
-    normal_pairs<3>(key, S_GPS_P_XY, (uint32_t)k, z0, z1);
+    normal_pairs<3>(key, S_GPS_P_XY, (uint32_t)k, z0, z1, mk, tab);
     const double z[6] = {z0[0], z1[0], z0[1], z1[1], z0[2], z1[2]};     // pos x,y,z  vel x,y,z
     const int64_t plane = a.m * a.runs;
 #pragma unroll
@@ -503,13 +519,19 @@ __global__ void __launch_bounds__(256) aux_gps_kernel(const ginsim_aux_params a)
 }
 
 __global__ void __launch_bounds__(256) aux_mag_kernel(const ginsim_aux_params a) {
+    __shared__ double2 ntab[kLogBins + kAngBins];
+    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const NormalTables tab{ntab, ntab + kLogBins};
+    MathConsts mk;
+    mk.init<false>();
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.n * a.runs) return;
     const int64_t r = idx % a.runs, j = idx / a.runs;
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     double z0[2], z1[2];
-    normal_pairs<2>(key, S_MAG_XY, (uint32_t)j, z0, z1);
+    normal_pairs<2>(key, S_MAG_XY, (uint32_t)j, z0, z1, mk, tab);
     const double z[3] = {z0[0], z1[0], z0[1]};
     const double v[3] = {a.ref_mag[3 * j] + a.mag_hi[0], a.ref_mag[3 * j + 1] + a.mag_hi[1], a.ref_mag[3 * j + 2] + a.mag_hi[2]};
     const int64_t plane = a.n * a.runs;
@@ -530,11 +552,17 @@ hipError_t launch_aux(const ginsim_aux_params& p, hipStream_t s) {
 // RNG self-test: normals (and raw Philox words) of one (seed, run, stream), sample index = global lane.
 __global__ void rng_probe_kernel(uint64_t seed, uint64_t run, uint32_t stream, int64_t count,
                                  double* __restrict__ z0, double* __restrict__ z1, uint32_t* __restrict__ words) {
+    __shared__ double2 ntab[kLogBins + kAngBins];
+    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const NormalTables tab{ntab, ntab + kLogBins};
+    MathConsts mk;
+    mk.init<true>();                // the hot kernels' configuration
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)run, (uint32_t)(run >> 32)};
     double a, b;
-    normal_pair(key, stream, (uint32_t)j, a, b);
+    normal_pair(key, stream, (uint32_t)j, a, b, mk, tab);
     z0[j] = a;
     z1[j] = b;
     if (words) {

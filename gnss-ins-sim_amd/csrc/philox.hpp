@@ -45,84 +45,56 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 // (0,1] uniform with 53 significant bits from two words: u = ((hi:lo >> 11) + 0.5) * 2^-53, rounded once (the largest
 // of the 2^53 values rounds to 1.0).  v + 0.5 rounds exactly like the scaled sum and the power of two is exact, so
 // add + ldexp (two inline constants) gives the bits of fma(v, 2^-53, 2^-54) without materialising the constants.
-template <int EXP2>
-__device__ __forceinline__ double uniform53_scaled(uint32_t lo, uint32_t hi) {
+__device__ __forceinline__ double uniform53(uint32_t lo, uint32_t hi) {
     const uint32_t top = hi >> 11;                         // 21 bits
     const uint32_t low = (hi << 21) | (lo >> 11);          // 32 bits (one v_alignbit_b32)
     const double v = __builtin_fma((double)top, 4294967296.0, (double)low);     // exact, < 2^53
-    return __builtin_amdgcn_ldexp(v + 0.5, EXP2);
+    return __builtin_amdgcn_ldexp(v + 0.5, -53);
 }
-__device__ __forceinline__ double uniform53(uint32_t lo, uint32_t hi) { return uniform53_scaled<-53>(lo, hi); }
-// 4 u: the Box-Muller angle 2 pi u in quarter turns (exactly 4 * uniform53)
-__device__ __forceinline__ double uniform53q(uint32_t lo, uint32_t hi) { return uniform53_scaled<-51>(lo, hi); }
 
 struct RngKey {
     uint32_t k0, k1;    // seed
     uint32_t r0, r1;    // global run id
 };
 
-// Two standard normals for (key.run, stream, sample j).
-__device__ __forceinline__ void normal_pair(const RngKey& key, uint32_t stream, uint32_t j, double& z0, double& z1) {
-    const u32x4 w = philox4x32_10(j, stream, key.r0, key.r1, key.k0, key.k1);
-    const double u1 = uniform53(w.x, w.y);
-    const double q2 = uniform53q(w.z, w.w);
-    const double r = sqrt_pos(-2.0 * log_u01(u1));
-    double s, c;
-    sincos_quarters(q2, s, c);
-    z0 = r * c;
-    z1 = r * s;
-}
-
-// N consecutive streams (first, first+1, ...) of one sample, evaluated phase by phase -- all Philox blocks, then
-// all logarithms, then all square roots, then all sin/cos -- instead of N complete Box-Muller transforms in a
-// row.  Each phase is N independent dependency chains (ILP for a lone wavefront on its SIMD) and only ONE
-// polynomial's fp64 constants are live at a time; interleaving the transforms kept ~35 constants (70 SGPRs) live
-// and spilled SGPRs to VGPR lanes (~240 v_readlane/v_writelane per step in the first build).
+// N consecutive streams (first, first+1, ...) of one sample -> N pairs of standard normals
+//   z0 = sqrt(-2 ln u1) cos(2 pi u2),  z1 = sqrt(-2 ln u1) sin(2 pi u2),  u1 = uniform53(w.x, w.y), u2 = uniform53(w.z, w.w)
+// evaluated phase by phase -- all Philox blocks, then all logarithms, then all square roots, then all sin/cos --
+// instead of N complete Box-Muller transforms in a row.  Each phase is N independent dependency chains (ILP for a
+// lone wavefront on its SIMD) and only ONE polynomial's constants are live at a time.  The angle never becomes a
+// uniform: sincos_turn53 works on the integer.
 template <int N>
 __device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, uint32_t j, double (&z0)[N], double (&z1)[N],
-                                             const MathConsts& mk) {
-    double u1[N], u2[N];
+                                             const MathConsts& mk, const NormalTables& tab) {
+    double r[N];
+    uint32_t a_lo[N], a_hi[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const u32x4 w = philox4x32_10(j, first + k, key.r0, key.r1, key.k0, key.k1);
-        u1[k] = uniform53(w.x, w.y);
-        u2[k] = uniform53q(w.z, w.w);
+        r[k] = uniform53(w.x, w.y);
+        a_lo[k] = w.z;
+        a_hi[k] = w.w;
     }
-    double r[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = -2.0 * log_u01(u1[k], mk);
+    for (int k = 0; k < N; ++k) r[k] = -2.0 * log_u01(r[k], mk, tab);
 #pragma unroll
     for (int k = 0; k < N; ++k) r[k] = sqrt_pos(r[k]);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         double s, c;
-        sincos_quarters(u2[k], s, c, mk);
+        sincos_turn53(a_lo[k], a_hi[k], s, c, mk, tab);
         z0[k] = r[k] * c;
         z1[k] = r[k] * s;
     }
 }
 
-template <int N>
-__device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, uint32_t j, double (&z0)[N], double (&z1)[N]) {
-    double u1[N], u2[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const u32x4 w = philox4x32_10(j, first + k, key.r0, key.r1, key.k0, key.k1);
-        u1[k] = uniform53(w.x, w.y);
-        u2[k] = uniform53q(w.z, w.w);
-    }
-    double r[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = -2.0 * log_u01(u1[k]);
-#pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = sqrt_pos(r[k]);
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        double s, c;
-        sincos_quarters(u2[k], s, c);
-        z0[k] = r[k] * c;
-        z1[k] = r[k] * s;
-    }
+// Two standard normals for (key.run, stream, sample j).
+__device__ __forceinline__ void normal_pair(const RngKey& key, uint32_t stream, uint32_t j, double& z0, double& z1,
+                                            const MathConsts& mk, const NormalTables& tab) {
+    double a[1], b[1];
+    normal_pairs<1>(key, stream, j, a, b, mk, tab);
+    z0 = a[0];
+    z1 = b[0];
 }
 
 }  // namespace ginsim
