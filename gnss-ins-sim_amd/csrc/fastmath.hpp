@@ -99,15 +99,16 @@ GINSIM_FM double rcp_n1(double x) {
 
 // sqrt(x) for finite x >= 0 well inside the normal range (here x = -2 ln u <= 75.5); x below 2^-200 (only u = 1) is
 // lifted to 2^-200, i.e. returns 2^-100 instead of 0.  v_rsq_f64 estimate, one Goldschmidt step, one residual
-// correction: <= 1 ulp.  The compiler's sqrt() adds range scaling, a second correction and an inf/0 select (17 VALU).
+// correction: <= 1 ulp, 7 VALU + v_rsq.  The compiler's sqrt() adds range scaling, a second correction and an inf/0
+// select (17 VALU).
 GINSIM_FM double sqrt_pos(double x) {
     x = __builtin_fmax(x, 0x1.0p-200);
     const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
+    double g = x * y;
+    const double h = 0.5 * y;
     const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    return __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    g = __builtin_fma(g, r, g);                                // ~2^-46
+    return __builtin_fma(__builtin_fma(-g, g, x), h, g);       // the 2^-23 error of h only scales the correction
 }
 
 // Natural log for 0 < u <= 1 (normal, not denormal: u >= 2^-54 by construction of uniform53).

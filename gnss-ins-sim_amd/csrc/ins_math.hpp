@@ -112,7 +112,7 @@ struct Att {
     // over +-pi/2, or when a step exceeds 0.25 rad.  +-2pi wraps leave the trig untouched.
     GINSIM_HD void step(const Vec3& w, double dt, bool resync, const MathConsts& mk) {
         const double q = w.z * cr + w.y * sr;
-        const double icp = rcp_nr(cp);
+        const double icp = rcp_n1(cp);      // 2^-46 relative on a rate that is multiplied by dt: far below the state's ulp
         const double dy = q * icp * dt;
         const double dp = (w.y * cr - w.z * sr) * dt;
         const double dr = (w.x + q * (sp * icp)) * dt;

@@ -91,9 +91,9 @@ __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& a
         s.pos.z += v_prev.z * dt;
     } else {
         const Geo e = geo_param_sc(s.sl, s.cl, s.pos.z);
-        const double irm = rcp_nr(e.rm + s.pos.z);
-        const double irn = rcp_nr(e.rn + s.pos.z);
-        const double icl = rcp_nr(e.cl);
+        const double irm = rcp_n1(e.rm + s.pos.z);     // one Newton step (2^-46): these scale rates of ~1e-6 rad/s
+        const double irn = rcp_n1(e.rn + s.pos.z);
+        const double icl = rcp_n1(e.cl);
         const Vec3 v = s.vel;
         const Vec3 w_en{v.y * irn, -v.x * irm, -v.y * e.sl * icl * irn};
         Vec3 w_ie{0.0, 0.0, 0.0};
@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
     MathConsts mk;
-    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO))>();
+    // constants pinned in VGPRs except where that variant would spill to scratch (measured per variant)
+    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO)) || RF == 1>();
 
     if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
     if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(256 * (NP + 1)) mc_kernel_split(const ginsim_m
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     MathConsts mk;
-    mk.init<true>();
+    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO))>();     // the two-algorithm consumer would spill
     __shared__ double2 ntab[kLogBins + kAngBins];
     fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
