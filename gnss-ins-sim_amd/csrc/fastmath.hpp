@@ -97,6 +97,13 @@ GINSIM_FM double rcp_n1(double x) {
     return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
 }
 
+// 1/sqrt(x) to ~1 ulp for normal x: v_rsq_f64 estimate + two Newton steps y += y (1/2 - x y^2 / 2).
+GINSIM_FM double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = __builtin_fma(y, __builtin_fma(-0.5 * y, x * y, 0.5), y);
+    return __builtin_fma(y, __builtin_fma(-0.5 * y, x * y, 0.5), y);
+}
+
 // sqrt(x) for finite x >= 0 well inside the normal range (here x = -2 ln u <= 75.5); x below 2^-200 (only u = 1) is
 // lifted to 2^-200, i.e. returns 2^-100 instead of 0.  v_rsq_f64 estimate, one Goldschmidt step, one residual
 // correction: <= 1 ulp, 7 VALU + v_rsq.  The compiler's sqrt() adds range scaling, a second correction and an inf/0

@@ -36,14 +36,14 @@ GINSIM_HD Vec3 cross3(const Vec3& a, const Vec3& b) {   // attitude.cross3, atti
 struct Geo { double rm, rn, g, sl, cl; };
 
 // geoparams.geo_param, geoparams.py:25-53, with sin/cos(lat) supplied by the caller.  The three divisions by
-// sqrt(1 - e^2 sin^2) become one reciprocal (Newton-refined v_rcp_f64) and products.
+// sqrt(1 - e^2 sin^2) become one reciprocal square root (Newton-refined v_rsq_f64) and products.
 GINSIM_HD Geo geo_param_sc(double sl, double cl, double h) {
     Geo o;
     o.sl = sl;
     o.cl = cl;
     const double s2 = sl * sl;
     const double q = 1.0 - kEsq * s2;
-    const double iw = rcp_nr(sqrt(q));
+    const double iw = rsqrt_nr(q);
     o.rn = kRe * iw;
     o.rm = (kRe * (1.0 - kEsq)) * iw * (iw * iw);
     const double g1 = kG0 * (1.0 + kGk * s2) * iw;
