@@ -55,8 +55,8 @@ struct MathConsts {
 };
 
 // Box-Muller lookup tables, built by every workgroup in LDS (6 KB):
-//   lg[k] = {1/c_k, ln c_k}, c_k the centre of the k-th of 128 mantissa bins of m in [sqrt(1/2), sqrt(2)) (c = 1 exactly
-//           for the bin that contains 1, so that ln u -> 0 without cancellation as u -> 1);
+//   lg[k] = {1/c_k, ln c_k}, c_k within 2^-11 of the centre of the k-th of 128 mantissa bins of m in [sqrt(1/2), sqrt(2))
+//           (c = 1 exactly for the bin that contains 1, so that ln u -> 0 without cancellation as u -> 1);
 //   sc[i] = {sin a_i, cos a_i}, a_i = 2 pi (i + 1/2) / 256: the centre of the i-th of 256 sectors of the turn.
 // With them log needs a degree-7 series in |r| <= 2^-8 instead of a reciprocal, a quotient correction and a degree-21
 // series, and sin/cos need two three-term series in |b| <= pi/256 and four FMAs instead of a quadrant reduction, two
@@ -71,8 +71,15 @@ GINSIM_FM void fill_normal_tables(double2* tab, int tid, int nthreads) {
     for (int k = tid; k < kLogBins; k += nthreads) {
         const int h0 = (k << 13) + 0x3fe6a09e;
         const double m_lo = __hiloint2double(h0, 0), m_hi = __hiloint2double(h0 + 0x2000, 0);
-        const double c = (m_lo <= 1.0 && 1.0 < m_hi) ? 1.0 : 0.5 * (m_lo + m_hi);
-        tab[k] = double2{1.0 / c, log(c)};
+        // 1/c is rounded to 10 significant bits and ln c taken for THAT value: m * (1/c) - 1 is then one exactly rounded
+        // fma of the true ratio (no 2^-53 error of a rounded reciprocal, which would be an ABSOLUTE 1e-16 on ln u and
+        // spoil the relative accuracy of small |ln u|); the error of ln c scales with |ln c| ~ |ln u|.
+        double inv = 1.0;
+        if (!(m_lo <= 1.0 && 1.0 < m_hi)) {
+            inv = 1.0 / (0.5 * (m_lo + m_hi));
+            inv = __hiloint2double((__double2hiint(inv) + 0x200) & ~0x3ff, 0);
+        }
+        tab[k] = double2{inv, -log(inv)};
     }
     for (int i = tid; i < kAngBins; i += nthreads) {
         double sn, cs;
@@ -119,7 +126,7 @@ GINSIM_FM double sqrt_pos(double x) {
 }
 
 // Natural log for 0 < u <= 1 (normal, not denormal: u >= 2^-54 by construction of uniform53).
-//   u = m 2^e, m in [sqrt(1/2), sqrt(2));  ln u = e ln2 + ln c_k + log1p(r),  r = m / c_k - 1,  |r| <= 2^-8
+//   u = m 2^e, m in [sqrt(1/2), sqrt(2));  ln u = e ln2 + ln c_k + log1p(r),  r = m / c_k - 1,  |r| <= 4.4e-3
 // The exponent/mantissa split and the bin index are integer arithmetic on the high word (no compare/select):
 // adding (0x3ff00000 - 0x3fe6a09e) moves the sqrt(1/2) boundary onto an exponent boundary.
 GINSIM_FM double log_u01(double u, const MathConsts& k, const NormalTables& tab) {

@@ -35,6 +35,7 @@ hipError_t launch_aux(const ginsim_aux_params& p, hipStream_t s);
 hipError_t launch_rng_probe(uint64_t seed, uint64_t run, uint32_t stream, int64_t count, double* z0, double* z1,
                             uint32_t* words, hipStream_t stream_h);
 hipError_t launch_aos_to_soa(const double* src, double* dst, int64_t R, int64_t n, int C, hipStream_t s);
+hipError_t launch_box_muller(const uint32_t* words, int64_t count, double* z0, double* z1, hipStream_t s);
 hipError_t launch_gather_runs(const double* series, int C, int64_t n, int64_t runs, const int64_t* ids, int nsel,
                               double* out, hipStream_t s);
 size_t stats_scratch_bytes(int64_t runs);
@@ -591,6 +592,21 @@ int ginsim_rng_normals(ginsim_ctx* c, uint64_t seed, uint64_t run, uint32_t stre
     HIP_TRY(hipMemcpyAsync(host_z1, z1.p, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
     if (host_words)
         HIP_TRY(hipMemcpyAsync(host_words, w.p, sizeof(uint32_t) * 4 * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_box_muller(ginsim_ctx* c, const uint32_t* host_words, int64_t count, double* host_z0, double* host_z1) {
+    REQUIRE(c && host_words && host_z0 && host_z1 && count >= 1, "box_muller: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf z0, z1, w;
+    HIP_TRY(z0.alloc(sizeof(double) * count));
+    HIP_TRY(z1.alloc(sizeof(double) * count));
+    HIP_TRY(w.alloc(sizeof(uint32_t) * 4 * count));
+    HIP_TRY(hipMemcpyAsync(w.p, host_words, sizeof(uint32_t) * 4 * count, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_box_muller(w.as<uint32_t>(), count, z0.as<double>(), z1.as<double>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(host_z0, z0.p, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(host_z1, z1.p, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GINSIM_OK;
 }

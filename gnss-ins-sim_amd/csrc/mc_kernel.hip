@@ -601,6 +601,28 @@ __global__ void gather_runs_kernel(const double* __restrict__ series, int C, int
     out[idx] = series[((int64_t)c * n + j) * runs + ids[k]];
 }
 
+// Box-Muller on given words (test hook): same functions, same phase order as normal_pairs<1>.
+__global__ void box_muller_kernel(const uint32_t* __restrict__ words, int64_t count, double* __restrict__ z0, double* __restrict__ z1) {
+    __shared__ double2 ntab[kLogBins + kAngBins];
+    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const NormalTables tab{ntab, ntab + kLogBins};
+    MathConsts mk;
+    mk.init<true>();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double r = sqrt_pos(-2.0 * log_u01(uniform53(words[4 * i], words[4 * i + 1]), mk, tab));
+    double s, c;
+    sincos_turn53(words[4 * i + 2], words[4 * i + 3], s, c, mk, tab);
+    z0[i] = r * c;
+    z1[i] = r * s;
+}
+
+hipError_t launch_box_muller(const uint32_t* words, int64_t count, double* z0, double* z1, hipStream_t s) {
+    hipLaunchKernelGGL(box_muller_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, words, count, z0, z1);
+    return hipGetLastError();
+}
+
 hipError_t launch_aos_to_soa(const double* src, double* dst, int64_t R, int64_t n, int C, hipStream_t s) {
     const int tb = 256;
     hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)((n * R + tb - 1) / tb)), dim3(tb), 0, s, src, dst, R, n, C);

@@ -520,6 +520,14 @@ def rng_normals(ctx, seed, run, stream, count, words=False):
     return (z0, z1, w) if words else (z0, z1)
 
 
+def box_muller(ctx, words):
+    """Device Box-Muller on given Philox words (count, 4) uint32 -> (z0, z1).  Test hook for corner cases."""
+    w = np.ascontiguousarray(np.asarray(words, dtype=np.uint32).reshape(-1, 4))
+    z0, z1 = np.empty(w.shape[0]), np.empty(w.shape[0])
+    check(lib.ginsim_box_muller(ctx.handle, w.ctypes.data_as(C.POINTER(C.c_uint32)), w.shape[0], dptr(z0), dptr(z1)))
+    return z0, z1
+
+
 def allan_var(ctx, x, n, nseries, series_stride, fs, cap=128):
     """Allan variance of `nseries` device-resident series (DeviceBuffer or raw pointer), allan.py:18-59.
     Returns (avar (nseries, ntau), tau (ntau,))."""

@@ -214,6 +214,12 @@ int ginsim_allan(ginsim_ctx* ctx, const double* x, int64_t n, int32_t nseries, i
 int ginsim_rng_normals(ginsim_ctx* ctx, uint64_t seed, uint64_t run, uint32_t stream, int64_t count,
                        double* host_z0, double* host_z1, uint32_t* host_words /*[count][4] or NULL*/);
 
+/* Test hook: the device Box-Muller transform applied to caller-chosen Philox words (w[i][0..1] -> radius uniform,
+ * w[i][2..3] -> angle), so that corner cases no seed will produce in a test (u = 1, u = 2^-54, table-bin and sector
+ * edges) can be pinned against the oracle. */
+int ginsim_box_muller(ginsim_ctx* ctx, const uint32_t* host_words /*[count][4]*/, int64_t count, double* host_z0,
+                      double* host_z1);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,8 +32,8 @@ def test_rng_words_bit_exact_and_normals(ctx):
     import ginsim
     from oracle import philox
     for seed, run, stream in ((0, 0, 0), (20260923, 3, 5), (2 ** 63 + 12345, 2 ** 40 + 7, 18)):
-        z0, z1, w = ginsim.rng_normals(ctx, seed, run, stream, 4096, words=True)
-        j = np.arange(4096, dtype=np.uint64)
+        z0, z1, w = ginsim.rng_normals(ctx, seed, run, stream, 65536, words=True)     # every table bin many times over
+        j = np.arange(65536, dtype=np.uint64)
         ref = philox.philox4x32_10(j, np.uint64(stream), np.uint64(run & 0xFFFFFFFF), np.uint64(run >> 32),
                                    seed & 0xFFFFFFFF, seed >> 32)
         for k in range(4):
@@ -41,6 +41,43 @@ def test_rng_words_bit_exact_and_normals(ctx):
         r0, r1 = philox.normal_pair(seed, run, stream, j)
         np.testing.assert_allclose(z0, r0, rtol=0, atol=2e-14)
         np.testing.assert_allclose(z1, r1, rtol=0, atol=2e-14)
+
+
+def test_box_muller_corner_cases(ctx):
+    """Words no seed will produce in a test: u = 1 (rounds up from 1 - 2^-54), the smallest u, mantissas on the
+    edges of the log table's bins (around 1 and around sqrt(1/2) / sqrt(2)), angles on sector edges of the sin/cos
+    table, plus a dense random sample -- all against NumPy's log / sqrt / cos / sin on the same uniforms."""
+    import ginsim
+    from oracle import philox
+    rng = np.random.default_rng(7)
+    rows = []
+    full, zero = 0xFFFFFFFF, 0
+    rows += [(full, full, zero, zero), (zero, zero, full, full), (zero, zero, zero, zero), (full, full, full, full)]
+    # radius uniforms around u = 1/2, 1/4 (exponent change), around m = sqrt(2) and around every bin edge of the log table
+    for hi in (0x7FFFFFFF, 0x80000000, 0x3FFFFFFF, 0x40000000, 0xB504F333, 0xB504F334, 0x5A827999, 0x5A82799A):
+        for lo in (zero, full, 0x12345678):
+            rows.append((lo, hi, 0x9E3779B9, 0x3C6EF372))
+    for k in range(0, 2048, 7):                       # mantissa bins: top 11 bits of hi sweep, lo at both ends
+        rows.append((zero, (k << 21) | 0x100000, 1, 2))
+        rows.append((full, (k << 21) | 0x0FFFFF, 3, 4))
+    for i in range(256):                              # sector edges of the angle: A = i 2^45 - 1 and i 2^45
+        rows.append((0xDEADBEEF, 0x6789ABCD, zero, (i << 24)))
+        rows.append((0xDEADBEEF, 0x6789ABCD, full, ((i << 24) - 1) & full))
+    w = np.array(rows, dtype=np.uint64)
+    w = np.vstack([w, rng.integers(0, 2 ** 32, size=(200000, 4), dtype=np.uint64)])
+    z0, z1 = ginsim.box_muller(ctx, w.astype(np.uint32))
+    u1 = philox.uniform53(w[:, 0], w[:, 1])
+    u2 = philox.uniform53(w[:, 2], w[:, 3])
+    assert u1.max() == 1.0 and u1.min() == 2.0 ** -54
+    r = np.sqrt(-2.0 * np.log(u1))
+    a = (2.0 * np.pi) * u2
+    assert np.isfinite(z0).all() and np.isfinite(z1).all()
+    # the oracle's own angle 2 pi u2 carries up to 4.4e-16 rad of rounding -> allow r * 1e-15 on top of 2e-14
+    np.testing.assert_array_less(np.abs(z0 - r * np.cos(a)), 2e-14 + 1e-15 * r)
+    np.testing.assert_array_less(np.abs(z1 - r * np.sin(a)), 2e-14 + 1e-15 * r)
+    # radius to a few ulp RELATIVE, also for small radii (u -> 1), and no distortion of the direction
+    keep = r > 1e-6
+    np.testing.assert_allclose(np.hypot(z0[keep], z1[keep]) / r[keep], 1.0, rtol=0, atol=2e-15)
 
 
 @pytest.mark.parametrize('name', ['bosch', 'nxp'])
