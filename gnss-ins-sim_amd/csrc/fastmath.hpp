@@ -32,7 +32,7 @@ struct MathConsts {
     double ln2_hi, ln2_lo;
     double sc[5];           // sin: -1/3!, 1/5!, -1/7!, 1/9!, -1/11!   (Box-Muller uses 3, rotate_sincos 5)
     double cc[6];           // cos: -1/2!, 1/4!, ... 1/12!             (Box-Muller uses 3, rotate_sincos 6)
-    double ang_bias, ang_scale;     // 0.5 - 2^44 and 2 pi 2^-53: centred remainder of the 53-bit angle -> radians
+    double ang_bias, ang_scale;     // 0.5 - 2^23 and 2 pi 2^-32: centred remainder of the 32-bit angle -> radians
     // OPAQUE = true pins the 21 constants in VGPRs (42 registers); false leaves them to the compiler (SGPR literals),
     // which is what the two-algorithm kernels need to stay under 256 VGPRs without scratch spills.
     template <bool OPAQUE>
@@ -49,8 +49,8 @@ struct MathConsts {
         for (int k = 0; k < 5; ++k) sc[k] = vconst(s[k]);
 #pragma unroll
         for (int k = 0; k < 6; ++k) cc[k] = vconst(c[k]);
-        ang_bias = vconst(0.5 - 17592186044416.0);
-        ang_scale = vconst(6.283185307179586476925 * 0x1.0p-53);
+        ang_bias = vconst(0.5 - 8388608.0);
+        ang_scale = vconst(6.283185307179586476925 * 0x1.0p-32);
     }
 };
 
@@ -145,14 +145,11 @@ GINSIM_FM double log_u01(double u, const MathConsts& k, const NormalTables& tab)
     return __builtin_fma(ed, k.ln2_hi, t.y) + small;
 }
 
-// sin and cos of the Box-Muller angle 2 pi (A + 1/2) 2^-53, A the 53-bit integer (hi:lo) >> 11 of two Philox words:
-// sector i = top 8 bits of A, b = centred remainder in radians (|b| <= pi/256), angle = a_i + b.
-GINSIM_FM void sincos_turn53(uint32_t lo, uint32_t hi, double& s, double& c, const MathConsts& k, const NormalTables& tab) {
-    const double2 t = tab.sc[hi >> 24];
-    const uint32_t mid = (hi >> 11) & 0x1fffu;                // bits 44..32 of A
-    const uint32_t low = (hi << 21) | (lo >> 11);             // bits 31..0 (one v_alignbit_b32)
-    const double rho = __builtin_fma((double)mid, 4294967296.0, (double)low);      // A mod 2^45, exact
-    const double b = (rho + k.ang_bias) * k.ang_scale;        // the sum is exact (< 2^44, 46 significant bits)
+// sin and cos of the Box-Muller angle 2 pi (w + 1/2) 2^-32, w one Philox word: sector i = top 8 bits of w,
+// b = centred remainder in radians (|b| <= pi/256), angle = a_i + b.
+GINSIM_FM void sincos_turn32(uint32_t w, double& s, double& c, const MathConsts& k, const NormalTables& tab) {
+    const double2 t = tab.sc[w >> 24];
+    const double b = ((double)(w & 0xffffffu) + k.ang_bias) * k.ang_scale;     // the sum is exact
     const double tt = b * b;
     double ps = __builtin_fma(tt, k.sc[2], k.sc[1]);
     ps = __builtin_fma(tt, ps, k.sc[0]);

@@ -292,46 +292,37 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
 // ---------------------------------------------------------------------------------------------------
 // Wave-specialised variant for SMALL batches (<= 1024 wavefronts of runs, i.e. one wavefront per SIMD with the kernel
 // above -- BASELINE config 2).  A lone wavefront cannot hide its own dependent-instruction and s_waitcnt latencies
-// (76 % VALU-active at 65 536 runs against ~100 % with two resident wavefronts at 262 144 runs), and there are no
-// more runs to give the SIMD a second wavefront.  So the work of one step is split across TWO wavefronts per 64 runs:
+// and there are no more runs to give the SIMD a second wavefront.  So the work of one step is split across TWO
+// wavefronts per 64 runs, at the point where the normal generator changes character:
 //
-//   waves 4-7 of a 512-thread workgroup (producers): Philox + Box-Muller for streams 0..3 of tile i (8 of the 12
-//                                                    normals of a step) -> LDS ring  z[2][T][8][256]
-//   waves 0-3 (consumers)                          : read tile i-1 from LDS, generate streams 4..5 themselves (the
-//                                                    other 4 normals), sensor sums, mechanisation, all stores
+//   waves 4-7 of a 512-thread workgroup (producers): the four Philox blocks of a step and the RADIUS half of the six
+//                                                    Box-Muller transforms (uniform, log, sqrt) -> LDS ring, per step
+//                                                    and run 6 doubles r and 6 angle words  (72 B)
+//   waves 0-3 (consumers)                          : read tile i-1 from LDS, the DIRECTION half (sin/cos of the angle
+//                                                    words), sensor sums, mechanisation, all stores
 //
-// ~560 VALU instructions per step on either side; one __syncthreads() per tile of T = 4 steps; the instruction total
+// ~400 VALU instructions per step on either side; one __syncthreads() per tile of T = 4 steps; the instruction total
 // is unchanged, the SIMD just always has a second wavefront to issue from.  Results are bit-identical to mc_kernel
-// (same normals, same arithmetic order on the consumer side).  Measured at 65 536 runs: 2.70 -> 2.52 ms
-// materialised, 2.36 -> 2.09 ms stats-only; at 262 144 runs it is 3 % slower than the plain kernel, hence the policy.
-// (Moving the whole accelerometer to the producer -- 5 LDS slots instead of 8 -- measured no better.)
+// (same functions in the same order on the same values).
 constexpr int kSplitRuns = 256;
-// NP producer groups per workgroup of 256*(NP+1) threads.  NP = 1: streams 0..3 produced, 4..5 by the consumer, tile
-// of 4 steps (128 KiB ring).  NP = 2: streams 0..2 and 3..5 produced by two groups, the consumer generates nothing,
-// tile of 3 steps (144 KiB ring).  Either way the ring allows exactly one workgroup per CU.  Only NP = 1 is
-// instantiated: NP = 2 (three wavefronts per SIMD) measured the same 2.40 ms at 65 536 runs -- with two wavefronts the
-// SIMD is already issue-bound -- and 10 % slower for ref_frame 0.  TILE = 2 (64 KiB ring, two workgroups per CU) for
-// batches above 1024 wavefronts measured 5 % slower than mc_kernel (7.43 against 7.06 ms at 262 144 runs).
-constexpr int split_pairs(int np) { return np == 1 ? 4 : 3; }          // Philox blocks (normal pairs) per producer and step
-constexpr int split_slots(int np) { return 2 * np * split_pairs(np); }
-constexpr size_t split_lds(int np, int tile) { return sizeof(double) * 2 * tile * split_slots(np) * kSplitRuns; }
+constexpr int kSplitTile = 4;
+constexpr int kSplitStep = 6 * 8 + 6 * 4;               // bytes per step and run in the ring
+constexpr size_t kSplitLds = (size_t)2 * kSplitTile * kSplitStep * kSplitRuns;         // 144 KiB -> one workgroup per CU
 
-template <int RF, int ALGOS, int NP, int TILE>
-__global__ void __launch_bounds__(256 * (NP + 1)) mc_kernel_split(const ginsim_mc_params a) {
-    extern __shared__ double zring[];
+template <int RF, int ALGOS>
+__global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a) {
+    extern __shared__ double zring[];                   // [2 stages][T steps]{ r[6][256] doubles, ang[6][256] words }
     constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
     constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
-    constexpr int PP = split_pairs(NP), SLOTS = split_slots(NP);
-    constexpr int OWN = 6 - NP * PP;                  // pairs left to the consumer
-    constexpr int kStage = TILE * SLOTS * kSplitRuns;
+    constexpr int kStepDoubles = kSplitStep * kSplitRuns / 8;          // 2304 doubles per step
     const int lane = threadIdx.x & (kSplitRuns - 1);
-    const int role = threadIdx.x / kSplitRuns;        // 0 consumer, 1..NP producers
+    const bool producer = threadIdx.x >= kSplitRuns;
     const int64_t r = (int64_t)blockIdx.x * kSplitRuns + lane;
     const bool active = r < a.runs;
     const int64_t n = a.n, runs = a.runs, plane = n * runs;
     const bool keep_last = a.out_accel || a.out_gyro || a.out_odo;      // the last sample only exists as sensor output
     const int64_t n_noise = keep_last ? n : n - 1;
-    const int64_t ntiles = (n_noise + TILE - 1) / TILE;
+    const int64_t ntiles = (n_noise + kSplitTile - 1) / kSplitTile;
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     MathConsts mk;
@@ -341,21 +332,28 @@ __global__ void __launch_bounds__(256 * (NP + 1)) mc_kernel_split(const ginsim_m
     __syncthreads();
     const NormalTables tab{ntab, ntab + kLogBins};
 
-    if (role != 0) {
-        const uint32_t first = (uint32_t)((role - 1) * PP);
+    if (producer) {
         for (int64_t i = 0; i <= ntiles; ++i) {
             if (i < ntiles && active) {
-                double* zb = zring + (i & 1) * kStage + 2 * first * kSplitRuns + lane;
+                double* stage = zring + (i & 1) * (kSplitTile * kStepDoubles);
 #pragma unroll
-                for (int t = 0; t < TILE; ++t) {
-                    const int64_t j = i * TILE + t;
+                for (int t = 0; t < kSplitTile; ++t) {
+                    const int64_t j = i * kSplitTile + t;
                     if (j < n_noise) {
-                        double z0[PP], z1[PP];
-                        normal_pairs<PP>(key, first, (uint32_t)j, z0, z1, mk, tab);
+                        double u[6];
+                        uint32_t ang[6];
+                        draw_group(key, 0, (uint32_t)j, u, ang);
+                        draw_group(key, 1, (uint32_t)j, u + 3, ang + 3);
 #pragma unroll
-                        for (int k = 0; k < PP; ++k) {
-                            zb[(t * SLOTS + 2 * k) * kSplitRuns] = z0[k];
-                            zb[(t * SLOTS + 2 * k + 1) * kSplitRuns] = z1[k];
+                        for (int k = 0; k < 6; ++k) u[k] = -2.0 * log_u01(u[k], mk, tab);
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) u[k] = sqrt_pos(u[k]);
+                        double* rb = stage + t * kStepDoubles + lane;
+                        uint32_t* ab = reinterpret_cast<uint32_t*>(stage + t * kStepDoubles + 6 * kSplitRuns) + lane;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            rb[k * kSplitRuns] = u[k];
+                            ab[k * kSplitRuns] = ang[k];
                         }
                     }
                 }
@@ -378,25 +376,24 @@ __global__ void __launch_bounds__(256 * (NP + 1)) mc_kernel_split(const ginsim_m
     }
     for (int64_t i = 0; i <= ntiles; ++i) {
         if (i >= 1 && active) {
-            const double* zb = zring + ((i - 1) & 1) * kStage + lane;
+            const double* stage = zring + ((i - 1) & 1) * (kSplitTile * kStepDoubles);
 #pragma unroll 1
-            for (int t = 0; t < TILE; ++t) {
-                const int64_t j = (i - 1) * TILE + t;
+            for (int t = 0; t < kSplitTile; ++t) {
+                const int64_t j = (i - 1) * kSplitTile + t;
                 if (j >= n_noise) break;
                 const int64_t off = j * runs + r;
                 const bool last = (j == n - 1);
                 const Vec3 cur_a = load3(as_uniform(a.ref_accel), j), cur_g = load3(as_uniform(a.ref_gyro), j);
+                const double* rb = stage + t * kStepDoubles + lane;
+                const uint32_t* ab = reinterpret_cast<const uint32_t*>(stage + t * kStepDoubles + 6 * kSplitRuns) + lane;
                 double p0[6], p1[6];                  // z0 / z1 of streams 0..5
 #pragma unroll
-                for (int k = 0; k < NP * PP; ++k) {
-                    p0[k] = zb[(t * SLOTS + 2 * k) * kSplitRuns];
-                    p1[k] = zb[(t * SLOTS + 2 * k + 1) * kSplitRuns];
-                }
-                if constexpr (OWN > 0) {
-                    double y0[OWN], y1[OWN];
-                    normal_pairs<OWN>(key, (uint32_t)(NP * PP), (uint32_t)j, y0, y1, mk, tab);
-#pragma unroll
-                    for (int k = 0; k < OWN; ++k) { p0[NP * PP + k] = y0[k]; p1[NP * PP + k] = y1[k]; }
+                for (int k = 0; k < 6; ++k) {
+                    const double rad = rb[k * kSplitRuns];
+                    double sn, cs;
+                    sincos_turn32(ab[k * kSplitRuns], sn, cs, mk, tab);
+                    p0[k] = rad * cs;
+                    p1[k] = rad * sn;
                 }
                 const params_ptr kp = kernarg_params();
                 const Vec3 acc = sense3(cur_a, &kp->accel, da, Vec3{p0[0], p1[0], p0[1]}, Vec3{p1[1], p0[2], p1[2]});
@@ -463,12 +460,12 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
         const dim3 sgrid((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns));
         if (v == 1) {
             static bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, 1, 4>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds(1, 4));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
                 return true;
             }();
             (void)once;
-            hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, 1, 4>), sgrid, dim3(512), split_lds(1, 4), stream, p);
+            hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS>), sgrid, dim3(512), kSplitLds, stream, p);
             return hipGetLastError();
         }
     }
@@ -531,9 +528,9 @@ __global__ void __launch_bounds__(256) aux_mag_kernel(const ginsim_aux_params a)
     const int64_t r = idx % a.runs, j = idx / a.runs;
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
-    double z0[2], z1[2];
-    normal_pairs<2>(key, S_MAG_XY, (uint32_t)j, z0, z1, mk, tab);
-    const double z[3] = {z0[0], z1[0], z0[1]};
+    double z0[3], z1[3];
+    normal_pairs<3>(key, S_ODO, (uint32_t)j, z0, z1, mk, tab);          // group 2: odometer, mag xy, mag z
+    const double z[3] = {z0[1], z1[1], z0[2]};
     const double v[3] = {a.ref_mag[3 * j] + a.mag_hi[0], a.ref_mag[3 * j + 1] + a.mag_hi[1], a.ref_mag[3 * j + 2] + a.mag_hi[2]};
     const int64_t plane = a.n * a.runs;
 #pragma unroll
@@ -601,7 +598,7 @@ __global__ void gather_runs_kernel(const double* __restrict__ series, int C, int
     out[idx] = series[((int64_t)c * n + j) * runs + ids[k]];
 }
 
-// Box-Muller on given words (test hook): same functions, same phase order as normal_pairs<1>.
+// Box-Muller on given words (test hook): radius uniform from words 0-1, angle from word 2 (word 3 unused).
 __global__ void box_muller_kernel(const uint32_t* __restrict__ words, int64_t count, double* __restrict__ z0, double* __restrict__ z1) {
     __shared__ double2 ntab[kLogBins + kAngBins];
     fill_normal_tables(ntab, threadIdx.x, blockDim.x);
@@ -611,11 +608,11 @@ __global__ void box_muller_kernel(const uint32_t* __restrict__ words, int64_t co
     mk.init<true>();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const double r = sqrt_pos(-2.0 * log_u01(uniform53(words[4 * i], words[4 * i + 1]), mk, tab));
-    double s, c;
-    sincos_turn53(words[4 * i + 2], words[4 * i + 3], s, c, mk, tab);
-    z0[i] = r * c;
-    z1[i] = r * s;
+    double r[1] = {uniform53(words[4 * i], words[4 * i + 1])}, a[1], b[1];
+    const uint32_t ang[1] = {words[4 * i + 2]};
+    box_muller<1>(r, ang, a, b, mk, tab);
+    z0[i] = a[0];
+    z1[i] = b[0];
 }
 
 hipError_t launch_box_muller(const uint32_t* words, int64_t count, double* z0, double* z1, hipStream_t s) {

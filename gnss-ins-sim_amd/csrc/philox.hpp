@@ -1,6 +1,8 @@
 // Counter-based normal generator of the MC engine (device side).
 //
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11; Random123 constants) + Box-Muller in fp64.
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11; Random123 constants) + Box-Muller in fp64.  A pair of normals
+// takes a 53-bit radius uniform and a 32-bit angle uniform; three pairs (streams 3g, 3g+1, 3g+2) are cut from the 256
+// bits of the two blocks (j, 2g) and (j, 2g+1) -- the cut is spelled out in oracle/philox.py.
 // It replaces the reference's serial global np.random.randn stream
 // (gnss_ins_sim/pathgen/pathgen.py:495,557,588,593,621-622,639,660): every (run, stream, sample)
 // triple owns its variates, so lanes never share RNG state and only variates that are consumed are
@@ -16,7 +18,7 @@ enum : uint32_t {
     S_ACC_D_XY = 0, S_ACC_DZ_WX = 1, S_ACC_W_YZ = 2,
     S_GYR_D_XY = 3, S_GYR_DZ_WX = 4, S_GYR_W_YZ = 5,
     S_ODO = 6, S_MAG_XY = 7, S_MAG_Z = 8,
-    S_GPS_P_XY = 16, S_GPS_PZ_VX = 17, S_GPS_V_YZ = 18,
+    S_GPS_P_XY = 15, S_GPS_PZ_VX = 16, S_GPS_V_YZ = 17,
 };
 
 struct u32x4 { uint32_t x, y, z, w; };
@@ -57,24 +59,24 @@ struct RngKey {
     uint32_t r0, r1;    // global run id
 };
 
-// N consecutive streams (first, first+1, ...) of one sample -> N pairs of standard normals
-//   z0 = sqrt(-2 ln u1) cos(2 pi u2),  z1 = sqrt(-2 ln u1) sin(2 pi u2),  u1 = uniform53(w.x, w.y), u2 = uniform53(w.z, w.w)
-// evaluated phase by phase -- all Philox blocks, then all logarithms, then all square roots, then all sin/cos --
-// instead of N complete Box-Muller transforms in a row.  Each phase is N independent dependency chains (ILP for a
-// lone wavefront on its SIMD) and only ONE polynomial's constants are live at a time.  The angle never becomes a
-// uniform: sincos_turn53 works on the integer.
+// The three streams of group g at sample j: radius uniforms u[3] and angle words ang[3] from two Philox blocks.
+__device__ __forceinline__ void draw_group(const RngKey& key, uint32_t g, uint32_t j, double* u, uint32_t* ang) {
+    const u32x4 A = philox4x32_10(j, 2 * g, key.r0, key.r1, key.k0, key.k1);
+    const u32x4 B = philox4x32_10(j, 2 * g + 1, key.r0, key.r1, key.k0, key.k1);
+    u[0] = uniform53(A.x, A.y);
+    ang[0] = A.z;
+    u[1] = uniform53(A.w, B.x);
+    ang[1] = B.y;
+    u[2] = uniform53(((A.x & 0x7ffu) << 21) | ((A.w & 0x7ffu) << 10), B.z);     // the spare low bits of A.x and A.w
+    ang[2] = B.w;
+}
+
+// Box-Muller on N (radius uniform, angle word) draws, phase by phase -- all logarithms, then all square roots, then
+// all sin/cos -- instead of N complete transforms in a row: each phase is N independent dependency chains (ILP for
+// a lone wavefront on its SIMD) and only ONE polynomial's constants are live at a time.
 template <int N>
-__device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, uint32_t j, double (&z0)[N], double (&z1)[N],
-                                             const MathConsts& mk, const NormalTables& tab) {
-    double r[N];
-    uint32_t a_lo[N], a_hi[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const u32x4 w = philox4x32_10(j, first + k, key.r0, key.r1, key.k0, key.k1);
-        r[k] = uniform53(w.x, w.y);
-        a_lo[k] = w.z;
-        a_hi[k] = w.w;
-    }
+__device__ __forceinline__ void box_muller(double (&r)[N], const uint32_t (&ang)[N], double (&z0)[N], double (&z1)[N],
+                                           const MathConsts& mk, const NormalTables& tab) {
 #pragma unroll
     for (int k = 0; k < N; ++k) r[k] = -2.0 * log_u01(r[k], mk, tab);
 #pragma unroll
@@ -82,17 +84,42 @@ __device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, 
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         double s, c;
-        sincos_turn53(a_lo[k], a_hi[k], s, c, mk, tab);
+        sincos_turn32(ang[k], s, c, mk, tab);
         z0[k] = r[k] * c;
         z1[k] = r[k] * s;
     }
 }
 
-// Two standard normals for (key.run, stream, sample j).
+// N consecutive streams first .. first+N-1 of one sample (whole groups: first and N multiples of 3) -> N normal pairs
+template <int N>
+__device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, uint32_t j, double (&z0)[N], double (&z1)[N],
+                                             const MathConsts& mk, const NormalTables& tab) {
+    static_assert(N % 3 == 0, "streams come in groups of three");
+    double r[N];
+    uint32_t ang[N];
+#pragma unroll
+    for (int g = 0; g < N / 3; ++g) draw_group(key, first / 3 + g, j, r + 3 * g, ang + 3 * g);
+    box_muller<N>(r, ang, z0, z1, mk, tab);
+}
+
+// Two standard normals of one stream.  Slot 0 of a group needs the first block only.
 __device__ __forceinline__ void normal_pair(const RngKey& key, uint32_t stream, uint32_t j, double& z0, double& z1,
                                             const MathConsts& mk, const NormalTables& tab) {
-    double a[1], b[1];
-    normal_pairs<1>(key, stream, j, a, b, mk, tab);
+    const uint32_t g = stream / 3, slot = stream - 3 * g;
+    double r[1], a[1], b[1];
+    uint32_t ang[1];
+    if (slot == 0) {
+        const u32x4 A = philox4x32_10(j, 2 * g, key.r0, key.r1, key.k0, key.k1);
+        r[0] = uniform53(A.x, A.y);
+        ang[0] = A.z;
+    } else {
+        double u[3];
+        uint32_t w[3];
+        draw_group(key, g, j, u, w);
+        r[0] = slot == 1 ? u[1] : u[2];
+        ang[0] = slot == 1 ? w[1] : w[2];
+    }
+    box_muller<1>(r, ang, a, b, mk, tab);
     z0 = a[0];
     z1 = b[0];
 }

@@ -349,7 +349,7 @@ class MonteCarloJob(object):
         if p.precision == 1:
             return 'ginsim::f32::mc_kernel_f32%s<%d, %d>' % ('_split' if v.value else '', p.ref_frame, p.algo_mask)
         if v.value:
-            return 'ginsim::mc_kernel_split<%d, %d, 1, 4>' % (p.ref_frame, p.algo_mask)
+            return 'ginsim::mc_kernel_split<%d, %d>' % (p.ref_frame, p.algo_mask)
         return 'ginsim::mc_kernel<%d, %d, %s>' % (p.ref_frame, p.algo_mask, 'true' if p.given_sensors else 'false')
 
     def run(self):

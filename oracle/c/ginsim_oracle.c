@@ -54,10 +54,18 @@ static double uniform53(uint32_t lo, uint32_t hi) {
     return ((double)v + 0.5) * 0x1.0p-53;
 }
 
+/* stream = 3 g + slot: three streams are cut from the two Philox blocks (j, 2g) and (j, 2g+1) -- oracle/philox.py */
 static void normal_pair(uint64_t seed, uint64_t run, uint32_t stream, uint32_t j, double* z0, double* z1) {
-    uint32_t c[4] = {j, stream, (uint32_t)run, (uint32_t)(run >> 32)};
-    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    double u1 = uniform53(c[0], c[1]), u2 = uniform53(c[2], c[3]);
+    const uint32_t g = stream / 3, slot = stream % 3;
+    uint32_t A[4] = {j, 2 * g, (uint32_t)run, (uint32_t)(run >> 32)};
+    uint32_t B[4] = {j, 2 * g + 1, (uint32_t)run, (uint32_t)(run >> 32)};
+    philox4x32_10(A, (uint32_t)seed, (uint32_t)(seed >> 32));
+    if (slot != 0) philox4x32_10(B, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t lo, hi, aw;
+    if (slot == 0) { lo = A[0]; hi = A[1]; aw = A[2]; }
+    else if (slot == 1) { lo = A[3]; hi = B[0]; aw = B[1]; }
+    else { lo = ((A[0] & 0x7ffu) << 21) | ((A[3] & 0x7ffu) << 10); hi = B[2]; aw = B[3]; }
+    const double u1 = uniform53(lo, hi), u2 = ((double)aw + 0.5) * 0x1.0p-32;
     double r = sqrt(-2.0 * log(u1)), a = (2.0 * PI) * u2;
     *z0 = r * cos(a);
     *z1 = r * sin(a);

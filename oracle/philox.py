@@ -10,20 +10,26 @@ unmodified reference is fed THESE normals through a ``np.random.randn`` shim
 (``oracle/ref_shim.py``).
 
 Stream definition (shared by this file, ``oracle/c/ginsim_oracle.c`` and
-``gnss-ins-sim_amd/csrc/philox.hpp``):
+``gnss-ins-sim_amd/csrc/philox.hpp``).  A normal pair needs a 53-bit uniform for the radius (tails to 8.5 sigma,
+as NumPy's doubles) and a 32-bit uniform for the angle: 85 bits, so THREE pairs ("streams" 3g, 3g+1, 3g+2 of
+group g) are cut from the 256 bits of TWO Philox blocks:
 
     key     = (seed & 0xffffffff, seed >> 32)
-    counter = (j, stream, run & 0xffffffff, run >> 32)      j = sample index
-    w0..w3  = philox4x32_10(counter, key)
-    u1 = (((w1<<32 | w0) >> 11) + 0.5) * 2**-53 ;  u2 likewise from (w2, w3)
+    A       = philox4x32_10((j, 2g,   run & 0xffffffff, run >> 32), key)      j = sample index
+    B       = philox4x32_10((j, 2g+1, run & 0xffffffff, run >> 32), key)
+    slot 0:  radius words (lo, hi) = (A0, A1)                                        angle word A2
+    slot 1:  radius words (lo, hi) = (A3, B0)                                        angle word B1
+    slot 2:  radius words (lo, hi) = ((A0 & 0x7ff) << 21 | (A3 & 0x7ff) << 10, B2)   angle word B3
+             (a radius uses all of hi and the top 21 bits of lo: the low 11 bits of A0 and A3 are the spare ones)
+    u1 = (((hi<<32 | lo) >> 11) + 0.5) * 2**-53 ;  u2 = (angle word + 0.5) * 2**-32
     r  = sqrt(-2 ln u1) ;  z0 = r cos(2 pi u2) ;  z1 = r sin(2 pi u2)
 
-Stream ids (one Philox call -> two normals (z0, z1)):
+Stream ids (one stream -> two normals (z0, z1)):
 
-    0: accel drift x, y     1: accel drift z, accel white x    2: accel white y, z
-    3: gyro  drift x, y     4: gyro  drift z, gyro  white x    5: gyro  white y, z
-    6: odometer, -          7: mag x, y                        8: mag z, -
-    16: gps pos x, y       17: gps pos z, vel x               18: gps vel y, z   (j = GPS sample index)
+    0: accel drift x, y     1: accel drift z, accel white x    2: accel white y, z        (group 0)
+    3: gyro  drift x, y     4: gyro  drift z, gyro  white x    5: gyro  white y, z        (group 1)
+    6: odometer, -          7: mag x, y                        8: mag z, -                (group 2)
+    15: gps pos x, y       16: gps pos z, vel x               17: gps vel y, z            (group 5; j = GPS sample index)
 """
 import numpy as np
 
@@ -37,7 +43,7 @@ MASK32 = np.uint64(0xFFFFFFFF)
 S_ACC_D_XY, S_ACC_DZ_WX, S_ACC_W_YZ = 0, 1, 2
 S_GYR_D_XY, S_GYR_DZ_WX, S_GYR_W_YZ = 3, 4, 5
 S_ODO, S_MAG_XY, S_MAG_Z = 6, 7, 8
-S_GPS_P_XY, S_GPS_PZ_VX, S_GPS_V_YZ = 16, 17, 18
+S_GPS_P_XY, S_GPS_PZ_VX, S_GPS_V_YZ = 15, 16, 17
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -71,15 +77,29 @@ def uniform53(lo, hi):
     return (v.astype(np.float64) + 0.5) * (2.0 ** -53)
 
 
-def normal_pair(seed, run, stream, j):
-    """Two standard normals (z0, z1) for (run, stream, sample j); arrays broadcast."""
+def stream_words(seed, run, stream, j):
+    """(lo, hi, angle) words of one stream: the radius uniform is uniform53(lo, hi), the angle uniform is
+    (angle + 0.5) 2^-32.  See the module docstring for the cut of two Philox blocks into three streams."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     run = np.asarray(run, dtype=np.uint64)
-    w0, w1, w2, w3 = philox4x32_10(np.asarray(j, dtype=np.uint64), np.uint64(stream),
-                                   run & MASK32, run >> np.uint64(32),
-                                   seed & 0xFFFFFFFF, seed >> 32)
-    u1 = uniform53(w0, w1)
-    u2 = uniform53(w2, w3)
+    g, slot = divmod(int(stream), 3)
+    jj = np.asarray(j, dtype=np.uint64)
+    k0, k1 = seed & 0xFFFFFFFF, seed >> 32
+    A = philox4x32_10(jj, np.uint64(2 * g), run & MASK32, run >> np.uint64(32), k0, k1)
+    if slot == 0:
+        return A[0], A[1], A[2]
+    B = philox4x32_10(jj, np.uint64(2 * g + 1), run & MASK32, run >> np.uint64(32), k0, k1)
+    if slot == 1:
+        return A[3], B[0], B[1]
+    lo = ((A[0] & np.uint64(0x7FF)) << np.uint64(21)) | ((A[3] & np.uint64(0x7FF)) << np.uint64(10))
+    return lo, B[2], B[3]
+
+
+def normal_pair(seed, run, stream, j):
+    """Two standard normals (z0, z1) for (run, stream, sample j); arrays broadcast."""
+    lo, hi, aw = stream_words(seed, run, stream, j)
+    u1 = uniform53(lo, hi)
+    u2 = (aw.astype(np.float64) + 0.5) * (2.0 ** -32)
     r = np.sqrt(-2.0 * np.log(u1))
     a = (2.0 * np.pi) * u2
     return r * np.cos(a), r * np.sin(a)
