@@ -43,7 +43,7 @@ int stats_blocks(int64_t runs);
 hipError_t launch_end_stats(const double* end_err, int64_t runs, void* scratch, hipStream_t s);
 void stats_merge_host(const ginsim_stats* parts, int nparts, ginsim_stats* out);
 hipError_t launch_process_stats(const double* traj, const double* ref, int64_t n, int64_t runs, int64_t j0, int pos_ned,
-                                double* out, hipStream_t s);
+                                int run_major, double* out, hipStream_t s);
 
 
 }  // namespace ginsim
@@ -359,12 +359,9 @@ int ginsim_process_stats(ginsim_ctx* c, const double* traj, const double* ref, i
     void* ws = nullptr;
     const size_t bytes = sizeof(double) * 27 * (size_t)runs;
     HIP_TRY(scratch(c, 2, bytes, &ws));
-    HIP_TRY(launch_process_stats(traj, ref, n, runs, first_sample, pos_ned, reinterpret_cast<double*>(ws), c->stream));
-    std::vector<double> tmp((size_t)27 * runs);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), ws, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(launch_process_stats(traj, ref, n, runs, first_sample, pos_ned, 1, reinterpret_cast<double*>(ws), c->stream));
+    HIP_TRY(hipMemcpyAsync(host_out, ws, bytes, hipMemcpyDeviceToHost, c->stream));      // already [runs][3][9]
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int64_t r = 0; r < runs; ++r)          // [3][9][runs] -> [runs][3][9]
-        for (int k = 0; k < 27; ++k) host_out[r * 27 + k] = tmp[(size_t)k * runs + r];
     return GINSIM_OK;
 }
 
@@ -375,7 +372,7 @@ int ginsim_end_stats_from_traj(ginsim_ctx* c, const double* traj, const double* 
     void* ws = nullptr;
     HIP_TRY(scratch(c, 2, sizeof(double) * 27 * (size_t)runs, &ws));
     // a one-sample window: the "mean" plane [9][runs] of the process kernel IS the end-point error
-    HIP_TRY(launch_process_stats(traj, ref, n, runs, n - 1, pos_ned, reinterpret_cast<double*>(ws), c->stream));
+    HIP_TRY(launch_process_stats(traj, ref, n, runs, n - 1, pos_ned, 0, reinterpret_cast<double*>(ws), c->stream));
     return ginsim_end_stats(c, reinterpret_cast<double*>(ws) + (size_t)9 * runs, runs, host_out);
 }
 

@@ -6,6 +6,7 @@
 // (count, mean, M2, max) partials are mergeable, so per-device results combine exactly across GPUs.
 #include <hip/hip_runtime.h>
 #include "ginsim.h"
+#include "fastmath.hpp"
 #include "ins_math.hpp"
 
 namespace ginsim {
@@ -74,60 +75,93 @@ __global__ void stats_final_kernel(const Mom* __restrict__ partial, int blocks, 
     }
 }
 
-// Process-error statistics: one lane per run walks the time axis of its trajectory (coalesced across lanes, the
-// truth row is wave-uniform -> scalar loads) with a Welford accumulator per component.  HBM-bound: 72 B per
-// sample*run read once.  out [3][9][runs] = max|e|, mean, M2/n -> std on the host side of the ABI.
+// Process-error statistics: the time axis of 64 runs is cut into kSeg segments, one wavefront each (coalesced across
+// lanes, the truth row is wave-uniform -> scalar loads), a Welford accumulator per component; the segment records
+// are Chan-merged in a fixed order through LDS.  HBM-bound: 72 B per sample*run read once; four wavefronts per SIMD
+// at 65 536 runs hide the load latency a lone wavefront per run group would wait out every step.
+// out = max|e|, mean, std (ddof = 0) as [runs][3][9] (run_major, what the host API returns) or [3][9][runs].
 typedef const double __attribute__((address_space(4))) * uniform_ref;
+constexpr int kSeg = 4;
 
-__global__ void __launch_bounds__(256) process_stats_kernel(const double* __restrict__ traj, const double* __restrict__ ref,
-                                                            int64_t n, int64_t runs, int64_t j0, int pos_ned,
-                                                            double* __restrict__ out) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= runs) return;
+// attitude.angle_range_pi with the division by 2 pi replaced by a multiplication (same result: the two range
+// fix-ups after the floor absorb a quotient that lands one ulp on the other side of an integer)
+__device__ __forceinline__ double angle_range_pi_mul(double x) {
+    double m = x - kTwoPi * floor(x * (1.0 / kTwoPi));
+    if (m >= kTwoPi) m -= kTwoPi;
+    if (m < 0.0) m += kTwoPi;
+    return m > kPi ? m - kTwoPi : m;
+}
+
+__global__ void __launch_bounds__(64 * kSeg) process_stats_kernel(const double* __restrict__ traj, const double* __restrict__ ref,
+                                                                 int64_t n, int64_t runs, int64_t j0, int pos_ned,
+                                                                 int run_major, double* __restrict__ out) {
+    __shared__ Mom part[kSeg][9][64];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+    const bool active = r < runs;
     const int64_t plane = n * runs;
     const uniform_ref truth = (uniform_ref)(uintptr_t)ref;
+    const int64_t len = n - j0, per = (len + kSeg - 1) / kSeg;
+    const int64_t jb = j0 + seg * per, je = (jb + per < n) ? jb + per : n;
     double mean[9], m2[9], mx[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) { mean[c] = 0.0; m2[c] = 0.0; mx[c] = 0.0; }
     double cnt = 0.0;
-    for (int64_t j = j0; j < n; ++j) {
-        double x[9], t[9], e[9];
+    if (active) {
+        for (int64_t j = jb; j < je; ++j) {
+            double x[9], t[9], e[9];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) { x[c] = traj[c * plane + j * runs + r]; t[c] = truth[9 * j + c]; }
+            for (int c = 0; c < 9; ++c) { x[c] = traj[c * plane + j * runs + r]; t[c] = truth[9 * j + c]; }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) e[c] = angle_range_pi(x[c] - t[c]);
-        if (pos_ned) {
-            const Vec3 d = lla_error_ned(Vec3{x[3], x[4], x[5]}, Vec3{t[3], t[4], t[5]});
-            e[3] = d.x; e[4] = d.y; e[5] = d.z;
-        } else {
+            for (int c = 0; c < 3; ++c) e[c] = angle_range_pi_mul(x[c] - t[c]);
+            if (pos_ned) {
+                const Vec3 d = lla_error_ned(Vec3{x[3], x[4], x[5]}, Vec3{t[3], t[4], t[5]});
+                e[3] = d.x; e[4] = d.y; e[5] = d.z;
+            } else {
 #pragma unroll
-            for (int c = 3; c < 6; ++c) e[c] = x[c] - t[c];
-        }
+                for (int c = 3; c < 6; ++c) e[c] = x[c] - t[c];
+            }
 #pragma unroll
-        for (int c = 6; c < 9; ++c) e[c] = x[c] - t[c];
-        cnt += 1.0;
-        const double icnt = 1.0 / cnt;
+            for (int c = 6; c < 9; ++c) e[c] = x[c] - t[c];
+            cnt += 1.0;
+            const double icnt = rcp_nr(cnt);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            const double d = e[c] - mean[c];
-            mean[c] += d * icnt;
-            m2[c] += d * (e[c] - mean[c]);
-            const double a = fabs(e[c]);
-            mx[c] = a > mx[c] ? a : mx[c];
+            for (int c = 0; c < 9; ++c) {
+                const double d = e[c] - mean[c];
+                mean[c] = __builtin_fma(d, icnt, mean[c]);
+                m2[c] = __builtin_fma(d, e[c] - mean[c], m2[c]);
+                const double a = fabs(e[c]);
+                mx[c] = a > mx[c] ? a : mx[c];
+            }
         }
     }
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-        out[(0 * 9 + c) * runs + r] = mx[c];
-        out[(1 * 9 + c) * runs + r] = mean[c];
-        out[(2 * 9 + c) * runs + r] = cnt > 0.0 ? sqrt(m2[c] / cnt) : 0.0;
+    for (int c = 0; c < 9; ++c) part[seg][c][lane] = Mom{cnt, mean[c], m2[c], mx[c]};
+    __syncthreads();
+    if (seg == 0 && active) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            Mom t = part[0][c][lane];
+#pragma unroll
+            for (int k = 1; k < kSeg; ++k) t = merge(t, part[k][c][lane]);
+            const double sd = t.n > 0.0 ? sqrt(t.m2 / t.n) : 0.0;
+            if (run_major) {
+                out[(r * 3 + 0) * 9 + c] = t.mx;
+                out[(r * 3 + 1) * 9 + c] = t.mean;
+                out[(r * 3 + 2) * 9 + c] = sd;
+            } else {
+                out[(0 * 9 + c) * runs + r] = t.mx;
+                out[(1 * 9 + c) * runs + r] = t.mean;
+                out[(2 * 9 + c) * runs + r] = sd;
+            }
+        }
     }
 }
 
 hipError_t launch_process_stats(const double* traj, const double* ref, int64_t n, int64_t runs, int64_t j0, int pos_ned,
-                                double* out, hipStream_t s) {
-    hipLaunchKernelGGL(process_stats_kernel, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, s, traj, ref, n, runs, j0,
-                       pos_ned, out);
+                                int run_major, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(process_stats_kernel, dim3((unsigned)((runs + 63) / 64)), dim3(64 * kSeg), 0, s, traj, ref, n, runs, j0,
+                       pos_ned, run_major, out);
     return hipGetLastError();
 }
 
