@@ -3,7 +3,7 @@
   * noise-free closed loop vs the reference's fp64 outputs: attitude 2e-6 rad, velocity 5e-5 m/s,
     position 1e-4 m (ref_frame 1: ECEF+displacement) / 1e-11 rad + 1e-4 m (ref_frame 0: lat, lon, alt);
     measured: 2.2e-7 rad, 7.6e-6 m/s, 1.4e-5 m, 3e-12 rad;
-  * with noise the fp32 path uses 24-bit uniforms (a different, coarser stream than fp64), so the comparison is
+  * with noise the fp32 path uses 23-bit uniforms (a different, coarser stream than fp64), so the comparison is
     statistical: end-point std of 65 536 runs within 1.5 % of the fp64 path (sampling error of the ratio 0.4 %),
     means within 5 sigma/sqrt(R); generated white noise has the model's sigma within 1 %.
 """
