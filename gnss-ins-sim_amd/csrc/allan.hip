@@ -141,7 +141,7 @@ allan_level_kernel(const double* __restrict__ in, double* __restrict__ out, doub
         double v[kLoads];
         if (full) {                 // forty independent 512-byte wave loads in flight
 #pragma unroll
-            for (int q = 0; q < kLoads; ++q) v[q] = x[base + q * 64 + lane];
+            for (int q = 0; q < kLoads; ++q) v[q] = __builtin_nontemporal_load(&x[base + q * 64 + lane]);
         } else {                    // tail of the series: clamp the address, zero what lies beyond the end
 #pragma unroll
             for (int q = 0; q < kLoads; ++q) {
