@@ -122,22 +122,25 @@ __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& a
     }
 }
 
+// Series are written once and not read back by the kernel: non-temporal stores keep them from displacing the L2.
+__device__ __forceinline__ void st(double* p, double v) { __builtin_nontemporal_store(v, p); }
+
 __device__ __forceinline__ void store9(double* __restrict__ base, int64_t plane, int64_t off, const Nav& s) {
-    base[0 * plane + off] = s.att.yaw;
-    base[1 * plane + off] = s.att.pit;
-    base[2 * plane + off] = s.att.rol;
-    base[3 * plane + off] = s.pos.x;
-    base[4 * plane + off] = s.pos.y;
-    base[5 * plane + off] = s.pos.z;
-    base[6 * plane + off] = s.vel.x;
-    base[7 * plane + off] = s.vel.y;
-    base[8 * plane + off] = s.vel.z;
+    st(base + 0 * plane + off, s.att.yaw);
+    st(base + 1 * plane + off, s.att.pit);
+    st(base + 2 * plane + off, s.att.rol);
+    st(base + 3 * plane + off, s.pos.x);
+    st(base + 4 * plane + off, s.pos.y);
+    st(base + 5 * plane + off, s.pos.z);
+    st(base + 6 * plane + off, s.vel.x);
+    st(base + 7 * plane + off, s.vel.y);
+    st(base + 8 * plane + off, s.vel.z);
 }
 
 __device__ __forceinline__ void store3(double* __restrict__ base, int64_t plane, int64_t off, const Vec3& v) {
-    base[off] = v.x;
-    base[plane + off] = v.y;
-    base[2 * plane + off] = v.z;
+    st(base + off, v.x);
+    st(base + plane + off, v.y);
+    st(base + 2 * plane + off, v.z);
 }
 
 __device__ __forceinline__ void store_end(double* __restrict__ out, int64_t runs, int64_t r, const Nav& s) {
