@@ -225,16 +225,19 @@ __device__ __forceinline__ void nav_step(Nav& s, const V3& gyro, const V3& accel
     }
 }
 
+// written once, never read back by the kernel: non-temporal stores
+__device__ __forceinline__ void st(float* p, float v) { __builtin_nontemporal_store(v, p); }
+
 __device__ __forceinline__ void store9(float* __restrict__ base, int64_t plane, int64_t off, const Nav& s) {
-    base[0 * plane + off] = s.att.yaw.v;
-    base[1 * plane + off] = s.att.pit.v;
-    base[2 * plane + off] = s.att.rol.v;
-    base[3 * plane + off] = (float)(s.pos[0] - s.pos0[0]);      // displacement from the initial position
-    base[4 * plane + off] = (float)(s.pos[1] - s.pos0[1]);
-    base[5 * plane + off] = (float)(s.pos[2] - s.pos0[2]);
-    base[6 * plane + off] = s.vel.x;
-    base[7 * plane + off] = s.vel.y;
-    base[8 * plane + off] = s.vel.z;
+    st(base + 0 * plane + off, s.att.yaw.v);
+    st(base + 1 * plane + off, s.att.pit.v);
+    st(base + 2 * plane + off, s.att.rol.v);
+    st(base + 3 * plane + off, (float)(s.pos[0] - s.pos0[0]));      // displacement from the initial position
+    st(base + 4 * plane + off, (float)(s.pos[1] - s.pos0[1]));
+    st(base + 5 * plane + off, (float)(s.pos[2] - s.pos0[2]));
+    st(base + 6 * plane + off, s.vel.x);
+    st(base + 7 * plane + off, s.vel.y);
+    st(base + 8 * plane + off, s.vel.z);
 }
 
 typedef const ginsim_mc_params __attribute__((address_space(4))) * params_ptr;
@@ -325,14 +328,14 @@ __global__ void __launch_bounds__(256) mc_kernel_f32(const ginsim_mc_params a) {
         const float zdg[3] = {z1[2], z1[3], z2[0]}, zwg[3] = {z2[1], z2[2], z2[3]};
         const V3 acc = sense3(ta, ma, da, zda, zwa);
         const V3 gyr = sense3(tg, mg, dg, zdg, zwg);
-        if (o_acc) { o_acc[off] = acc.x; o_acc[plane + off] = acc.y; o_acc[2 * plane + off] = acc.z; }
-        if (o_gyr) { o_gyr[off] = gyr.x; o_gyr[plane + off] = gyr.y; o_gyr[2 * plane + off] = gyr.z; }
+        if (o_acc) { st(o_acc + off, acc.x); st(o_acc + plane + off, acc.y); st(o_acc + 2 * plane + off, acc.z); }
+        if (o_gyr) { st(o_gyr + off, gyr.x); st(o_gyr + plane + off, gyr.y); st(o_gyr + 2 * plane + off, gyr.z); }
         float odo = 0.f;
         if (ODO || o_odo) {
             float z3[4];
             normals4(key, S_ODO, jj, z3);
             odo = odo_scale * (float)ref_o[j] + odo_stdv * z3[0];
-            if (o_odo) o_odo[off] = odo;
+            if (o_odo) st(o_odo + off, odo);
         }
         if (last) break;
         const bool resync = ((j + 1) & (kTrigResync - 1)) == 0;
@@ -440,14 +443,14 @@ __global__ void __launch_bounds__(512) mc_kernel_f32_split(const ginsim_mc_param
                 const float zdg[3] = {z1[2], z1[3], z2[0]}, zwg[3] = {z2[1], z2[2], z2[3]};
                 const V3 acc = sense3(ta, ma, da, zda, zwa);
                 const V3 gyr = sense3(tg, mg, dg, zdg, zwg);
-                if (o_acc) { o_acc[off] = acc.x; o_acc[plane + off] = acc.y; o_acc[2 * plane + off] = acc.z; }
-                if (o_gyr) { o_gyr[off] = gyr.x; o_gyr[plane + off] = gyr.y; o_gyr[2 * plane + off] = gyr.z; }
+                if (o_acc) { st(o_acc + off, acc.x); st(o_acc + plane + off, acc.y); st(o_acc + 2 * plane + off, acc.z); }
+                if (o_gyr) { st(o_gyr + off, gyr.x); st(o_gyr + plane + off, gyr.y); st(o_gyr + 2 * plane + off, gyr.z); }
                 float odo = 0.f;
                 if (ODO || o_odo) {
                     float z3[4];
                     normals4(key, S_ODO, (uint32_t)j, z3);
                     odo = odo_scale * (float)ref_o[j] + odo_stdv * z3[0];
-                    if (o_odo) o_odo[off] = odo;
+                    if (o_odo) st(o_odo + off, odo);
                 }
                 if (last) break;
                 const bool resync = ((j + 1) & (kTrigResync - 1)) == 0;
