@@ -26,6 +26,39 @@ def test_normals_moments():
     assert abs(np.mean(z0 * z1)) < 4 / np.sqrt(z0.size)
 
 
+def test_stream_cut_statistics():
+    """Three normal pairs are cut from two Philox blocks (oracle/philox.py): the six normals of a group must be
+    standard normal (Kolmogorov-Smirnov), mutually uncorrelated -- also in their squares, which would expose shared
+    radius bits -- and uncorrelated along the sample index and across runs."""
+    from scipy import stats
+    n = 200000
+    j = np.arange(n, dtype=np.uint64)
+    z = []
+    for stream in (3, 4, 5):                      # group 1: slots 0, 1, 2
+        a, b = philox.normal_pair(12345, 77, stream, j)
+        z += [a, b]
+    z = np.array(z)
+    for k in range(6):
+        assert stats.kstest(z[k], 'norm').pvalue > 1e-3, 'normal %d of the group fails KS' % k
+        assert abs(z[k].mean()) < 4.5 / np.sqrt(n) and abs(z[k].var() - 1.0) < 4.5 * np.sqrt(2.0 / n)
+        assert abs(stats.kurtosis(z[k])) < 4.5 * np.sqrt(24.0 / n)
+    lim = 4.5 / np.sqrt(n)
+    c = np.corrcoef(z)
+    c2 = np.corrcoef(z ** 2)
+    for a in range(6):
+        for b in range(a + 1, 6):
+            assert abs(c[a, b]) < lim and abs(c2[a, b]) < lim, (a, b, c[a, b], c2[a, b])
+        assert abs(np.corrcoef(z[a][:-1], z[a][1:])[0, 1]) < lim            # consecutive samples
+    other = philox.normal_pair(12345, 78, 5, j)[0]                             # the neighbouring run
+    assert abs(np.corrcoef(z[4], other)[0, 1]) < lim
+    # the radius uniform of slot 2 is built from the spare low bits of the words that feed slots 0 and 1
+    w0 = philox.stream_words(12345, 77, 3, j)
+    w2 = philox.stream_words(12345, 77, 5, j)
+    u0, u2 = philox.uniform53(w0[0], w0[1]), philox.uniform53(w2[0], w2[1])
+    assert abs(np.corrcoef(u0, u2)[0, 1]) < lim
+    assert stats.kstest(u2, 'uniform').pvalue > 1e-3
+
+
 @pytest.mark.parametrize('name', ['bosch', 'nxp'])
 def test_t1_given_data_fixture(name):
     g = load_golden('t1_fixture_' + name)
