@@ -43,6 +43,29 @@ def test_allan_matches_oracle_ragged_lengths(ctx, n, fs):
         np.testing.assert_allclose(avar[s], ra, rtol=1e-9)
 
 
+@pytest.mark.parametrize('n', [2520 * 4, 2520 * 4 + 9, 2520 * 40 - 1, 25200 * 3 + 2527, 252000 + 10])
+def test_allan_chunk_boundaries_strided_series_and_drift(ctx, n):
+    """Lengths around multiples of the 2520-entry chunk (its 9-entry halo, the hand-over between the per-chunk levels
+    and the single-chunk tail levels), series packed with a stride larger than n, and a bias + ramp a million times
+    the noise: the per-chunk origin shift must keep the bin-sum differences exact."""
+    import ginsim
+    from oracle import ins_np
+    S, stride, fs = 4, n + 13, 100.0
+    t = np.arange(n) / fs
+    rows = [_series(10 + s, n) + 1.0e6 * (s + 1) + 3.0e3 * s * t for s in range(S)]
+    packed = np.full((S, stride), np.nan)
+    for s in range(S):
+        packed[s, :n] = rows[s]
+    buf = ctx.upload(packed)
+    avar, tau = ginsim.allan_var(ctx, buf, n, S, stride, fs)
+    for s in range(S):
+        ra, rt = ins_np.allan_var(rows[s], fs)
+        assert tau.shape == rt.shape and np.isfinite(avar[s]).all()
+        np.testing.assert_allclose(tau, rt, rtol=1e-15)
+        # the reference's own means of ~1e6-sized samples carry 1e-10 of rounding relative to a noise-sized difference
+        np.testing.assert_allclose(avar[s], ra, rtol=2e-7)
+
+
 def test_allan_plugin_and_module_surface(ctx):
     from gnss_ins_sim.allan import allan
     from demo_algorithms import allan_analysis
