@@ -88,14 +88,8 @@ def emit_profile(src, dst, comment):
 
 
 # ------------------------------------------------------------------ T1: logged-data fixtures
-def t1_fixture(name):
-    d = REF + '/demo_data_files/%s/' % name
-    ini = np.genfromtxt(d + 'ini.txt', delimiter=',')
-    ini[0:2] *= D2R
-    ini[6:9] *= D2R
-    gyro = np.genfromtxt(d + 'gyro-0.csv', delimiter=',', skip_header=1) * D2R   # file is deg/s
-    accel = np.genfromtxt(d + 'accel-0.csv', delimiter=',', skip_header=1)
-    k = rows(gyro.shape[0], 10)
+def t1_run(name, ini, gyro, accel, stride):
+    k = rows(gyro.shape[0], stride)
     out = {}
     for tag, use_g, erot in (('extg', True, False), ('wgs', False, True)):
         algo = free_integration.FreeIntegration(ini if use_g else ini[0:9], earth_rot=erot)
@@ -107,6 +101,39 @@ def t1_fixture(name):
     att, pos, vel = algo.get_results()
     out.update({'att_rf1': att[k], 'pos_rf1': pos[k], 'vel_rf1': vel[k]})
     save('t1_fixture_' + name, rows=k, ini=ini, gyro=gyro, accel=accel, fs=100.0, **out)
+    return att
+
+
+def t1_fixture(name):
+    d = REF + '/demo_data_files/%s/' % name
+    ini = np.genfromtxt(d + 'ini.txt', delimiter=',')
+    ini[0:2] *= D2R
+    ini[6:9] *= D2R
+    gyro = np.genfromtxt(d + 'gyro-0.csv', delimiter=',', skip_header=1) * D2R   # file is deg/s
+    accel = np.genfromtxt(d + 'accel-0.csv', delimiter=',', skip_header=1)
+    t1_run(name, ini, gyro, accel, 10)
+
+
+def t1_tumble():
+    """Synthetic body rates that drive the pitch through +-90 deg (the fold of attitude.euler_update_zyx,
+    attitude.py:700-712) and yaw / roll through +-180 deg (the single 2 pi wrap, :713-720) several times.
+    Every sample is kept: the branches are what is being pinned."""
+    n = 900
+    t = np.arange(n) / 100.0
+    ini = np.array([32.0 * D2R, 120.0 * D2R, 0.0, 5.0, 0.0, 0.0, 170.0 * D2R, 78.0 * D2R, 0.0, 9.794])
+    # a pure pitch rotation first (Euler kinematics only cross the pole when q = wz cos(roll) + wy sin(roll) ~ 0:
+    # 78 deg + 0.61 deg per step overshoots 90 deg at step 20, -90 deg at step 315), then yaw / roll rates as well
+    late = (t >= 4.0).astype(np.float64)
+    gyro = np.stack([late * 40.0 * D2R * np.cos(2 * np.pi * t / 4.1), 61.0 * D2R * np.ones(n),
+                     late * (70.0 * D2R + 10.0 * D2R * np.sin(2 * np.pi * t / 2.9))], axis=1)
+    accel = np.stack([0.3 * np.sin(2 * np.pi * t / 3.0), 0.2 * np.cos(2 * np.pi * t / 1.7),
+                      -9.794 + 0.1 * np.sin(2 * np.pi * t / 0.9)], axis=1)
+    att = t1_run('tumble', ini, gyro, accel, 1)
+    pit = att[:, 1]
+    dy, dr = np.abs(np.diff(att[:, 0])), np.abs(np.diff(att[:, 2]))
+    print('   tumble: min |cos(pitch)| = %.2e, %d folds, %d wraps, %d steps > 0.25 rad' % (
+        np.min(np.abs(np.cos(pit))), int(np.sum((dy > 2) & (dy < 4) & (dr > 2) & (dr < 4))), int(np.sum(dy > 5) + np.sum(dr > 5)),
+        int(np.sum(np.maximum(dy, dr) > 0.25))))
 
 
 # ------------------------------------------------------------------ T2: noise-free closed loop
@@ -268,6 +295,7 @@ if __name__ == '__main__':
     emit_profile(MOTION + 'motion_def-90deg_turn.csv', prof + '/turn_90deg.csv', '90-degree turn, 10 s')
     emit_profile(MOTION + 'motion_def-long_drive.csv', prof + '/long_drive.csv', 'long drive, <=1410 s')
     emit_profile(MOTION + 'motion_def-Allan.csv', prof + '/static_1800s.csv', 'static, 1800 s')
+    t1_tumble()
     t1_fixture('bosch')
     t1_fixture('nxp')
     t2_turn(1)

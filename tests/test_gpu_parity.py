@@ -80,7 +80,7 @@ def test_box_muller_corner_cases(ctx):
     np.testing.assert_allclose(np.hypot(z0[keep], z1[keep]) / r[keep], 1.0, rtol=0, atol=2e-15)
 
 
-@pytest.mark.parametrize('name', ['bosch', 'nxp'])
+@pytest.mark.parametrize('name', ['bosch', 'nxp', 'tumble'])
 def test_t1_given_data_fixture(ctx, name):
     import ginsim
     g = load_golden('t1_fixture_' + name)

@@ -14,7 +14,7 @@ def test_c_normals_match_numpy():
         np.testing.assert_allclose(z1, r1, rtol=0, atol=1e-15)
 
 
-@pytest.mark.parametrize('name', ['bosch', 'nxp'])
+@pytest.mark.parametrize('name', ['bosch', 'nxp', 'tumble'])
 def test_c_t1_fixture(name):
     g = load_golden('t1_fixture_' + name)
     k = g['rows']

@@ -59,7 +59,7 @@ def test_stream_cut_statistics():
     assert stats.kstest(u2, 'uniform').pvalue > 1e-3
 
 
-@pytest.mark.parametrize('name', ['bosch', 'nxp'])
+@pytest.mark.parametrize('name', ['bosch', 'nxp', 'tumble'])
 def test_t1_given_data_fixture(name):
     g = load_golden('t1_fixture_' + name)
     k = g['rows']
