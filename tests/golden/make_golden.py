@@ -302,6 +302,8 @@ if __name__ == '__main__':
     t2_turn(0)
     t3_case('t3_demo_rf1', 1, dict(DEMO_IMU), False, {'scale': 0.999, 'stdv': 0.1}, ['odo', 'fi'], 4)
     t3_case('t3_mid_rf0', 0, 'mid-accuracy', False, None, ['fi'], 4)
+    t3_case('t3_low_rf1', 1, 'low-accuracy', False, None, ['fi'], 3)
+    t3_case('t3_high_odo_rf0', 0, 'high-accuracy', False, {'scale': 1.002, 'stdv': 0.02}, ['odo', 'fi'], 3)
     white = {k: v for k, v in DEMO_IMU.items() if not k.endswith('_corr')}
     white['gyro_b'] = np.array([10.0, -20.0, 30.0])
     white['accel_b'] = np.array([1e-3, -2e-3, 3e-3])
