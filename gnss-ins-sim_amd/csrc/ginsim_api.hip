@@ -28,6 +28,9 @@ void set_error(const char* fmt, ...) {
 hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream);
 hipError_t launch_mc_f32(const ginsim_mc_params& p, hipStream_t stream);
 int mc_variant(const ginsim_mc_params& p);
+bool series_path_applies(const ginsim_mc_params& p);
+int64_t series_chunks(const ginsim_mc_params& p, int32_t* L_out);
+hipError_t launch_series(const ginsim_mc_params& p, double* carry, hipStream_t stream);
 int mc_variant_f32(const ginsim_mc_params& p);
 hipError_t launch_gather_runs_f32(const float* series, int C, int64_t n, int64_t runs, const int64_t* ids, int nsel,
                                   double* out, hipStream_t s);
@@ -296,6 +299,12 @@ int ginsim_mc_run(ginsim_ctx* c, const ginsim_mc_params* p) {
     if (p->precision == 1) {
         REQUIRE(!p->given_sensors && p->algo_mask != 0, "mc_run: the fp32 kernel supports generate mode with an algorithm only");
         HIP_TRY(launch_mc_f32(*p, c->stream));
+    } else if (series_path_applies(*p)) {       // sensors only, few runs, long series: parallel along time
+        int32_t L = 0;
+        const int64_t nchunks = series_chunks(*p, &L);
+        void* carry = nullptr;
+        HIP_TRY(scratch(c, 3, sizeof(double) * 6 * (size_t)nchunks * (size_t)p->runs, &carry));
+        HIP_TRY(launch_series(*p, reinterpret_cast<double*>(carry), c->stream));
     } else {
         HIP_TRY(launch_mc(*p, c->stream));
     }

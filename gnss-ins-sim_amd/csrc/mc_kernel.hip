@@ -498,6 +498,124 @@ hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Sensor series for FEW runs (Sim.run(1) as a data generator, the Allan flow of BASELINE config 5): with one lane per
+// run the time loop of mc_kernel is a single sequential chain (n = 1 440 000 samples -> 2.8 s on one lane).  Noise
+// generation is parallel along time except for the Gauss-Markov recurrence d[j+1] = a d[j] + b w[j], which is linear:
+//   pass A  every thread takes a chunk of L samples of one run and integrates the drift from zero -> chunk-end value
+//   pass S  one thread per (run, axis) turns the chunk-end values into chunk-START values:
+//           start[k+1] = a^L start[k] + end[k]
+//   pass B  every thread regenerates the normals of its chunk (counter-based RNG: no state to carry) and emits
+//           truth + bias + drift + white with the recurrence restarted from start[k]
+// Same normals, same recurrence inside a chunk; only the L-step hand-over is evaluated as a^L x + y instead of L
+// fused multiply-adds (a relative 1e-16 on a drift of ~1e-5: far below the 1e-12 / 1e-14 sensor tolerances).
+struct SeriesPlan {
+    double* carry;          // [runs][nchunks][6]: pass A chunk-end values, pass S overwrites them with chunk-start values
+    double a_pow[6];        // gm_a ^ L for accel xyz, gyro xyz
+    int64_t nchunks;
+    int32_t L;
+};
+
+template <int PASS>
+__global__ void __launch_bounds__(256) series_kernel(const ginsim_mc_params a, const SeriesPlan pl) {
+    __shared__ double2 ntab[kLogBins + kAngBins];
+    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const NormalTables tab{ntab, ntab + kLogBins};
+    MathConsts mk;
+    mk.init<true>();
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= pl.nchunks * a.runs) return;
+    const int64_t r = id % a.runs, c = id / a.runs;        // run fastest: coalesced when there are >= 64 runs
+    const int64_t j0 = c * pl.L, j1 = (j0 + pl.L < a.n) ? j0 + pl.L : a.n;
+    const uint64_t grun = a.run_offset + (uint64_t)r;
+    const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
+    double* cb = pl.carry + (r * pl.nchunks + c) * 6;
+    const params_ptr kp = kernarg_params();
+    if (PASS == 0) {
+        Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
+        for (int64_t j = j0; j < j1; ++j) {
+            double z0[6], z1[6];
+            normal_pairs<6>(key, S_ACC_D_XY, (uint32_t)j, z0, z1, mk, tab);
+            da.x = __builtin_fma(kp->accel.gm_a[0], da.x, kp->accel.gm_b[0] * z0[0]);
+            da.y = __builtin_fma(kp->accel.gm_a[1], da.y, kp->accel.gm_b[1] * z1[0]);
+            da.z = __builtin_fma(kp->accel.gm_a[2], da.z, kp->accel.gm_b[2] * z0[1]);
+            dg.x = __builtin_fma(kp->gyro.gm_a[0], dg.x, kp->gyro.gm_b[0] * z0[3]);
+            dg.y = __builtin_fma(kp->gyro.gm_a[1], dg.y, kp->gyro.gm_b[1] * z1[3]);
+            dg.z = __builtin_fma(kp->gyro.gm_a[2], dg.z, kp->gyro.gm_b[2] * z0[4]);
+        }
+        cb[0] = da.x; cb[1] = da.y; cb[2] = da.z; cb[3] = dg.x; cb[4] = dg.y; cb[5] = dg.z;
+    } else {
+        Vec3 da{cb[0], cb[1], cb[2]}, dg{cb[3], cb[4], cb[5]};
+        const int64_t plane = a.n * a.runs;
+        for (int64_t j = j0; j < j1; ++j) {
+            const int64_t off = j * a.runs + r;
+            double z0[6], z1[6];
+            normal_pairs<6>(key, S_ACC_D_XY, (uint32_t)j, z0, z1, mk, tab);
+            const Vec3 ta{a.ref_accel[3 * j], a.ref_accel[3 * j + 1], a.ref_accel[3 * j + 2]};
+            const Vec3 tg{a.ref_gyro[3 * j], a.ref_gyro[3 * j + 1], a.ref_gyro[3 * j + 2]};
+            const Vec3 acc = sense3(ta, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
+            const Vec3 gyr = sense3(tg, &kp->gyro, dg, Vec3{z0[3], z1[3], z0[4]}, Vec3{z1[4], z0[5], z1[5]});
+            if (a.out_accel) store3(a.out_accel, plane, off, acc);
+            if (a.out_gyro) store3(a.out_gyro, plane, off, gyr);
+            if (a.out_odo) {
+                double y0, y1;
+                normal_pair(key, S_ODO, (uint32_t)j, y0, y1, mk, tab);
+                a.out_odo[off] = kp->odo_scale * a.ref_odo[j] + kp->odo_stdv * y0;
+            }
+        }
+    }
+}
+
+// chunk-end values -> chunk-start values, one thread per (run, axis); the loads do not depend on the recurrence
+__global__ void series_scan_kernel(const SeriesPlan pl, int64_t runs) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= runs * 6) return;
+    const int64_t r = id / 6;
+    const int k = (int)(id % 6);
+    double* cb = pl.carry + r * pl.nchunks * 6 + k;
+    const double ap = pl.a_pow[k];
+    double start = 0.0;
+    for (int64_t c = 0; c < pl.nchunks; ++c) {
+        const double end = cb[c * 6];
+        cb[c * 6] = start;
+        start = __builtin_fma(ap, start, end);
+    }
+}
+
+// sensors only, few runs, long series
+bool series_path_applies(const ginsim_mc_params& p) {
+    return p.algo_mask == 0 && !p.given_sensors && p.precision == 0 && !p.wave_trace && p.block_threads == 0 &&
+           p.runs <= 1024 && p.n >= 2048;
+}
+
+int64_t series_chunks(const ginsim_mc_params& p, int32_t* L_out) {
+    // ~8192 threads over the chip, chunks of at least 64 samples
+    int64_t L = (p.n * p.runs + 8191) / 8192;
+    if (L < 64) L = 64;
+    if (L > 4096) L = 4096;
+    *L_out = (int32_t)L;
+    return (p.n + L - 1) / L;
+}
+
+hipError_t launch_series(const ginsim_mc_params& p, double* carry, hipStream_t stream) {
+    SeriesPlan pl;
+    pl.carry = carry;
+    pl.nchunks = series_chunks(p, &pl.L);
+    for (int k = 0; k < 6; ++k) {
+        const double aa = k < 3 ? p.accel.gm_a[k] : p.gyro.gm_a[k - 3];
+        double v = 1.0;
+        for (int i = 0; i < pl.L; ++i) v *= aa;
+        pl.a_pow[k] = v;
+    }
+    const int64_t threads = pl.nchunks * p.runs;
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    hipLaunchKernelGGL((series_kernel<0>), grid, block, 0, stream, p, pl);
+    hipLaunchKernelGGL(series_scan_kernel, dim3((unsigned)((p.runs * 6 + 63) / 64)), dim3(64), 0, stream, pl, p.runs);
+    hipLaunchKernelGGL((series_kernel<1>), grid, block, 0, stream, p, pl);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Auxiliary sensors: one thread per (sample, run), run fastest.  gps_gen: pathgen.py:621-624; mag_gen: :658-661.
 __global__ void __launch_bounds__(256) aux_gps_kernel(const ginsim_aux_params a) {
     __shared__ double2 ntab[kLogBins + kAngBins];

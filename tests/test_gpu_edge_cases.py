@@ -252,3 +252,34 @@ def test_async_stats_slots_match_blocking_reduction(ctx, turn):
     with pytest.raises(ValueError):
         job.stats_begin('free', 8)
     job.release()
+
+
+@pytest.mark.parametrize('runs,n,with_odo', [(1, 60000, False), (3, 20000, True), (700, 2500, False)])
+def test_time_parallel_sensor_series_match_oracle_and_lane_per_run_kernel(ctx, runs, n, with_odo):
+    """Sensors only, few runs, long series (Sim.run(1) as a data generator, the Allan flow): ginsim_mc_run cuts the time
+    axis into chunks (Gauss-Markov carry by a linear scan).  Same normals -> same series as the oracle's sequential
+    recurrence and as the lane-per-run kernel (taken here from a batch too large for the time-parallel path)."""
+    import ginsim
+    from ginsim import workloads
+    from oracle import ins_np
+    ini, truth, _ = workloads.truth_from_profile('long_drive', 200.0, 0)
+    t = {k: (v[:n] if hasattr(v, 'shape') and v.shape and v.shape[0] > n else v) for k, v in truth.items()}
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    odo_err = {'scale': 0.998, 'stdv': 0.07} if with_odo else None
+    job = ginsim.MonteCarloJob(ctx, 200.0, 0, t, acc, gyr, None, runs=runs, algos=(), odo_err=odo_err, seed=77,
+                               keep_sensors=True).run()
+    pick = sorted({0, runs // 2, runs - 1})
+    a_dev, g_dev = job.sensors('accel', pick), job.sensors('gyro', pick)
+    a_ref, g_ref = ins_np.mc_sensors(77, np.array(pick), 200.0, t['ref_accel'], t['ref_gyro'], acc, gyr)
+    np.testing.assert_allclose(a_dev, a_ref, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(g_dev, g_ref, rtol=0, atol=1e-14)
+    if with_odo:
+        o_ref = ins_np.mc_odo(77, np.array(pick), t['ref_odo'], odo_err)
+        np.testing.assert_allclose(job.sensors('odo', pick).reshape(len(pick), -1), o_ref, rtol=0, atol=1e-12)
+    big = ginsim.MonteCarloJob(ctx, 200.0, 0, t, acc, gyr, None, runs=1100, algos=(), odo_err=odo_err, seed=77,
+                               keep_sensors=True).run()            # > 1024 runs: one lane per run
+    if runs <= 1100:
+        np.testing.assert_allclose(a_dev, big.sensors('accel', pick), rtol=0, atol=4e-15)      # an ulp of the terms
+        np.testing.assert_allclose(g_dev, big.sensors('gyro', pick), rtol=0, atol=2e-16)
+    big.release()
+    job.release()
