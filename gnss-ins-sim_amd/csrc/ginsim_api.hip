@@ -38,6 +38,7 @@ hipError_t launch_aux(const ginsim_aux_params& p, hipStream_t s);
 hipError_t launch_rng_probe(uint64_t seed, uint64_t run, uint32_t stream, int64_t count, double* z0, double* z1,
                             uint32_t* words, hipStream_t stream_h);
 hipError_t launch_aos_to_soa(const double* src, double* dst, int64_t R, int64_t n, int C, hipStream_t s);
+hipError_t launch_runs_to_series(const double* in, double* out, int C, int64_t n, int64_t R, hipStream_t s);
 hipError_t launch_box_muller(const uint32_t* words, int64_t count, double* z0, double* z1, hipStream_t s);
 hipError_t launch_gather_runs(const double* series, int C, int64_t n, int64_t runs, const int64_t* ids, int nsel,
                               double* out, hipStream_t s);
@@ -599,6 +600,14 @@ int ginsim_rng_normals(ginsim_ctx* c, uint64_t seed, uint64_t run, uint32_t stre
     if (host_words)
         HIP_TRY(hipMemcpyAsync(host_words, w.p, sizeof(uint32_t) * 4 * count, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_runs_to_series(ginsim_ctx* c, const double* series, int32_t ncomp, int64_t n, int64_t runs, double* out) {
+    REQUIRE(c && series && out && series != out, "runs_to_series: bad pointers");
+    REQUIRE(ncomp >= 1 && ncomp <= 65535 && n >= 1 && runs >= 1 && (runs + 63) / 64 <= 65535, "runs_to_series: bad sizes");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_runs_to_series(series, out, ncomp, n, runs, c->stream));
     return GINSIM_OK;
 }
 

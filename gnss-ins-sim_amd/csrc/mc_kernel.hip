@@ -741,6 +741,32 @@ hipError_t launch_box_muller(const uint32_t* words, int64_t count, double* z0, d
     return hipGetLastError();
 }
 
+// [C][n][R] -> [R][C][n]: per component a (n x R) -> (R x n) transpose through a padded 64 x 64 LDS tile; both the
+// reads (64 runs contiguous) and the writes (64 samples contiguous) are 512-byte rows.
+__global__ void __launch_bounds__(256) runs_to_series_kernel(const double* __restrict__ in, double* __restrict__ out, int C,
+                                                            int64_t n, int64_t R) {
+    __shared__ double tile[64][65];
+    const int c = blockIdx.z;
+    const int64_t j0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const double* src = in + (int64_t)c * n * R;
+    for (int k = ty; k < 64; k += 4) {
+        const int64_t j = j0 + k, r = r0 + tx;
+        tile[k][tx] = (j < n && r < R) ? src[j * R + r] : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4) {
+        const int64_t r = r0 + k, j = j0 + tx;
+        if (r < R && j < n) out[(r * C + c) * n + j] = tile[tx][k];
+    }
+}
+
+hipError_t launch_runs_to_series(const double* in, double* out, int C, int64_t n, int64_t R, hipStream_t s) {
+    hipLaunchKernelGGL(runs_to_series_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((R + 63) / 64), (unsigned)C), dim3(256), 0, s,
+                       in, out, C, n, R);
+    return hipGetLastError();
+}
+
 hipError_t launch_aos_to_soa(const double* src, double* dst, int64_t R, int64_t n, int C, hipStream_t s) {
     const int tb = 256;
     hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)((n * R + tb - 1) / tb)), dim3(tb), 0, s, src, dst, R, n, C);

@@ -323,6 +323,28 @@ class MonteCarloJob(object):
                 p.out_traj[s] = self._bufs['traj_' + a].ptr
 
     # bytes the launch writes to HBM (the algorithmic traffic of SURVEY 8(d))
+    def allan(self, fs=None, names=('accel', 'gyro')):
+        """Allan deviation of the kept sensor series on the device (allan_analysis.py:33-49 for every run at once):
+        returns (tau (ntau,), {name: (runs, ntau, 3)}).  One run is already laid out as three contiguous series; more
+        runs are re-laid out [3][n][runs] -> [runs][3][n] on the device first."""
+        if not self.keep_sensors or self.precision != 'f64':
+            raise ValueError('Allan analysis needs the fp64 sensor series (keep_sensors=True)')
+        fs = float(self.params.fs if fs is None else fs)
+        out, tau = {}, None
+        for nm in names:
+            src = self._bufs[nm]
+            if self.runs == 1:
+                ptr, tmp = src.ptr, None
+            else:
+                tmp = self.ctx.malloc(3 * self.n * self.runs * 8)
+                check(lib.ginsim_runs_to_series(self.ctx.handle, src.ptr, 3, self.n, self.runs, tmp.ptr))
+                ptr = tmp.ptr
+            avar, tau = allan_var(self.ctx, ptr, self.n, 3 * self.runs, self.n, fs)
+            if tmp is not None:
+                tmp.free()
+            out[nm] = np.sqrt(avar).reshape(self.runs, 3, -1).transpose(0, 2, 1).copy()
+        return tau, out
+
     def buffer(self, name):
         """Device buffer of a materialised series ('accel', 'gyro', 'odo', 'traj_free', ...), e.g. to feed given=."""
         if name not in self._bufs:

@@ -280,12 +280,24 @@ class Sim(object):
             d.set_mc_results(self.mc)
         # plugins outside the fused kernel: the reference's per-run loop over host copies (user code)
         if hosted:
-            inputs = d.get_data(self.amgr.input)
-            out = self.amgr.run_algo(inputs, list(runs), only=hosted)
+            # plugins that take the device-resident sensor series of all runs at once (demo_algorithms.allan_analysis)
+            on_device = [i for i in hosted if hasattr(algos[i], 'run_device') and sensor_job is not None and count > 0]
+            merged = [{} for _ in self.amgr.output]
+            for i in on_device:
+                name = self.amgr.get_algo_name(i)
+                per_run = algos[i].run_device(sensor_job, fs_imu)
+                for k, res in enumerate(per_run):
+                    for j, slot in enumerate(self.amgr.output_alloc[i]):
+                        merged[slot][name + '_' + str(first + k)] = res[j]
+            rest = [i for i in hosted if i not in on_device]
+            if rest:
+                inputs = d.get_data(self.amgr.input)
+                out = self.amgr.run_algo(inputs, list(runs), only=rest)
+                for j in range(len(merged)):
+                    merged[j].update(out[j])
             for j, oname in enumerate(self.amgr.output):
-                if out[j]:
-                    merged = dict(out[j])
-                    d.add_data(oname, merged)
+                if merged[j]:
+                    d.add_data(oname, merged[j])
 
     def _output_view(self, jobs_by_algo, fused, kinds, names, comp, first, count, quat=False):
         """Mapping '<algo>_<run>' -> (n,3) (or (n,4) quaternion) over the trajectory buffers of all fused plugins."""

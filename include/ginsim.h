@@ -210,6 +210,11 @@ int ginsim_free_integration(ginsim_ctx* ctx, int32_t algo, int32_t ref_frame, do
 int ginsim_allan(ginsim_ctx* ctx, const double* x, int64_t n, int32_t nseries, int64_t series_stride, double fs,
                  double* tau, double* avar, int32_t* ntau, int32_t cap);
 
+/* Device-to-device re-layout of a Monte-Carlo series [ncomp][n][runs] (run fastest, what ginsim_mc_run writes) into
+ * per-run contiguous series [runs][ncomp][n] -- the input layout of ginsim_allan, so that the Allan plugin
+ * (demo_algorithms/allan_analysis.py:33-49) works on the generated sensors without a host round trip. */
+int ginsim_runs_to_series(ginsim_ctx* ctx, const double* series, int32_t ncomp, int64_t n, int64_t runs, double* out);
+
 /* ---- RNG self-test hook: first `count` normal pairs of (seed, run, stream) computed ON DEVICE ---- */
 int ginsim_rng_normals(ginsim_ctx* ctx, uint64_t seed, uint64_t run, uint32_t stream, int64_t count,
                        double* host_z0, double* host_z1, uint32_t* host_words /*[count][4] or NULL*/);

@@ -96,3 +96,43 @@ def test_allan_full_size_white_noise_slope(ctx):
     ad = np.sqrt(avar)
     k = tau <= 10.0
     np.testing.assert_allclose(ad[k], N / np.sqrt(tau[k]), rtol=0.08)
+
+
+@pytest.mark.parametrize('runs', [1, 3])
+def test_sim_allan_flow_stays_on_the_device_and_matches_the_host_plugin(ctx, runs):
+    """demo_allan.py's flow (BASELINE config 5, second half): Sim on a static profile with the Allan plugin.  Inside this
+    package's Sim the plugin gets the device-resident sensor series of all runs (run_device: time-parallel generation for
+    few runs, [3][n][R] -> [R][3][n] re-layout, one Allan call per sensor); the result per run must equal the plugin's
+    plain run() on the host copy of that run's series, and the model's ARW must show up as the -1/2 slope."""
+    import os
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import allan_analysis
+    from conftest import PKG
+    csv = os.path.join(PKG, 'motion_profiles', 'static_1800s.csv')
+    with open(csv) as f:
+        lines = f.read().splitlines()
+    short = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'static_short_%d.csv' % os.getpid())
+    cmd = lines[3].split(',')
+    cmd[7] = '120'                                   # 120 s instead of 1800 s
+    with open(short, 'w') as f:
+        f.write('\n'.join(lines[:3] + [','.join(cmd)]) + '\n')
+    fs = 100.0
+    imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False)
+    algo = allan_analysis.Allan()
+    sim = ins_sim.Sim([fs, 0.0, 0.0], short, ref_frame=1, imu=imu, mode=None, env=None, algorithm=algo, seed=5)
+    sim.run(runs)
+    tau = sim.dmgr.algo_time.data
+    ad_g, ad_a = sim.dmgr.ad_gyro.data, sim.dmgr.ad_accel.data
+    assert len(ad_g) == runs and len(ad_a) == runs
+    host = allan_analysis.Allan()
+    for r in range(runs):
+        key = 'algo0_%d' % r
+        host.run([fs, sim.dmgr.accel.data[r], sim.dmgr.gyro.data[r]])
+        t_h, a_h, g_h = host.get_results()
+        np.testing.assert_allclose(tau[key], t_h, rtol=1e-15)
+        np.testing.assert_allclose(ad_g[key], g_h, rtol=1e-9)
+        np.testing.assert_allclose(ad_a[key], a_h, rtol=1e-9)
+    # ARW 0.25 deg/sqrt(hr) = 7.27e-5 rad/s/sqrt(Hz): AD(tau = 1 s) within the estimator's scatter (12 000 samples)
+    k = int(np.argmin(np.abs(tau['algo0_0'] - 1.0)))
+    assert abs(ad_g['algo0_0'][k, 0] / (0.25 / 60 * np.pi / 180) - 1.0) < 0.25
+    os.remove(short)
