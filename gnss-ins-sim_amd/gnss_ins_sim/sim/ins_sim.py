@@ -25,6 +25,7 @@ Keyword-only extras (defaults keep the reference behaviour):
 """
 import math
 import os
+import sys
 import time
 
 import numpy as np
@@ -122,11 +123,10 @@ class Sim(object):
     @staticmethod
     def _dist():
         """(rank, world, group, exchange device) of the torch.distributed job, or a single-process stand-in."""
-        try:
-            import torch.distributed as dist
-        except ImportError:
-            return 0, 1, None, None
-        if not (dist.is_available() and dist.is_initialized()):
+        # a process group can only exist if the caller imported torch.distributed already: do not pay the ~1 s
+        # `import torch` of a single-GPU script for a question whose answer is then known to be "no"
+        dist = sys.modules.get('torch.distributed')
+        if dist is None or not (dist.is_available() and dist.is_initialized()):
             return 0, 1, None, None
         import torch
         dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))) if dist.get_backend() == 'nccl' \
