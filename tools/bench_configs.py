@@ -18,7 +18,7 @@ acc, gyr = workloads.imu_grade('mid-accuracy')
 out = {'device': ctx.name(), 'hbm_peak_GBps': 8000.0, 'rows': []}
 
 
-def measure(name, profile, fs, rf, R, keep, precision='f64', reps=5, gps=False):
+def measure(name, profile, fs, rf, R, keep, precision='f64', reps=30, gps=False):
     ini, truth, raw = workloads.truth_from_profile(profile, fs, rf, fs_gps=10.0 if gps else 0.0, gps=gps)
     n = truth['ref_accel'].shape[0]
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, seed=1, keep_sensors=keep, keep_traj=keep,
@@ -60,7 +60,7 @@ def measure_given(name, rf, R):
     rep = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, None, None, ini, runs=R, keep_traj=True,
                                given={'gyro': gen.buffer('gyro'), 'accel': gen.buffer('accel')}).run()
     ts = []
-    for _ in range(8):
+    for _ in range(30):
         ctx.timer_begin(); rep.launch(); ts.append(ctx.timer_end())
     ms = float(np.median(ts))
     alg = 120 * R * n + 72 * R
