@@ -27,7 +27,7 @@ if con:
     total = sum(r[2] for r in rows)
     with open(os.path.join(DST, tag + '_kernel_trace_stats.csv'), 'w', newline='') as f:
         w = csv.writer(f)
-        w.writerow(['# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --cpu-baseline-seconds 0'])
+        w.writerow(['# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-baseline-seconds 0   (default: 200 timed + 10 warm-up steps)'])
         w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'min_ns', 'max_ns', 'percent', 'vgpr', 'sgpr', 'lds_bytes',
                     'grid_x', 'workgroup_x'])
         for r in rows:
