@@ -23,7 +23,6 @@ Keyword-only extras (defaults keep the reference behaviour):
                        reference evaluates the WMM model once per run for this vector (pathgen.py:164-168,
                        date = today); that model is outside the accelerated path, so the caller supplies the vector.
 """
-import math
 import os
 import sys
 import time
