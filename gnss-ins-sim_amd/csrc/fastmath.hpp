@@ -28,21 +28,21 @@ GINSIM_FM double vconst(double k) {
 }
 
 struct MathConsts {
-    double l[6];            // log1p series after r: -1/2, 1/3, -1/4, 1/5, -1/6, 1/7
-    double ln2_hi, ln2_lo;
+    double l[5];            // -2 log1p(-r'/2) = r' + r'^2 (1/4 + r'/12 + r'^2/32 + r'^3/80 + r'^4/192)
+    double ln2_hi, ln2_lo;  // -2 ln 2, split
     double sc[5];           // sin: -1/3!, 1/5!, -1/7!, 1/9!, -1/11!   (Box-Muller uses 3, rotate_sincos 5)
     double cc[6];           // cos: -1/2!, 1/4!, ... 1/12!             (Box-Muller uses 3, rotate_sincos 6)
     double ang_bias, ang_scale;     // 0.5 - 2^23 and 2 pi 2^-32: centred remainder of the 32-bit angle -> radians
-    // OPAQUE = true pins the 21 constants in VGPRs (42 registers); false leaves them to the compiler (SGPR literals),
+    // OPAQUE = true pins the 20 constants in VGPRs (40 registers); false leaves them to the compiler (SGPR literals),
     // which is what the two-algorithm kernels need to stay under 256 VGPRs without scratch spills.
     template <bool OPAQUE>
     GINSIM_FM void init() {
         auto vconst = [](double x) { return OPAQUE ? ginsim::vconst(x) : x; };
-        const double lc[6] = {-0.5, 1.0 / 3.0, -0.25, 0.2, -1.0 / 6.0, 1.0 / 7.0};
+        const double lc[5] = {0.25, 1.0 / 12.0, 1.0 / 32.0, 1.0 / 80.0, 1.0 / 192.0};
 #pragma unroll
-        for (int k = 0; k < 6; ++k) l[k] = vconst(lc[k]);
-        ln2_hi = vconst(6.93147180369123816490e-01);
-        ln2_lo = vconst(1.90821492927058770002e-10);
+        for (int k = 0; k < 5; ++k) l[k] = vconst(lc[k]);
+        ln2_hi = vconst(-2.0 * 6.93147180369123816490e-01);
+        ln2_lo = vconst(-2.0 * 1.90821492927058770002e-10);
         const double s[5] = {-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0, -1.0 / 39916800.0};
         const double c[6] = {-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0, 1.0 / 479001600.0};
 #pragma unroll
@@ -54,14 +54,15 @@ struct MathConsts {
     }
 };
 
-// Box-Muller lookup tables, built by every workgroup in LDS (6 KB):
-//   lg[k] = {1/c_k, ln c_k}, c_k within 2^-11 of the centre of the k-th of 128 mantissa bins of m in [sqrt(1/2), sqrt(2))
-//           (c = 1 exactly for the bin that contains 1, so that ln u -> 0 without cancellation as u -> 1);
+// Box-Muller lookup tables, built by every workgroup in LDS (8 KB):
+//   lg[k] = {-2/c_k, -2 ln c_k}, c_k the (rounded) centre of the k-th of 256 mantissa bins of m in [sqrt(1/2), sqrt(2))
+//           (c = 1 exactly for the bin that contains 1, so that ln u -> 0 without cancellation as u -> 1); the factor
+//           -2 of the Box-Muller radius sqrt(-2 ln u) is folded into the table and the series;
 //   sc[i] = {sin a_i, cos a_i}, a_i = 2 pi (i + 1/2) / 256: the centre of the i-th of 256 sectors of the turn.
-// With them log needs a degree-7 series in |r| <= 2^-8 instead of a reciprocal, a quotient correction and a degree-21
+// With them log needs a degree-6 series in |r| <= 2^-9 instead of a reciprocal, a quotient correction and a degree-21
 // series, and sin/cos need two three-term series in |b| <= pi/256 and four FMAs instead of a quadrant reduction, two
 // degree-15/16 series and the swap / sign selects.
-constexpr int kLogBins = 128, kAngBins = 256;
+constexpr int kLogBins = 256, kAngBins = 256;
 struct NormalTables {
     const double2* lg;
     const double2* sc;
@@ -69,17 +70,13 @@ struct NormalTables {
 
 GINSIM_FM void fill_normal_tables(double2* tab, int tid, int nthreads) {
     for (int k = tid; k < kLogBins; k += nthreads) {
-        const int h0 = (k << 13) + 0x3fe6a09e;
-        const double m_lo = __hiloint2double(h0, 0), m_hi = __hiloint2double(h0 + 0x2000, 0);
-        // 1/c is rounded to 10 significant bits and ln c taken for THAT value: m * (1/c) - 1 is then one exactly rounded
-        // fma of the true ratio (no 2^-53 error of a rounded reciprocal, which would be an ABSOLUTE 1e-16 on ln u and
-        // spoil the relative accuracy of small |ln u|); the error of ln c scales with |ln c| ~ |ln u|.
-        double inv = 1.0;
-        if (!(m_lo <= 1.0 && 1.0 < m_hi)) {
-            inv = 1.0 / (0.5 * (m_lo + m_hi));
-            inv = __hiloint2double((__double2hiint(inv) + 0x200) & ~0x3ff, 0);
-        }
-        tab[k] = double2{inv, -log(inv)};
+        const int h0 = (k << 12) + 0x3fe6a09e;
+        const double m_lo = __hiloint2double(h0, 0), m_hi = __hiloint2double(h0 + 0x1000, 0);
+        // ln c is taken for the ROUNDED reciprocal that is stored: m * (1/c) - 1 is then one exactly rounded fma of the
+        // true ratio (a reciprocal rounded independently of ln c would put an ABSOLUTE 1e-16 on ln u and spoil the
+        // relative accuracy of small |ln u|); the error of ln c scales with |ln c| ~ |ln u|.
+        const double inv = (m_lo <= 1.0 && 1.0 < m_hi) ? 1.0 : 1.0 / (0.5 * (m_lo + m_hi));
+        tab[k] = double2{-2.0 * inv, 2.0 * log(inv)};
     }
     for (int i = tid; i < kAngBins; i += nthreads) {
         double sn, cs;
@@ -125,22 +122,23 @@ GINSIM_FM double sqrt_pos(double x) {
     return __builtin_fma(__builtin_fma(-g, g, x), h, g);       // the 2^-23 error of h only scales the correction
 }
 
-// Natural log for 0 < u <= 1 (normal, not denormal: u >= 2^-54 by construction of uniform53).
-//   u = m 2^e, m in [sqrt(1/2), sqrt(2));  ln u = e ln2 + ln c_k + log1p(r),  r = m / c_k - 1,  |r| <= 4.4e-3
+// -2 ln u for 0 < u <= 1 (normal, not denormal: u >= 2^-54 by construction of uniform53): the squared Box-Muller radius.
+//   u = m 2^e, m in [sqrt(1/2), sqrt(2));  -2 ln u = e (-2 ln2) + (-2 ln c_k) + (-2 log1p(r)),  r = m / c_k - 1,
+//   |r| <= 2^-9;  with r' = -2 r = fma(m, -2/c_k, 2):  -2 log1p(r) = r' + r'^2/4 + r'^3/12 + r'^4/32 + r'^5/80 + r'^6/192
 // The exponent/mantissa split and the bin index are integer arithmetic on the high word (no compare/select):
 // adding (0x3ff00000 - 0x3fe6a09e) moves the sqrt(1/2) boundary onto an exponent boundary.
-GINSIM_FM double log_u01(double u, const MathConsts& k, const NormalTables& tab) {
+GINSIM_FM double neg2_log_u01(double u, const MathConsts& k, const NormalTables& tab) {
     uint32_t hx = (uint32_t)__double2hiint(u) + (0x3ff00000u - 0x3fe6a09eu);
     const int e = (int)(hx >> 20) - 0x3ff;
-    const double2 t = tab.lg[(hx >> 13) & (kLogBins - 1)];
+    const double2 t = tab.lg[(hx >> 12) & (kLogBins - 1)];
     hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
     const double m = __hiloint2double((int)hx, __double2loint(u));
-    const double r = __builtin_fma(m, t.x, -1.0);
-    double p = k.l[5];
+    const double r = __builtin_fma(m, t.x, 2.0);
+    double p = k.l[4];
 #pragma unroll
-    for (int i = 4; i >= 0; --i) p = __builtin_fma(p, r, k.l[i]);
+    for (int i = 3; i >= 0; --i) p = __builtin_fma(p, r, k.l[i]);
     const double ed = (double)e;
-    // (e ln2_hi + ln c) + (r + e ln2_lo + r^2 p): the first sum is exact to 1 ulp (ln2_hi has 21 trailing zero bits)
+    // (e (-2 ln2)_hi + (-2 ln c)) + (r' + e (-2 ln2)_lo + r'^2 p): the first sum is exact to 1 ulp
     const double small = __builtin_fma(r * r, p, __builtin_fma(ed, k.ln2_lo, r));
     return __builtin_fma(ed, k.ln2_hi, t.y) + small;
 }

@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a)
                         draw_group(key, 0, (uint32_t)j, u, ang);
                         draw_group(key, 1, (uint32_t)j, u + 3, ang + 3);
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) u[k] = -2.0 * log_u01(u[k], mk, tab);
+                        for (int k = 0; k < 6; ++k) u[k] = neg2_log_u01(u[k], mk, tab);
 #pragma unroll
                         for (int k = 0; k < 6; ++k) u[k] = sqrt_pos(u[k]);
                         double* rb = stage + t * kStepDoubles + lane;

@@ -78,7 +78,7 @@ template <int N>
 __device__ __forceinline__ void box_muller(double (&r)[N], const uint32_t (&ang)[N], double (&z0)[N], double (&z1)[N],
                                            const MathConsts& mk, const NormalTables& tab) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = -2.0 * log_u01(r[k], mk, tab);
+    for (int k = 0; k < N; ++k) r[k] = neg2_log_u01(r[k], mk, tab);
 #pragma unroll
     for (int k = 0; k < N; ++k) r[k] = sqrt_pos(r[k]);
 #pragma unroll
