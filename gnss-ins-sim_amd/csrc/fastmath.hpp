@@ -30,10 +30,11 @@ GINSIM_FM double vconst(double k) {
 struct MathConsts {
     double l[5];            // -2 log1p(-r'/2) = r' + r'^2 (1/4 + r'/12 + r'^2/32 + r'^3/80 + r'^4/192)
     double ln2_hi, ln2_lo;  // -2 ln 2, split
-    double sc[5];           // sin: -1/3!, 1/5!, -1/7!, 1/9!, -1/11!   (Box-Muller uses 3, rotate_sincos 5)
-    double cc[6];           // cos: -1/2!, 1/4!, ... 1/12!             (Box-Muller uses 3, rotate_sincos 6)
-    double ang_bias, ang_scale;     // 0.5 - 2^23 and 2 pi 2^-32: centred remainder of the 32-bit angle -> radians
-    // OPAQUE = true pins the 20 constants in VGPRs (40 registers); false leaves them to the compiler (SGPR literals),
+    double sc[5];           // sin: -1/3!, 1/5!, -1/7!, 1/9!, -1/11!   (Box-Muller uses 2, rotate_sincos 5)
+    double cc[6];           // cos: -1/2!, 1/4!, ... 1/12!             (Box-Muller uses 2, rotate_sincos 6)
+    double ang_bias, ang_scale;     // 0.5 - 2^22 and 2 pi 2^-32: centred remainder of the 32-bit angle -> radians
+    double u_hi, u_lo, u_half;      // 2^-21, 2^-53, 2^-54: uniform53 as two FMAs
+    // OPAQUE = true pins the 23 constants in VGPRs (46 registers); false leaves them to the compiler (SGPR literals),
     // which is what the two-algorithm kernels need to stay under 256 VGPRs without scratch spills.
     template <bool OPAQUE>
     GINSIM_FM void init() {
@@ -49,20 +50,23 @@ struct MathConsts {
         for (int k = 0; k < 5; ++k) sc[k] = vconst(s[k]);
 #pragma unroll
         for (int k = 0; k < 6; ++k) cc[k] = vconst(c[k]);
-        ang_bias = vconst(0.5 - 8388608.0);
+        ang_bias = vconst(0.5 - 4194304.0);
         ang_scale = vconst(6.283185307179586476925 * 0x1.0p-32);
+        u_hi = vconst(0x1.0p-21);
+        u_lo = vconst(0x1.0p-53);
+        u_half = vconst(0x1.0p-54);
     }
 };
 
-// Box-Muller lookup tables, built by every workgroup in LDS (8 KB):
+// Box-Muller lookup tables, built by every workgroup in LDS (12 KB):
 //   lg[k] = {-2/c_k, -2 ln c_k}, c_k the (rounded) centre of the k-th of 256 mantissa bins of m in [sqrt(1/2), sqrt(2))
 //           (c = 1 exactly for the bin that contains 1, so that ln u -> 0 without cancellation as u -> 1); the factor
 //           -2 of the Box-Muller radius sqrt(-2 ln u) is folded into the table and the series;
-//   sc[i] = {sin a_i, cos a_i}, a_i = 2 pi (i + 1/2) / 256: the centre of the i-th of 256 sectors of the turn.
+//   sc[i] = {sin a_i, cos a_i}, a_i = 2 pi (i + 1/2) / 512: the centre of the i-th of 512 sectors of the turn.
 // With them log needs a degree-6 series in |r| <= 2^-9 instead of a reciprocal, a quotient correction and a degree-21
-// series, and sin/cos need two three-term series in |b| <= pi/256 and four FMAs instead of a quadrant reduction, two
+// series, and sin/cos need two two-term series in |b| <= pi/512 and four FMAs instead of a quadrant reduction, two
 // degree-15/16 series and the swap / sign selects.
-constexpr int kLogBins = 256, kAngBins = 256;
+constexpr int kLogBins = 256, kAngBins = 512;
 struct NormalTables {
     const double2* lg;
     const double2* sc;
@@ -75,12 +79,14 @@ GINSIM_FM void fill_normal_tables(double2* tab, int tid, int nthreads) {
         // ln c is taken for the ROUNDED reciprocal that is stored: m * (1/c) - 1 is then one exactly rounded fma of the
         // true ratio (a reciprocal rounded independently of ln c would put an ABSOLUTE 1e-16 on ln u and spoil the
         // relative accuracy of small |ln u|); the error of ln c scales with |ln c| ~ |ln u|.
-        const double inv = (m_lo <= 1.0 && 1.0 < m_hi) ? 1.0 : 1.0 / (0.5 * (m_lo + m_hi));
-        tab[k] = double2{-2.0 * inv, 2.0 * log(inv)};
+        const bool unit = m_lo <= 1.0 && 1.0 < m_hi;
+        const double inv = unit ? 1.0 : 1.0 / (0.5 * (m_lo + m_hi));
+        // the unit bin adds 2^-200 instead of 0: absorbed by every other value, and u = 1 gives radius 2^-100, not 0/0
+        tab[k] = double2{-2.0 * inv, unit ? 0x1.0p-200 : 2.0 * log(inv)};
     }
     for (int i = tid; i < kAngBins; i += nthreads) {
         double sn, cs;
-        sincospi((double)(2 * i + 1) * (1.0 / 256.0), &sn, &cs);
+        sincospi((double)(2 * i + 1) * (1.0 / kAngBins), &sn, &cs);
         tab[kLogBins + i] = double2{sn, cs};
     }
 }
@@ -108,12 +114,10 @@ GINSIM_FM double rsqrt_nr(double x) {
     return __builtin_fma(y, __builtin_fma(-0.5 * y, x * y, 0.5), y);
 }
 
-// sqrt(x) for finite x >= 0 well inside the normal range (here x = -2 ln u <= 75.5); x below 2^-200 (only u = 1) is
-// lifted to 2^-200, i.e. returns 2^-100 instead of 0.  v_rsq_f64 estimate, one Goldschmidt step, one residual
-// correction: <= 1 ulp, 7 VALU + v_rsq.  The compiler's sqrt() adds range scaling, a second correction and an inf/0
-// select (17 VALU).
+// sqrt(x) for finite x > 0 well inside the normal range (here x = -2 ln u in [2^-200, 75.5]: the log table returns
+// 2^-200 instead of 0 for u = 1).  v_rsq_f64 estimate, one Goldschmidt step, one residual correction: <= 1 ulp,
+// 6 VALU + v_rsq.  The compiler's sqrt() adds range scaling, a second correction and an inf/0 select (17 VALU).
 GINSIM_FM double sqrt_pos(double x) {
-    x = __builtin_fmax(x, 0x1.0p-200);
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y;
     const double h = 0.5 * y;
@@ -143,18 +147,15 @@ GINSIM_FM double neg2_log_u01(double u, const MathConsts& k, const NormalTables&
     return __builtin_fma(ed, k.ln2_hi, t.y) + small;
 }
 
-// sin and cos of the Box-Muller angle 2 pi (w + 1/2) 2^-32, w one Philox word: sector i = top 8 bits of w,
-// b = centred remainder in radians (|b| <= pi/256), angle = a_i + b.
+// sin and cos of the Box-Muller angle 2 pi (w + 1/2) 2^-32, w one Philox word: sector i = top 9 bits of w,
+// b = centred remainder in radians (|b| <= pi/512), angle = a_i + b.  sin b = b + b^3 (-1/6 + b^2/120) (next term
+// 6e-20), cos b - 1 = b^2 (-1/2 + b^2/24) (next term 7e-17).
 GINSIM_FM void sincos_turn32(uint32_t w, double& s, double& c, const MathConsts& k, const NormalTables& tab) {
-    const double2 t = tab.sc[w >> 24];
-    const double b = ((double)(w & 0xffffffu) + k.ang_bias) * k.ang_scale;     // the sum is exact
+    const double2 t = tab.sc[w >> 23];
+    const double b = ((double)(w & 0x7fffffu) + k.ang_bias) * k.ang_scale;     // the sum is exact
     const double tt = b * b;
-    double ps = __builtin_fma(tt, k.sc[2], k.sc[1]);
-    ps = __builtin_fma(tt, ps, k.sc[0]);
-    const double sb = __builtin_fma(b * tt, ps, b);           // sin b
-    double pc = __builtin_fma(tt, k.cc[2], k.cc[1]);
-    pc = __builtin_fma(tt, pc, k.cc[0]);
-    const double cm = tt * pc;                                // cos b - 1
+    const double sb = __builtin_fma(b * tt, __builtin_fma(tt, k.sc[1], k.sc[0]), b);       // sin b
+    const double cm = tt * __builtin_fma(tt, k.cc[1], k.cc[0]);                            // cos b - 1
     s = t.x + __builtin_fma(t.y, sb, t.x * cm);
     c = t.y + __builtin_fma(-t.x, sb, t.y * cm);
 }

@@ -345,8 +345,8 @@ __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a)
                     if (j < n_noise) {
                         double u[6];
                         uint32_t ang[6];
-                        draw_group(key, 0, (uint32_t)j, u, ang);
-                        draw_group(key, 1, (uint32_t)j, u + 3, ang + 3);
+                        draw_group(key, 0, (uint32_t)j, u, ang, mk);
+                        draw_group(key, 1, (uint32_t)j, u + 3, ang + 3, mk);
 #pragma unroll
                         for (int k = 0; k < 6; ++k) u[k] = neg2_log_u01(u[k], mk, tab);
 #pragma unroll
@@ -729,7 +729,7 @@ __global__ void box_muller_kernel(const uint32_t* __restrict__ words, int64_t co
     mk.init<true>();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    double r[1] = {uniform53(words[4 * i], words[4 * i + 1])}, a[1], b[1];
+    double r[1] = {uniform53(words[4 * i], words[4 * i + 1], mk)}, a[1], b[1];
     const uint32_t ang[1] = {words[4 * i + 2]};
     box_muller<1>(r, ang, a, b, mk, tab);
     z0[i] = a[0];

@@ -45,13 +45,12 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 }
 
 // (0,1] uniform with 53 significant bits from two words: u = ((hi:lo >> 11) + 0.5) * 2^-53, rounded once (the largest
-// of the 2^53 values rounds to 1.0).  v + 0.5 rounds exactly like the scaled sum and the power of two is exact, so
-// add + ldexp (two inline constants) gives the bits of fma(v, 2^-53, 2^-54) without materialising the constants.
-__device__ __forceinline__ double uniform53(uint32_t lo, uint32_t hi) {
+// of the 2^53 values rounds to 1.0).  top 2^-21 + (low 2^-53 + 2^-54): the inner FMA is exact (33 bits), the outer one
+// rounds the exact sum once -- the bits of (v + 0.5) 2^-53 in two FMAs on three register constants.
+__device__ __forceinline__ double uniform53(uint32_t lo, uint32_t hi, const MathConsts& k) {
     const uint32_t top = hi >> 11;                         // 21 bits
     const uint32_t low = (hi << 21) | (lo >> 11);          // 32 bits (one v_alignbit_b32)
-    const double v = __builtin_fma((double)top, 4294967296.0, (double)low);     // exact, < 2^53
-    return __builtin_amdgcn_ldexp(v + 0.5, -53);
+    return __builtin_fma((double)top, k.u_hi, __builtin_fma((double)low, k.u_lo, k.u_half));
 }
 
 struct RngKey {
@@ -60,14 +59,15 @@ struct RngKey {
 };
 
 // The three streams of group g at sample j: radius uniforms u[3] and angle words ang[3] from two Philox blocks.
-__device__ __forceinline__ void draw_group(const RngKey& key, uint32_t g, uint32_t j, double* u, uint32_t* ang) {
+__device__ __forceinline__ void draw_group(const RngKey& key, uint32_t g, uint32_t j, double* u, uint32_t* ang,
+                                           const MathConsts& mk) {
     const u32x4 A = philox4x32_10(j, 2 * g, key.r0, key.r1, key.k0, key.k1);
     const u32x4 B = philox4x32_10(j, 2 * g + 1, key.r0, key.r1, key.k0, key.k1);
-    u[0] = uniform53(A.x, A.y);
+    u[0] = uniform53(A.x, A.y, mk);
     ang[0] = A.z;
-    u[1] = uniform53(A.w, B.x);
+    u[1] = uniform53(A.w, B.x, mk);
     ang[1] = B.y;
-    u[2] = uniform53(((A.x & 0x7ffu) << 21) | ((A.w & 0x7ffu) << 10), B.z);     // the spare low bits of A.x and A.w
+    u[2] = uniform53(((A.x & 0x7ffu) << 21) | ((A.w & 0x7ffu) << 10), B.z, mk);     // the spare low bits of A.x and A.w
     ang[2] = B.w;
 }
 
@@ -98,7 +98,7 @@ __device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, 
     double r[N];
     uint32_t ang[N];
 #pragma unroll
-    for (int g = 0; g < N / 3; ++g) draw_group(key, first / 3 + g, j, r + 3 * g, ang + 3 * g);
+    for (int g = 0; g < N / 3; ++g) draw_group(key, first / 3 + g, j, r + 3 * g, ang + 3 * g, mk);
     box_muller<N>(r, ang, z0, z1, mk, tab);
 }
 
@@ -110,12 +110,12 @@ __device__ __forceinline__ void normal_pair(const RngKey& key, uint32_t stream, 
     uint32_t ang[1];
     if (slot == 0) {
         const u32x4 A = philox4x32_10(j, 2 * g, key.r0, key.r1, key.k0, key.k1);
-        r[0] = uniform53(A.x, A.y);
+        r[0] = uniform53(A.x, A.y, mk);
         ang[0] = A.z;
     } else {
         double u[3];
         uint32_t w[3];
-        draw_group(key, g, j, u, w);
+        draw_group(key, g, j, u, w, mk);
         r[0] = slot == 1 ? u[1] : u[2];
         ang[0] = slot == 1 ? w[1] : w[2];
     }
