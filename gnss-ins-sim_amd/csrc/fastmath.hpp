@@ -32,7 +32,7 @@ struct MathConsts {
     double ln2_hi, ln2_lo;  // -2 ln 2, split
     double sc[5];           // sin: -1/3!, 1/5!, -1/7!, 1/9!, -1/11!   (Box-Muller uses 2, rotate_sincos 5)
     double cc[6];           // cos: -1/2!, 1/4!, ... 1/12!             (Box-Muller uses 2, rotate_sincos 6)
-    double ang_bias, ang_scale;     // 0.5 - 2^22 and 2 pi 2^-32: centred remainder of the 32-bit angle -> radians
+    double ang_bias, ang_scale;     // (0.5 - 2^22) 2 pi 2^-32 and 2 pi 2^-32: centred remainder of the 32-bit angle -> radians
     double u_hi, u_lo, u_half;      // 2^-21, 2^-53, 2^-54: uniform53 as two FMAs
     // OPAQUE = true pins the 23 constants in VGPRs (46 registers); false leaves them to the compiler (SGPR literals),
     // which is what the two-algorithm kernels need to stay under 256 VGPRs without scratch spills.
@@ -50,7 +50,7 @@ struct MathConsts {
         for (int k = 0; k < 5; ++k) sc[k] = vconst(s[k]);
 #pragma unroll
         for (int k = 0; k < 6; ++k) cc[k] = vconst(c[k]);
-        ang_bias = vconst(0.5 - 4194304.0);
+        ang_bias = vconst((0.5 - 4194304.0) * (6.283185307179586476925 * 0x1.0p-32));
         ang_scale = vconst(6.283185307179586476925 * 0x1.0p-32);
         u_hi = vconst(0x1.0p-21);
         u_lo = vconst(0x1.0p-53);
@@ -152,7 +152,7 @@ GINSIM_FM double neg2_log_u01(double u, const MathConsts& k, const NormalTables&
 // 6e-20), cos b - 1 = b^2 (-1/2 + b^2/24) (next term 7e-17).
 GINSIM_FM void sincos_turn32(uint32_t w, double& s, double& c, const MathConsts& k, const NormalTables& tab) {
     const double2 t = tab.sc[w >> 23];
-    const double b = ((double)(w & 0x7fffffu) + k.ang_bias) * k.ang_scale;     // the sum is exact
+    const double b = __builtin_fma((double)(w & 0x7fffffu), k.ang_scale, k.ang_bias);      // centred remainder, radians
     const double tt = b * b;
     const double sb = __builtin_fma(b * tt, __builtin_fma(tt, k.sc[1], k.sc[0]), b);       // sin b
     const double cm = tt * __builtin_fma(tt, k.cc[1], k.cc[0]);                            // cos b - 1
