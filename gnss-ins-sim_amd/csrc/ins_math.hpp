@@ -109,7 +109,8 @@ struct Att {
     // The angles themselves are propagated exactly as the reference does; their cached sin/cos are ROTATED by
     // the step (angle-addition with short sin/cos(d) series, fastmath.hpp) instead of re-evaluated, and are
     // re-evaluated exactly when `resync` is set (every kTrigResync steps, wave-uniform), when the pitch folds
-    // over +-pi/2, or when a step exceeds 0.25 rad.  +-2pi wraps leave the trig untouched.
+    // over +-pi/2, or when a step exceeds 0.25 rad.  +-2pi wraps leave the trig untouched.  When no lane of the
+    // wavefront steps by more than 2^-6 rad the rotation uses the three-term series.
     GINSIM_HD void step(const Vec3& w, double dt, bool resync, const MathConsts& mk) {
         const double q = w.z * cr + w.y * sr;
         const double icp = rcp_n1(cp);      // 2^-46 relative on a rate that is multiplied by dt: far below the state's ulp
@@ -131,9 +132,15 @@ struct Att {
             if (r > kPi) r -= kTwoPi; else if (r < -kPi) r += kTwoPi;
             set(y, p, r);
         } else {
-            rotate_sincos(dy, sy, cy, mk);
-            rotate_sincos(dp, sp, cp, mk);
-            rotate_sincos(dr, sr, cr, mk);
+            if (__all(big <= 0x1.0p-6)) {       // wave-uniform: the short series when every lane's step is small
+                rotate_sincos_small(dy, sy, cy, mk);
+                rotate_sincos_small(dp, sp, cp, mk);
+                rotate_sincos_small(dr, sr, cr, mk);
+            } else {
+                rotate_sincos(dy, sy, cy, mk);
+                rotate_sincos(dp, sp, cp, mk);
+                rotate_sincos(dr, sr, cr, mk);
+            }
             if (y > kPi) y -= kTwoPi; else if (y < -kPi) y += kTwoPi;
             if (r > kPi) r -= kTwoPi; else if (r < -kPi) r += kTwoPi;
             yaw = y; pit = p; rol = r;

@@ -114,6 +114,7 @@ __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& a
         }
         const double dlat = v.x * irm * dt;
         if (resync || !(fabs(dlat) <= 0.25)) sincos(s.pos.x + dlat, &s.sl, &s.cl);
+        else if (__all(fabs(dlat) <= 0x1.0p-6)) rotate_sincos_small(dlat, s.sl, s.cl, mk);
         else rotate_sincos(dlat, s.sl, s.cl, mk);
         s.pos.x += dlat;
         s.pos.y += v.y * irn * icl * dt;
