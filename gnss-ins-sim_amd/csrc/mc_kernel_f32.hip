@@ -5,8 +5,8 @@
 //     velocity components) are Kahan-compensated so that 1e5 forward-Euler steps do not random-walk in the last bit;
 //   * POSITION is accumulated in fp64 (3 adds per step): ECEF (4.7e6 m) and LLA radians do not fit fp32 (ulp 0.5 m /
 //     6e-8 rad), and the series written to HBM is the fp32 DISPLACEMENT from the initial position;
-//   * noise: the same Philox4x32-10 counter stream, but each 32-bit word feeds one 23-bit uniform
-//     u = (2 (w >> 9) + 1) 2^-24, so one Philox block gives two Box-Muller pairs (4 normals) evaluated with the
+//   * noise: the same Philox4x32-10 generator, but a Box-Muller pair takes a 23-bit radius uniform
+//     u = (2 (w >> 9) + 1) 2^-24 and an 18-bit angle, so TWO blocks give the six pairs (12 normals) of a step, evaluated with the
 //     hardware v_log_f32 / v_sin_f32 / v_cos_f32 units.  |z| <= 5.77 sigma.  This is a different (coarser) noise
 //     stream than the fp64 path; run-by-run comparison with fp64 is therefore done noise-free and in given-data
 //     form, and with noise the comparison is statistical (tests/test_gpu_fp32.py states the tolerances).
@@ -120,6 +120,27 @@ __device__ __forceinline__ void normals4(const RngKey& key, uint32_t stream, uin
     z[1] = r0 * __builtin_amdgcn_sinf(u1);
     z[2] = r1 * __builtin_amdgcn_cosf(u3);
     z[3] = r1 * __builtin_amdgcn_sinf(u3);
+}
+
+// The twelve IMU normals of a step from TWO Philox blocks (256 bits): six Box-Muller pairs of a 23-bit radius uniform
+// (top 23 bits of A0..A3, B0, B1) and an 18-bit angle uniform cut from B2, B3 and the spare low bits of the radius
+// words.  z[2p] = r_p cos, z[2p+1] = r_p sin.
+__device__ __forceinline__ void normals12(const RngKey& key, uint32_t j, float (&z)[12]) {
+    const u32x4 A = philox4x32_10(j, 0u, key.r0, key.r1, key.k0, key.k1);
+    const u32x4 B = philox4x32_10(j, 1u, key.r0, key.r1, key.k0, key.k1);
+    const uint32_t rw[6] = {A.x, A.y, A.z, A.w, B.x, B.y};
+    const uint32_t aw[6] = {B.z >> 14, B.w >> 14,
+                            ((B.z & 0x3fffu) << 4) | (A.x & 0xfu), ((B.w & 0x3fffu) << 4) | (A.y & 0xfu),
+                            ((A.z & 0x1ffu) << 9) | (A.w & 0x1ffu), ((B.x & 0x1ffu) << 9) | (B.y & 0x1ffu)};
+    float rad[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) rad[p] = __builtin_amdgcn_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(uniform23(rw[p])));
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        const float rev = __builtin_fmaf((float)aw[p], 0x1.0p-18f, 0x1.0p-19f);      // (k + 1/2) 2^-18 revolutions
+        z[2 * p] = rad[p] * __builtin_amdgcn_cosf(rev);
+        z[2 * p + 1] = rad[p] * __builtin_amdgcn_sinf(rev);
+    }
 }
 
 struct Nav {
@@ -319,13 +340,11 @@ __global__ void __launch_bounds__(256) mc_kernel_f32(const ginsim_mc_params a) {
         // wave-uniform truth of this step, requested before the noise is generated (scalar-load latency hidden)
         const double ta[3] = {ref_a[3 * j], ref_a[3 * j + 1], ref_a[3 * j + 2]};
         const double tg[3] = {ref_g[3 * j], ref_g[3 * j + 1], ref_g[3 * j + 2]};
-        // 12 normals from streams 0..2 (4 each): accel drift xyz + white x | accel white yz + gyro drift xy | gyro drift z + white xyz
-        float z0[4], z1[4], z2[4];
-        normals4(key, S_ACC_D_XY, jj, z0);
-        normals4(key, S_ACC_DZ_WX, jj, z1);
-        normals4(key, S_ACC_W_YZ, jj, z2);
-        const float zda[3] = {z0[0], z0[1], z0[2]}, zwa[3] = {z0[3], z1[0], z1[1]};
-        const float zdg[3] = {z1[2], z1[3], z2[0]}, zwg[3] = {z2[1], z2[2], z2[3]};
+        // 12 normals from two Philox blocks: accel drift xyz, accel white xyz, gyro drift xyz, gyro white xyz
+        float z[12];
+        normals12(key, jj, z);
+        const float zda[3] = {z[0], z[1], z[2]}, zwa[3] = {z[3], z[4], z[5]};
+        const float zdg[3] = {z[6], z[7], z[8]}, zwg[3] = {z[9], z[10], z[11]};
         const V3 acc = sense3(ta, ma, da, zda, zwa);
         const V3 gyr = sense3(tg, mg, dg, zdg, zwg);
         if (o_acc) { st(o_acc + off, acc.x); st(o_acc + plane + off, acc.y); st(o_acc + 2 * plane + off, acc.z); }
@@ -353,11 +372,11 @@ __global__ void __launch_bounds__(256) mc_kernel_f32(const ginsim_mc_params a) {
 }
 
 // Wave-specialised variant for batches of <= 1024 wavefronts (see mc_kernel_split in mc_kernel.hip for the rationale):
-// waves 4-7 produce the normals of streams 0 and 1 (8 of the 12 per step) into an LDS ring, waves 0-3 consume them,
-// generate stream 2 themselves and do sensors, mechanisation and stores.  Bit-identical to mc_kernel_f32.
-constexpr int kSplitTileF = 8;
+// waves 4-7 produce the twelve normals of a step (two Philox blocks, six Box-Muller pairs) into an LDS ring, waves 0-3
+// consume them and do sensors, mechanisation and stores.  Bit-identical to mc_kernel_f32.
+constexpr int kSplitTileF = 6;
 constexpr int kSplitRunsF = 256;
-constexpr size_t kSplitLdsF = sizeof(float) * 2 * kSplitTileF * 8 * kSplitRunsF;       // 128 KiB
+constexpr size_t kSplitLdsF = sizeof(float) * 2 * kSplitTileF * 12 * kSplitRunsF;      // 144 KiB
 
 template <int RF, int ALGOS>
 __global__ void __launch_bounds__(512) mc_kernel_f32_split(const ginsim_mc_params a) {
@@ -383,19 +402,15 @@ __global__ void __launch_bounds__(512) mc_kernel_f32_split(const ginsim_mc_param
     if (producer) {
         for (int64_t i = 0; i <= ntiles; ++i) {
             if (i < ntiles && active) {
-                float* zb = zringf + (i & 1) * (kSplitTileF * 8 * kSplitRunsF) + lane;
+                float* zb = zringf + (i & 1) * (kSplitTileF * 12 * kSplitRunsF) + lane;
 #pragma unroll
                 for (int t = 0; t < kSplitTileF; ++t) {
                     const int64_t j = i * kSplitTileF + t;
                     if (j < n_noise) {
-                        float z0[4], z1[4];
-                        normals4(key, S_ACC_D_XY, (uint32_t)j, z0);
-                        normals4(key, S_ACC_DZ_WX, (uint32_t)j, z1);
+                        float z[12];
+                        normals12(key, (uint32_t)j, z);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            zb[(t * 8 + k) * kSplitRunsF] = z0[k];
-                            zb[(t * 8 + 4 + k) * kSplitRunsF] = z1[k];
-                        }
+                        for (int k = 0; k < 12; ++k) zb[(t * 12 + k) * kSplitRunsF] = z[k];
                     }
                 }
             }
@@ -423,7 +438,7 @@ __global__ void __launch_bounds__(512) mc_kernel_f32_split(const ginsim_mc_param
     }
     for (int64_t i = 0; i <= ntiles; ++i) {
         if (i >= 1 && active) {
-            const float* zb = zringf + ((i - 1) & 1) * (kSplitTileF * 8 * kSplitRunsF) + lane;
+            const float* zb = zringf + ((i - 1) & 1) * (kSplitTileF * 12 * kSplitRunsF) + lane;
 #pragma unroll 1
             for (int t = 0; t < kSplitTileF; ++t) {
                 const int64_t j = (i - 1) * kSplitTileF + t;
@@ -432,15 +447,11 @@ __global__ void __launch_bounds__(512) mc_kernel_f32_split(const ginsim_mc_param
                 const bool last = (j == n - 1);
                 const double ta[3] = {ref_a[3 * j], ref_a[3 * j + 1], ref_a[3 * j + 2]};
                 const double tg[3] = {ref_g[3 * j], ref_g[3 * j + 1], ref_g[3 * j + 2]};
-                float z0[4], z1[4], z2[4];
+                float z[12];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    z0[k] = zb[(t * 8 + k) * kSplitRunsF];
-                    z1[k] = zb[(t * 8 + 4 + k) * kSplitRunsF];
-                }
-                normals4(key, S_ACC_W_YZ, (uint32_t)j, z2);
-                const float zda[3] = {z0[0], z0[1], z0[2]}, zwa[3] = {z0[3], z1[0], z1[1]};
-                const float zdg[3] = {z1[2], z1[3], z2[0]}, zwg[3] = {z2[1], z2[2], z2[3]};
+                for (int k = 0; k < 12; ++k) z[k] = zb[(t * 12 + k) * kSplitRunsF];
+                const float zda[3] = {z[0], z[1], z[2]}, zwa[3] = {z[3], z[4], z[5]};
+                const float zdg[3] = {z[6], z[7], z[8]}, zwg[3] = {z[9], z[10], z[11]};
                 const V3 acc = sense3(ta, ma, da, zda, zwa);
                 const V3 gyr = sense3(tg, mg, dg, zdg, zwg);
                 if (o_acc) { st(o_acc + off, acc.x); st(o_acc + plane + off, acc.y); st(o_acc + 2 * plane + off, acc.z); }
