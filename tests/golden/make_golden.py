@@ -282,6 +282,43 @@ def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=
     save(name, **out)
 
 
+def csv_case():
+    """The files Sim.results(data_dir) writes (sim_data.py:117-165 via ins_data_manager.save_data): names, header lines
+    and a few rows of every file, from the unmodified reference on a two-run, two-algorithm, rf 0 case with GPS + odo."""
+    import tempfile
+    csv = MOTION + 'motion_def-90deg_turn.csv'
+    odo_opt = {'scale': 0.999, 'stdv': 0.1}
+    imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=True, odo=True, odo_opt=odo_opt)
+    ini = read_ini(csv)
+    objs = [free_integration.FreeIntegration(ini.copy()), free_integration_odo.FreeIntegration(ini.copy())]
+    sim = ins_sim.Sim([100.0, 10.0, 0.0], csv, ref_frame=0, imu=imu, algorithm=objs)
+    shim = RandnShim(SEED, 1000, imu.accel_err['b_corr'], imu.gyro_err['b_corr'], gps_m=100, mag=False, odo=True)
+    with injected(shim):
+        sim.run(2)
+    d = tempfile.mkdtemp()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim.results(d, err_stats_start=-1)
+    names, headers, shapes, rows_kept, values = [], [], [], [], {}
+    for f in sorted(os.listdir(d)):
+        if not f.endswith('.csv'):
+            continue
+        with open(os.path.join(d, f)) as fh:
+            head = fh.readline().rstrip('\n')
+        a = np.atleast_1d(np.genfromtxt(os.path.join(d, f), delimiter=',', skip_header=1))
+        if a.ndim == 1:
+            a = a[:, None]
+        k = rows(a.shape[0], max(1, a.shape[0] // 6))
+        names.append(f)
+        headers.append(head)
+        shapes.append(a.shape)
+        values['rows_' + f] = k
+        values['data_' + f] = a[k]
+    save('csv_files_rf0', seed=SEED, names=np.array(names), headers=np.array(headers), shapes=np.array(shapes),
+         ini=ini, odo_scale=odo_opt['scale'], odo_stdv=odo_opt['stdv'], **values)
+    print('   csv: %d files: %s' % (len(names), ' '.join(names)))
+
+
 def allan_case():
     n, fs = 360000, 100.0
     x = 0.3 * philox.normal_pair(SEED, 7, 5, np.arange(n, dtype=np.uint64))[0] \
@@ -313,5 +350,6 @@ if __name__ == '__main__':
                  'mag_hi': np.array([5.0, -8.0, 12.0]), 'mag_std': np.array([0.2, 0.1, 0.3])})
     for rf in (0, 1):
         t3_case('t3_mag9_gps_rf%d' % rf, rf, dict(mag9), True, None, ['fi'], 2, fs_gps=10.0, axis=9)
+    csv_case()
     allan_case()
     t2_long_drive()

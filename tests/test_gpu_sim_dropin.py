@@ -1,6 +1,8 @@
 """The drop-in surface on the GPU: the calling sequence of the reference's demo_free_integration.py, verbatim
 except for the motion-profile path, reproduces the statistics the UNMODIFIED reference printed for the same
 injected noise (golden t3_demo_rf1: Sim.run(4), algorithm=[odo, free], ref_frame=1)."""
+import contextlib
+import io
 import math
 import os
 
@@ -106,3 +108,39 @@ def test_stats_only_large_run_and_seed_convention():
     att_std = out[0]['att_euler']['std']
     assert np.all(np.abs(att_std - 0.01318) < 0.01318 * 0.03), att_std          # ARW*sqrt(T), deg
     assert 'accel' not in sim.dmgr.available
+
+
+def test_saved_csv_files_match_the_reference(tmp_path):
+    """Sim.results(data_dir): same file names, same header lines ('legend (unit)', sim_data.py:117-165) and the same numbers
+    as the files the unmodified reference wrote for this case (two runs, two algorithms, rf 0, GPS + odometer; the
+    reference fed the engine's normals).  Angles are in degrees in the files, so differences modulo 360 count."""
+    from conftest import load_golden
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration, free_integration_odo
+    g = load_golden('csv_files_rf0')
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=True, odo=True,
+                        odo_opt={'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])})
+    ini = g['ini']
+    algos = [free_integration.FreeIntegration(ini.copy()), free_integration_odo.FreeIntegration(ini.copy())]
+    sim = ins_sim.Sim([100.0, 10.0, 0.0], csv, ref_frame=0, imu=imu, mode=None, env=None, algorithm=algos, seed=int(g['seed']))
+    sim.run(2)
+    out = str(tmp_path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim.results(out, err_stats_start=-1)
+    ours = sorted(f for f in os.listdir(out) if f.endswith('.csv'))
+    want = [str(x) for x in g['names']]
+    assert ours == want
+    for f, head, shape in zip(want, g['headers'], g['shapes']):
+        with open(os.path.join(out, f)) as fh:
+            assert fh.readline().rstrip('\n') == str(head), f
+        a = np.atleast_1d(np.genfromtxt(os.path.join(out, f), delimiter=',', skip_header=1))
+        if a.ndim == 1:
+            a = a[:, None]
+        assert a.shape == tuple(shape), f
+        got, ref = a[g['rows_' + f]], g['data_' + f]
+        if '(deg)' in str(head) and 'pos' not in f and 'gps' not in f:
+            d = np.mod(got - ref + 180.0, 360.0) - 180.0
+            assert np.max(np.abs(d)) < 1e-7, f
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-9, err_msg=f)
