@@ -176,12 +176,15 @@ __device__ __forceinline__ uniform_ptr as_uniform(const double* p) {
 // Gauss-Markov update d[j+1] = a d[j] + b N[j] (pathgen.py:589-590).
 __device__ __forceinline__ Vec3 load3(uniform_ptr ref, int64_t j) { return Vec3{ref[3 * j], ref[3 * j + 1], ref[3 * j + 2]}; }
 
+// WD = false: the launcher saw no axis with an infinite correlation time (white_drift) in either sensor, the usual
+// case, and the six wave-uniform selects per sensor are compiled out.
+template <bool WD = true>
 __device__ __forceinline__ Vec3 sense3(const Vec3& truth, model_ptr m, Vec3& drift, const Vec3& zd,
                                        const Vec3& zw) {
     const double bx = m->gm_b[0] * zd.x, by = m->gm_b[1] * zd.y, bz = m->gm_b[2] * zd.z;
-    const double dx = m->white_drift[0] ? bx : drift.x;
-    const double dy = m->white_drift[1] ? by : drift.y;
-    const double dz = m->white_drift[2] ? bz : drift.z;
+    const double dx = (WD && m->white_drift[0]) ? bx : drift.x;
+    const double dy = (WD && m->white_drift[1]) ? by : drift.y;
+    const double dz = (WD && m->white_drift[2]) ? bz : drift.z;
     Vec3 o;
     o.x = truth.x + m->bias[0] + dx + m->white[0] * zw.x;
     o.y = truth.y + m->bias[1] + dy + m->white[1] * zw.y;
@@ -192,7 +195,7 @@ __device__ __forceinline__ Vec3 sense3(const Vec3& truth, model_ptr m, Vec3& dri
     return o;
 }
 
-template <int RF, int ALGOS, bool GIVEN>
+template <int RF, int ALGOS, bool GIVEN, bool WD>
 __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t* trace = nullptr;
@@ -256,16 +259,16 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
                 double z0[6], z1[6];
                 normal_pairs<6>(key, S_ACC_D_XY, jj, z0, z1, mk, tab);
                 const params_ptr kp = kernarg_params();
-                acc = sense3(cur_a, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
-                gyr = sense3(cur_g, &kp->gyro, dg, Vec3{z0[3], z1[3], z0[4]}, Vec3{z1[4], z0[5], z1[5]});
+                acc = sense3<WD>(cur_a, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
+                gyr = sense3<WD>(cur_g, &kp->gyro, dg, Vec3{z0[3], z1[3], z0[4]}, Vec3{z1[4], z0[5], z1[5]});
             } else if (need_acc) {
                 double z0[3], z1[3];
                 normal_pairs<3>(key, S_ACC_D_XY, jj, z0, z1, mk, tab);
-                acc = sense3(cur_a, &kernarg_params()->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
+                acc = sense3<WD>(cur_a, &kernarg_params()->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             } else if (need_gyr) {
                 double z0[3], z1[3];
                 normal_pairs<3>(key, S_GYR_D_XY, jj, z0, z1, mk, tab);
-                gyr = sense3(cur_g, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
+                gyr = sense3<WD>(cur_g, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             }
             if (need_acc && a.out_accel) store3(a.out_accel, plane, off, acc);
             if (need_gyr && a.out_gyro) store3(a.out_gyro, plane, off, gyr);
@@ -313,7 +316,7 @@ constexpr int kSplitTile = 4;
 constexpr int kSplitStep = 6 * 8 + 6 * 4;               // bytes per step and run in the ring
 constexpr size_t kSplitLds = (size_t)2 * kSplitTile * kSplitStep * kSplitRuns;         // 144 KiB -> one workgroup per CU
 
-template <int RF, int ALGOS>
+template <int RF, int ALGOS, bool WD>
 __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a) {
     extern __shared__ double zring[];                   // [2 stages][T steps]{ r[6][256] doubles, ang[6][256] words }
     constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
@@ -400,8 +403,8 @@ __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a)
                     p1[k] = rad * sn;
                 }
                 const params_ptr kp = kernarg_params();
-                const Vec3 acc = sense3(cur_a, &kp->accel, da, Vec3{p0[0], p1[0], p0[1]}, Vec3{p1[1], p0[2], p1[2]});
-                const Vec3 gyr = sense3(cur_g, &kp->gyro, dg, Vec3{p0[3], p1[3], p0[4]}, Vec3{p1[4], p0[5], p1[5]});
+                const Vec3 acc = sense3<WD>(cur_a, &kp->accel, da, Vec3{p0[0], p1[0], p0[1]}, Vec3{p1[1], p0[2], p1[2]});
+                const Vec3 gyr = sense3<WD>(cur_g, &kp->gyro, dg, Vec3{p0[3], p1[3], p0[4]}, Vec3{p1[4], p0[5], p1[5]});
                 if (a.out_accel) store3(a.out_accel, plane, off, acc);
                 if (a.out_gyro) store3(a.out_gyro, plane, off, gyr);
                 double odo = 0.0;
@@ -455,21 +458,26 @@ int mc_variant(const ginsim_mc_params& p) {
     return (p.runs + kWave - 1) / kWave <= 1024 ? 1 : 0;
 }
 
-template <int RF, int ALGOS>
-static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
+static bool any_white_drift(const ginsim_mc_params& p) {
+    int f = 0;
+    for (int k = 0; k < 3; ++k) f |= p.accel.white_drift[k] | p.gyro.white_drift[k];
+    return f != 0;
+}
+
+template <int RF, int ALGOS, bool WD>
+static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream) {
     const int tb = p.block_threads > 0 ? p.block_threads : kBlock;
     const int64_t waves = (p.runs + kWave - 1) / kWave;
     if constexpr ((ALGOS & GINSIM_ALGO_FREE) != 0) {
-        const int v = mc_variant(p);
-        const dim3 sgrid((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns));
-        if (v == 1) {
+        if (mc_variant(p) == 1) {
             static bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
                 return true;
             }();
             (void)once;
-            hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS>), sgrid, dim3(512), kSplitLds, stream, p);
+            const dim3 sgrid((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns));
+            hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD>), sgrid, dim3(512), kSplitLds, stream, p);
             return hipGetLastError();
         }
     }
@@ -477,11 +485,24 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
     // strictly more than 1/(k+1) of the LDS so that k+1 workgroups do not fit: 81 KB (k = 1), 54 KB (k = 2)
     const size_t lds = p.block_threads > 0 ? 0 : kLdsPerCu / (per_cu + 1) + 1024;
     const dim3 grid((unsigned)((p.runs + tb - 1) / tb)), block(tb);
-    if (p.given_sensors)
-        hipLaunchKernelGGL((mc_kernel<RF, ALGOS, true>), grid, block, lds, stream, p);
-    else
-        hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, WD>), grid, block, lds, stream, p);
     return hipGetLastError();
+}
+
+template <int RF, int ALGOS>
+static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
+    if (p.given_sensors) {
+        if constexpr (ALGOS != 0) {
+            const int tb = p.block_threads > 0 ? p.block_threads : kBlock;
+            const int64_t waves = (p.runs + kWave - 1) / kWave;
+            const int per_cu = waves <= 1024 ? 1 : 2;
+            const size_t lds = p.block_threads > 0 ? 0 : kLdsPerCu / (per_cu + 1) + 1024;
+            hipLaunchKernelGGL((mc_kernel<RF, ALGOS, true, false>), dim3((unsigned)((p.runs + tb - 1) / tb)), dim3(tb), lds, stream, p);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;        // given sensors without an algorithm: rejected by the C ABI
+    }
+    return any_white_drift(p) ? launch3<RF, ALGOS, true>(p, stream) : launch3<RF, ALGOS, false>(p, stream);
 }
 
 template <int RF>

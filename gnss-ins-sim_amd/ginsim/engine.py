@@ -370,9 +370,11 @@ class MonteCarloJob(object):
         p = self.params
         if p.precision == 1:
             return 'ginsim::f32::mc_kernel_f32%s<%d, %d>' % ('_split' if v.value else '', p.ref_frame, p.algo_mask)
+        wd = (not p.given_sensors) and any(p.accel.white_drift[k] or p.gyro.white_drift[k] for k in range(3))
         if v.value:
-            return 'ginsim::mc_kernel_split<%d, %d>' % (p.ref_frame, p.algo_mask)
-        return 'ginsim::mc_kernel<%d, %d, %s>' % (p.ref_frame, p.algo_mask, 'true' if p.given_sensors else 'false')
+            return 'ginsim::mc_kernel_split<%d, %d, %s>' % (p.ref_frame, p.algo_mask, 'true' if wd else 'false')
+        return 'ginsim::mc_kernel<%d, %d, %s, %s>' % (p.ref_frame, p.algo_mask, 'true' if p.given_sensors else 'false',
+                                                      'true' if wd else 'false')
 
     def run(self):
         self.launch()

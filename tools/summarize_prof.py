@@ -2,6 +2,7 @@
 """Turn the rocprofv3 result databases under gpurun_out/prof_* into the small text summaries committed under
 profiles/ (kernel trace stats, PMC counters, HBM traffic per launch)."""
 import csv
+import re
 import json
 import os
 import sqlite3
@@ -72,7 +73,7 @@ for k, c in pmc.items():
         # half of the bytes of a coalesced stream -> doubled.  WRITE_SIZE matched the known byte count exactly here.
         fetch_b = 2.0 * c['FETCH_SIZE'][1] * 1024
         write_b = c['WRITE_SIZE'][1] * 1024
-        key = 'mc_kernel_rf1_free_given' if ', true>' in k else 'mc_kernel_rf1_free_keep'
+        key = 'mc_kernel_rf1_free_given' if re.search(r'mc_kernel<\d, \d, true', k) else 'mc_kernel_rf1_free_keep'
         traffic[key] = {'kernel': k, 'hbm_bytes_per_launch': fetch_b + write_b, 'fetch_bytes_corrected': fetch_b,
                         'write_bytes': write_b, 'source': 'profiles/%s_pmc_counters.csv' % tag}
 with open(os.path.join(DST, 'pmc_traffic.json'), 'w') as f:
