@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
     Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
     MathConsts mk;
     // constants pinned in VGPRs except where that variant would spill to scratch (measured per variant)
-    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO)) || RF == 1>();
+    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO)) || (RF == 1 && WD)>();
 
     if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
     if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
