@@ -176,8 +176,9 @@ __device__ __forceinline__ uniform_ptr as_uniform(const double* p) {
 // Gauss-Markov update d[j+1] = a d[j] + b N[j] (pathgen.py:589-590).
 __device__ __forceinline__ Vec3 load3(uniform_ptr ref, int64_t j) { return Vec3{ref[3 * j], ref[3 * j + 1], ref[3 * j + 2]}; }
 
-// WD = false: the launcher saw no axis with an infinite correlation time (white_drift) in either sensor, the usual
-// case, and the six wave-uniform selects per sensor are compiled out.
+// WD = false: the launcher saw no axis with an infinite correlation time (white_drift) and no constant bias in either
+// sensor -- every standard IMU grade of imu_model.py -- so the six wave-uniform selects and the three bias additions
+// per sensor are compiled out (x + 0.0 == x: the values are the same).
 template <bool WD = true>
 __device__ __forceinline__ Vec3 sense3(const Vec3& truth, model_ptr m, Vec3& drift, const Vec3& zd,
                                        const Vec3& zw) {
@@ -186,9 +187,15 @@ __device__ __forceinline__ Vec3 sense3(const Vec3& truth, model_ptr m, Vec3& dri
     const double dy = (WD && m->white_drift[1]) ? by : drift.y;
     const double dz = (WD && m->white_drift[2]) ? bz : drift.z;
     Vec3 o;
-    o.x = truth.x + m->bias[0] + dx + m->white[0] * zw.x;
-    o.y = truth.y + m->bias[1] + dy + m->white[1] * zw.y;
-    o.z = truth.z + m->bias[2] + dz + m->white[2] * zw.z;
+    if (WD) {
+        o.x = truth.x + m->bias[0] + dx + m->white[0] * zw.x;
+        o.y = truth.y + m->bias[1] + dy + m->white[1] * zw.y;
+        o.z = truth.z + m->bias[2] + dz + m->white[2] * zw.z;
+    } else {
+        o.x = truth.x + dx + m->white[0] * zw.x;
+        o.y = truth.y + dy + m->white[1] * zw.y;
+        o.z = truth.z + dz + m->white[2] * zw.z;
+    }
     drift.x = __builtin_fma(m->gm_a[0], drift.x, bx);
     drift.y = __builtin_fma(m->gm_a[1], drift.y, by);
     drift.z = __builtin_fma(m->gm_a[2], drift.z, bz);
@@ -458,10 +465,12 @@ int mc_variant(const ginsim_mc_params& p) {
     return (p.runs + kWave - 1) / kWave <= 1024 ? 1 : 0;
 }
 
+// white-drift axes or a constant bias anywhere: the general sensor model (WD = true kernels)
 static bool any_white_drift(const ginsim_mc_params& p) {
-    int f = 0;
-    for (int k = 0; k < 3; ++k) f |= p.accel.white_drift[k] | p.gyro.white_drift[k];
-    return f != 0;
+    bool f = false;
+    for (int k = 0; k < 3; ++k)
+        f = f || p.accel.white_drift[k] || p.gyro.white_drift[k] || p.accel.bias[k] != 0.0 || p.gyro.bias[k] != 0.0;
+    return f;
 }
 
 template <int RF, int ALGOS, bool WD>
