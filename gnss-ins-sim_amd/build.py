@@ -55,9 +55,26 @@ def build(force=False, verbose=False):
         objs.append(o)
         if force or newer(s, o) or any(newer(d, o) for d in deps):
             cmd = [HIPCC] + COMMON + extra + ['-c', s, '-o', o]
+            if src.endswith('.hip'):
+                # per-kernel registers / scratch / occupancy as the compiler reports them -> build/<name>.resources.txt
+                # (tests/test_host_cpu.py holds the hot kernels to two wavefronts per SIMD and no AGPR spills)
+                cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
             if verbose:
                 print(' '.join(cmd))
-            subprocess.check_call(cmd)
+            p = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)
+            if src.endswith('.hip'):
+                remarks = [l for l in p.stderr.splitlines() if 'kernel-resource-usage' in l]
+                with open(o[:-2] + '.resources.txt', 'w') as f:
+                    f.write('\n'.join(l.split('remark:', 1)[1].replace('[-Rpass-analysis=kernel-resource-usage]', '').strip()
+                                      for l in remarks) + '\n')
+                other = [l for l in p.stderr.splitlines() if 'kernel-resource-usage' not in l and not l.startswith(' ')]
+                other = [l for l in other if l.strip() and not l.lstrip().startswith('|')]
+                if p.returncode != 0 or verbose:
+                    sys.stderr.write(p.stderr if p.returncode != 0 else '\n'.join(other) + '\n')
+            elif p.stderr:
+                sys.stderr.write(p.stderr)
+            if p.returncode != 0:
+                raise subprocess.CalledProcessError(p.returncode, cmd)
     if force or any(newer(o, LIB) for o in objs):
         cmd = [HIPCC, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + objs
         if verbose:

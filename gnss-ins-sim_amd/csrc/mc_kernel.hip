@@ -202,8 +202,11 @@ __device__ __forceinline__ Vec3 sense3(const Vec3& truth, model_ptr m, Vec3& dri
     return o;
 }
 
+// Two workgroups per CU is what the launch geometry below counts on: tell the register allocator (variants had grown
+// to 256 VGPRs + a few AGPRs = one wavefront per SIMD, 30 % slower at 262 144 runs, with no functional symptom;
+// tests/test_host_cpu.py now reads the compiler's resource report).
 template <int RF, int ALGOS, bool GIVEN, bool WD>
-__global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
+__global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t* trace = nullptr;
     if (a.wave_trace && (threadIdx.x & 63) == 0) {
@@ -238,7 +241,7 @@ __global__ void __launch_bounds__(256) mc_kernel(const ginsim_mc_params a) {
     Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
     MathConsts mk;
     // constants pinned in VGPRs except where that variant would spill to scratch (measured per variant)
-    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO)) || (RF == 1 && WD)>();
+    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO))>();
 
     if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
     if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
@@ -511,7 +514,11 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
         }
         return hipErrorInvalidValue;        // given sensors without an algorithm: rejected by the C ABI
     }
-    return any_white_drift(p) ? launch3<RF, ALGOS, true>(p, stream) : launch3<RF, ALGOS, false>(p, stream);
+    // the simple-model variant of the two-algorithm ref_frame 0 kernels is the one instantiation that spills: use the general one
+    constexpr bool kSimpleFits = !(RF == 0 && ALGOS == (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO));
+    if (any_white_drift(p) || !kSimpleFits) return launch3<RF, ALGOS, true>(p, stream);
+    if constexpr (kSimpleFits) return launch3<RF, ALGOS, false>(p, stream);
+    return hipErrorInvalidValue;
 }
 
 template <int RF>

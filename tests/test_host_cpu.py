@@ -169,3 +169,35 @@ def test_native_pathgen_magnetometer(rf):
     r = ginsim.pathgen(t2['ini_pva'], t2['motion_def'], 100.0, 10.0, t2['mobility'], rf, gps=True, geo_mag_n=g['geo_mag_n'])
     np.testing.assert_allclose(r['mag'][:, 1:4], g['ref_mag'], rtol=0, atol=1e-13)
     np.testing.assert_allclose(r['gps'][:, 1:7], g['ref_gps'], rtol=1e-15, atol=1e-13)
+
+
+def test_hot_kernels_keep_two_wavefronts_per_simd():
+    """The launch geometry counts on two resident wavefronts per SIMD for every hot kernel (csrc/mc_kernel.hip, launch3).
+    hipcc reports registers / scratch / occupancy per kernel at build time (build/<file>.resources.txt): no hot
+    kernel may drop to one wavefront, park registers in AGPRs or spill more than a few words.  (A variant that grew
+    to 256 VGPRs + 4 AGPRs once ran 30 % slower at 262 144 runs without any functional symptom.)"""
+    build = os.path.join(PKG, 'build')
+    kernels = {}
+    for fn in ('mc_kernel', 'mc_kernel_f32', 'allan', 'stats'):
+        path = os.path.join(build, fn + '.resources.txt')
+        assert os.path.exists(path), 'run gnss-ins-sim_amd/build.py (it writes %s)' % path
+        cur = None
+        for line in open(path):
+            k, _, v = line.strip().partition(':')
+            if k == 'Function Name':
+                cur = kernels.setdefault(v.strip(), {})
+            elif cur is not None and v.strip():
+                cur[k.split('[')[0].strip()] = v.strip()
+    checked = 0
+    for name, r in kernels.items():         # Itanium-mangled: ...9mc_kernelILi<rf>ELi<algos>ELb<given>ELb<general>EEEv...
+        occ, agpr, scratch = int(r['Occupancy']), int(r['AGPRs']), int(r['ScratchSize'])
+        hot = any(t in name for t in ('9mc_kernelI', '15mc_kernel_splitI', '13mc_kernel_f32I', '19mc_kernel_f32_splitI',
+                                      'allan_level_kernel', 'process_stats_kernel', '13series_kernelI'))
+        if not hot:
+            continue
+        checked += 1
+        two_algos = 'ILi0ELi3E' in name or 'ILi1ELi3E' in name
+        assert occ >= 2, '%s: %d wavefront(s) per SIMD' % (name, occ)
+        assert agpr == 0, '%s parks %d registers in AGPRs' % (name, agpr)
+        assert scratch <= (128 if two_algos else 32), '%s: %d bytes of scratch per lane' % (name, scratch)
+    assert checked >= 40, checked
