@@ -86,3 +86,37 @@ def test_fp32_generated_noise_moments(ctx):
     eo = job.sensors('odo', runs) - 0.999 * truth['ref_odo'][None]
     np.testing.assert_allclose(eo.std(), 0.1, rtol=0.01)
     job.release()
+
+
+def test_fp32_normals_cut_from_two_blocks_are_standard_and_independent(ctx):
+    """The twelve fp32 normals of a step come from two Philox blocks (23-bit radius + 18-bit angle per Box-Muller pair,
+    some angle bits being the spare low bits of radius words).  With zero drift the kept sensor series minus truth are
+    sigma * N per axis: the six axes must be standard normal (Kolmogorov-Smirnov), mutually uncorrelated -- also in
+    their squares, which would expose shared radius bits -- and white along time."""
+    import ginsim
+    from ginsim import workloads
+    from scipy import stats
+    ini, truth, _ = workloads.truth_from_profile('turn_90deg', 100.0, 1)
+    acc = {'b': np.zeros(3), 'b_drift': np.zeros(3), 'b_corr': np.full(3, 100.0), 'vrw': np.full(3, 0.03 / 60.0)}
+    gyr = {'b': np.zeros(3), 'b_drift': np.zeros(3), 'b_corr': np.full(3, 100.0), 'arw': np.full(3, 0.25 * np.pi / 180 / 60.0)}
+    R = 256
+    job = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=R, seed=123, keep_sensors=True, precision='f32').run()
+    runs = np.arange(R)
+    za = (job.sensors('accel', runs) - truth['ref_accel'][None]) / (acc['vrw'] * 10.0)      # white = rw / sqrt(dt), dt = 0.01
+    zg = (job.sensors('gyro', runs) - truth['ref_gyro'][None]) / (gyr['arw'] * 10.0)
+    z = np.concatenate([za, zg], axis=2)[:, :-1, :]                   # (R, n-1, 6)
+    flat = z.reshape(-1, 6).T
+    nsmp = flat.shape[1]
+    lim = 5.0 / np.sqrt(nsmp)
+    # accel z rides on -9.8 m/s^2 in fp32: its quantisation (ulp 9.5e-7 against sigma 5e-3) is far below the limits used
+    for k in range(6):
+        assert stats.kstest(flat[k][::7], 'norm').pvalue > 1e-4, 'axis %d fails KS' % k
+        assert abs(flat[k].mean()) < lim and abs(flat[k].var() - 1.0) < 5.0 * np.sqrt(2.0 / nsmp) + 2e-3
+        assert abs(stats.kurtosis(flat[k])) < 5.0 * np.sqrt(24.0 / nsmp) + 1e-2
+    c, c2 = np.corrcoef(flat), np.corrcoef(flat ** 2)
+    for a in range(6):
+        for b in range(a + 1, 6):
+            assert abs(c[a, b]) < lim and abs(c2[a, b]) < lim + 2e-3, (a, b, c[a, b], c2[a, b])
+        lag = np.mean(z[:, :-1, a] * z[:, 1:, a])
+        assert abs(lag) < lim, (a, lag)
+    job.release()
