@@ -10,7 +10,8 @@ fused kernel (noise injection + free-integration mechanisation + end-point error
 trajectories materialised in HBM exactly as the reference's Sim holds them after run()) -> on-device
 end-point statistics -> (N > 1) one all-reduce of the per-GPU statistics records -> merged mean/std/max.
 The host-side part of a step (waiting for the 28-double record, the all-reduce, the Chan merge) is done while the
-next batch integrates: K timed steps = K launches + K reductions + K exchanges, all inside the timed region.
+next batches integrate (the record one step later, the non-blocking all-reduce two steps later): K timed steps =
+K launches + K reductions + K exchanges, all inside the timed region.
 Workload = BASELINE.json configs[1]: 90-degree-turn profile @100 Hz (n = 1000), 'mid-accuracy' 6-axis IMU,
 ref_frame = 1, 65 536 runs per GPU, fp64.  Weak scaling: every rank integrates its own 65 536 runs
 (global run ids are disjoint, the Philox counter carries the global id).
@@ -143,23 +144,37 @@ def main():
     # HIP events bracket the MC kernel of every `stride`-th step (the context has 8192 event slots)
     stride = max(1, -(-2 * nsteps // 8192))
 
-    pending = []                                            # slot of the batch whose statistics are still in flight
+    # Two batches are in flight behind the one being integrated: batch s-1's on-device reduction (its 28-double record
+    # lands in a pinned slot) and batch s-2's all-reduce (issued non-blocking one step earlier).  The host therefore
+    # never waits for a collective that has not had a whole kernel time to complete -- also when the RCCL kernel
+    # cannot be scheduled next to the MC kernel, which fills every CU's LDS.
+    pending_stats, pending_coll = [], []
 
-    def exchange():
-        part = job.stats_finish(pending.pop())              # waits for that batch's 28-double record only
-        return distributed.allreduce_stats(part, group, device)
+    def collect():
+        """finish what can be finished: the all-reduce of batch s-2, then the record of batch s-1 -> issue its all-reduce"""
+        merged = distributed.allreduce_stats_end(pending_coll.pop()) if pending_coll else None
+        if pending_stats:
+            part = job.stats_finish(pending_stats.pop())
+            pending_coll.append(distributed.allreduce_stats_begin(part, group, device))
+        return merged
+
+    def drain():
+        merged = None
+        while pending_stats or pending_coll:
+            m = collect()
+            merged = m if m is not None else merged
+        return merged
 
     def step(s):
-        """launch batch s -> enqueue its on-device reduction -> while it integrates, merge / all-reduce batch s-1"""
         job.params.run_offset = (s * world + rank) * R      # a fresh batch of global run ids every step
         if s % stride == 0:
             ctx.event_record(2 * (s // stride))
         job.launch()
         if s % stride == 0:
             ctx.event_record(2 * (s // stride) + 1)
-        merged = exchange() if pending else None
+        merged = collect()
         job.stats_begin('free', s & 1)
-        pending.append(s & 1)
+        pending_stats.append(s & 1)
         return merged
 
     def fence():
@@ -172,13 +187,12 @@ def main():
 
     for s in range(args.warmup):
         step(s)
-    if pending:
-        exchange()
+    drain()
     fence()
     t0 = time.perf_counter()
     for s in range(args.warmup, nsteps):
         step(s)
-    merged = exchange()                                     # the last batch's exchange is inside the timed region
+    merged = drain()                                        # the last batches' exchanges are inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:

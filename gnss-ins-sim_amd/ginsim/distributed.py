@@ -35,6 +35,28 @@ def allreduce_stats(part, group=None, device=None):
     return StatsResult.merge(table.cpu().numpy())
 
 
+def allreduce_stats_begin(part, group=None, device=None):
+    """Non-blocking form: issue the all-reduce and return a handle for allreduce_stats_end.  The caller can enqueue more
+    GPU work in between; the collective completes whenever the device gets to it."""
+    if group is None:
+        return part
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    table = torch.zeros((world, RECORD), dtype=torch.float64, device=device)
+    table[rank] = torch.from_numpy(part.pack()).to(table.device)
+    work = dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return work, table
+
+
+def allreduce_stats_end(handle):
+    if isinstance(handle, StatsResult):
+        return handle
+    work, table = handle
+    work.wait()
+    return StatsResult.merge(table.cpu().numpy())
+
+
 def stats_from_errors(e):
     """Packed record of a host array of end-point errors (runs,9) -- used by tests to fabricate partials."""
     e = np.asarray(e, dtype=np.float64)

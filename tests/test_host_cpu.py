@@ -138,6 +138,11 @@ assert m.count == %(total)d
 np.testing.assert_allclose(m.mean, e.mean(0), rtol=1e-12)
 np.testing.assert_allclose(m.std, e.std(0), rtol=1e-11)
 np.testing.assert_array_equal(m.maxabs, np.abs(e).max(0))
+# the non-blocking form bench.py uses (issue now, collect a step later) gives the same record
+h = distributed.allreduce_stats_begin(part, dist.group.WORLD, torch.device('cpu'))
+m2 = distributed.allreduce_stats_end(h)
+np.testing.assert_array_equal(m2.pack(), m.pack())
+assert distributed.allreduce_stats_end(distributed.allreduce_stats_begin(part)) is part      # single process: identity
 dist.barrier()
 dist.destroy_process_group()
 print('rank', rank, 'ok')
