@@ -424,7 +424,10 @@ class Sim(object):
                     raise IOError('Unable to save summary to %s.' % data_dir)
 
     def plot(self, what_to_plot, sim_idx=None, opt=None, extra_opt=''):
-        raise NotImplementedError('plotting is outside the accelerated hot path (SURVEY.md section 2, #17)')
+        """Plotting is outside the accelerated path; the call is accepted (the reference's demo scripts end with it) and
+        says where the data are instead of drawing them."""
+        print('plot(%s): not drawn by this package -- the series are in sim.dmgr.<name>.data (per-run views) and in the '
+              'CSV files of results(data_dir).' % (what_to_plot,))
 
     def get_names_of_available_data(self):
         return self.dmgr.available
