@@ -40,7 +40,13 @@ def newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, tag=None, defines=()):
+    """tag / defines: an experiment build (A/B timing) -> lib/libginsim_<tag>.so from build/<tag>/ objects compiled with
+    -D<define>; loaded with GINSIM_LIB=<path>.  The product build has neither."""
+    global OBJ, LIB
+    if tag:
+        OBJ = os.path.join(HERE, 'build', tag)
+        LIB = os.path.join(HERE, 'lib', 'libginsim_%s.so' % tag)
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.h'))]
@@ -54,7 +60,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJ, src.rsplit('.', 1)[0] + '.o')
         objs.append(o)
         if force or newer(s, o) or any(newer(d, o) for d in deps):
-            cmd = [HIPCC] + COMMON + extra + ['-c', s, '-o', o]
+            cmd = [HIPCC] + COMMON + extra + ['-D' + d for d in defines] + ['-c', s, '-o', o]
             if src.endswith('.hip'):
                 # per-kernel registers / scratch / occupancy as the compiler reports them -> build/<name>.resources.txt
                 # (tests/test_host_cpu.py holds the hot kernels to two wavefronts per SIMD and no AGPR spills)
@@ -84,4 +90,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv))
+    _tag = sys.argv[sys.argv.index('--tag') + 1] if '--tag' in sys.argv else None
+    _defs = [a[2:] for a in sys.argv if a.startswith('-D')]
+    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv, tag=_tag, defines=_defs))

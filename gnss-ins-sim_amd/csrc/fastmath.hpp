@@ -6,7 +6,8 @@
 //   * log(u) for a uniform u in (0,1]               -> Box-Muller radius
 //   * sin/cos(pi*x) for x = 2u in (0,2)             -> Box-Muller angle
 //   * sin/cos(a + d) from sin/cos(a) for small |d|  -> Euler-angle attitude propagation
-// Errors are a few ulp (validated against libm in tests/test_fastmath.py through the probe entry point);
+// Errors are a few ulp (validated against NumPy through the ginsim_rng_normals / ginsim_box_muller hooks:
+// tests/test_gpu_parity.py::test_rng_words_bit_exact_and_normals, ::test_box_muller_corner_cases);
 // the engine's parity tolerances are 1e-12..1e-9.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -32,8 +33,8 @@ struct MathConsts {
     double ln2_hi, ln2_lo;  // -2 ln 2, split
     double sc[5];           // sin: -1/3!, 1/5!, -1/7!, 1/9!, -1/11!   (Box-Muller uses 2, rotate_sincos 5)
     double cc[6];           // cos: -1/2!, 1/4!, ... 1/12!             (Box-Muller uses 2, rotate_sincos 6)
-    double ang_bias, ang_scale;     // (0.5 - 2^22) 2 pi 2^-32 and 2 pi 2^-32: centred remainder of the 32-bit angle -> radians
-    double u_hi, u_lo, u_half;      // 2^-21, 2^-53, 2^-54: uniform53 as two FMAs
+    double ang_bias, ang_scale;     // (0.5 - 2^14) 2 pi 2^-24 and 2 pi 2^-24: centred remainder of the 24-bit angle -> radians
+    double u_hi, u_lo, u_half;      // 2^-32, 2^-40, 2^-41: uniform40 as two FMAs
     // OPAQUE = true pins the 23 constants in VGPRs (46 registers); false leaves them to the compiler (SGPR literals),
     // which is what the two-algorithm kernels need to stay under 256 VGPRs without scratch spills.
     template <bool OPAQUE>
@@ -50,11 +51,11 @@ struct MathConsts {
         for (int k = 0; k < 5; ++k) sc[k] = vconst(s[k]);
 #pragma unroll
         for (int k = 0; k < 6; ++k) cc[k] = vconst(c[k]);
-        ang_bias = vconst((0.5 - 4194304.0) * (6.283185307179586476925 * 0x1.0p-32));
-        ang_scale = vconst(6.283185307179586476925 * 0x1.0p-32);
-        u_hi = vconst(0x1.0p-21);
-        u_lo = vconst(0x1.0p-53);
-        u_half = vconst(0x1.0p-54);
+        ang_bias = vconst((0.5 - 16384.0) * (6.283185307179586476925 * 0x1.0p-24));
+        ang_scale = vconst(6.283185307179586476925 * 0x1.0p-24);
+        u_hi = vconst(0x1.0p-32);
+        u_lo = vconst(0x1.0p-40);
+        u_half = vconst(0x1.0p-41);
     }
 };
 
@@ -126,7 +127,7 @@ GINSIM_FM double sqrt_pos(double x) {
     return __builtin_fma(__builtin_fma(-g, g, x), h, g);       // the 2^-23 error of h only scales the correction
 }
 
-// -2 ln u for 0 < u <= 1 (normal, not denormal: u >= 2^-54 by construction of uniform53): the squared Box-Muller radius.
+// -2 ln u for 0 < u <= 1 (normal, not denormal: u >= 2^-41 by construction of uniform40): the squared Box-Muller radius.
 //   u = m 2^e, m in [sqrt(1/2), sqrt(2));  -2 ln u = e (-2 ln2) + (-2 ln c_k) + (-2 log1p(r)),  r = m / c_k - 1,
 //   |r| <= 2^-9;  with r' = -2 r = fma(m, -2/c_k, 2):  -2 log1p(r) = r' + r'^2/4 + r'^3/12 + r'^4/32 + r'^5/80 + r'^6/192
 // The exponent/mantissa split and the bin index are integer arithmetic on the high word (no compare/select):
@@ -147,12 +148,12 @@ GINSIM_FM double neg2_log_u01(double u, const MathConsts& k, const NormalTables&
     return __builtin_fma(ed, k.ln2_hi, t.y) + small;
 }
 
-// sin and cos of the Box-Muller angle 2 pi (w + 1/2) 2^-32, w one Philox word: sector i = top 9 bits of w,
-// b = centred remainder in radians (|b| <= pi/512), angle = a_i + b.  sin b = b + b^3 (-1/6 + b^2/120) (next term
-// 6e-20), cos b - 1 = b^2 (-1/2 + b^2/24) (next term 7e-17).
-GINSIM_FM void sincos_turn32(uint32_t w, double& s, double& c, const MathConsts& k, const NormalTables& tab) {
-    const double2 t = tab.sc[w >> 23];
-    const double b = __builtin_fma((double)(w & 0x7fffffu), k.ang_scale, k.ang_bias);      // centred remainder, radians
+// sin and cos of the Box-Muller angle 2 pi (a + 1/2) 2^-24, a = the low 24 bits of a Philox word: sector i = top 9
+// bits of a, b = centred remainder in radians (|b| <= pi/512), angle = a_i + b.  sin b = b + b^3 (-1/6 + b^2/120) (next
+// term 6e-20), cos b - 1 = b^2 (-1/2 + b^2/24) (next term 7e-17).
+GINSIM_FM void sincos_turn24(uint32_t w, double& s, double& c, const MathConsts& k, const NormalTables& tab) {
+    const double2 t = tab.sc[(w >> 15) & (kAngBins - 1)];
+    const double b = __builtin_fma((double)(w & 0x7fffu), k.ang_scale, k.ang_bias);        // centred remainder, radians
     const double tt = b * b;
     const double sb = __builtin_fma(b * tt, __builtin_fma(tt, k.sc[1], k.sc[0]), b);       // sin b
     const double cm = tt * __builtin_fma(tt, k.cc[1], k.cc[0]);                            // cos b - 1

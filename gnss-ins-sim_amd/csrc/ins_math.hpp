@@ -109,8 +109,8 @@ struct Att {
     // The angles themselves are propagated exactly as the reference does; their cached sin/cos are ROTATED by
     // the step (angle-addition with short sin/cos(d) series, fastmath.hpp) instead of re-evaluated, and are
     // re-evaluated exactly when `resync` is set (every kTrigResync steps, wave-uniform), when the pitch folds
-    // over +-pi/2, or when a step exceeds 0.25 rad.  +-2pi wraps leave the trig untouched.  When no lane of the
-    // wavefront steps by more than 2^-6 rad the rotation uses the three-term series.
+    // over +-pi/2, or when a step exceeds 0.25 rad.  +-2pi wraps leave the trig untouched.  A lane that steps by no
+    // more than 2^-6 rad uses the three-term series.
     GINSIM_HD void step(const Vec3& w, double dt, bool resync, const MathConsts& mk) {
         const double q = w.z * cr + w.y * sr;
         const double icp = rcp_n1(cp);      // 2^-46 relative on a rate that is multiplied by dt: far below the state's ulp
@@ -132,7 +132,11 @@ struct Att {
             if (r > kPi) r -= kTwoPi; else if (r < -kPi) r += kTwoPi;
             set(y, p, r);
         } else {
-            if (__all(big <= 0x1.0p-6)) {       // wave-uniform: the short series when every lane's step is small
+            // Which series rotates the cached trig is decided PER LANE from the lane's own step, so a run's bits never
+            // depend on which other runs share its wavefront (any sharding of the runs over launches / GPUs reproduces
+            // them exactly).  When all lanes agree -- every vehicle profile at >= 100 Hz -- the other side of the
+            // branch is skipped (s_cbranch_execz): measured no slower than a wave-wide vote.
+            if (big <= 0x1.0p-6) {
                 rotate_sincos_small(dy, sy, cy, mk);
                 rotate_sincos_small(dp, sp, cp, mk);
                 rotate_sincos_small(dr, sr, cr, mk);

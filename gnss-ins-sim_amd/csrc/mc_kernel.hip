@@ -1,7 +1,7 @@
 // Fused Monte-Carlo kernel: sensor-error injection + strapdown mechanisation + end-point error.
 //
 // One lane = one Monte-Carlo run (no inter-lane traffic in the time loop; workgroups of 256 or 512 threads only
-// shape the placement on the SIMDs and share the 6 KB Box-Muller tables).  Per-run state (Euler attitude + cached
+// shape the placement on the SIMDs and share the 12 KB Box-Muller tables).  Per-run state (Euler attitude + cached
 // trig, body/NED velocity, position, the six Gauss-Markov bias states) lives in VGPRs for the whole time loop.
 // Truth samples are wave-uniform and come in through the scalar cache.  Everything that leaves the lane is SoA [component][sample][run]
 // (run fastest) so that every store instruction of a wavefront writes 64 x 8 B contiguous bytes.
@@ -114,7 +114,7 @@ __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& a
         }
         const double dlat = v.x * irm * dt;
         if (resync || !(fabs(dlat) <= 0.25)) sincos(s.pos.x + dlat, &s.sl, &s.cl);
-        else if (__all(fabs(dlat) <= 0x1.0p-6)) rotate_sincos_small(dlat, s.sl, s.cl, mk);
+        else if (fabs(dlat) <= 0x1.0p-6) rotate_sincos_small(dlat, s.sl, s.cl, mk);      // per lane: see Att::step
         else rotate_sincos(dlat, s.sl, s.cl, mk);
         s.pos.x += dlat;
         s.pos.y += v.y * irn * icl * dt;
@@ -267,17 +267,17 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
             const bool need_odo = ODO || a.out_odo;
             if (need_acc && need_gyr) {             // the common case: six streams in one phased batch
                 double z0[6], z1[6];
-                normal_pairs<6>(key, S_ACC_D_XY, jj, z0, z1, mk, tab);
+                normal_pairs<S_ACC_D_XY, 6>(key, jj, z0, z1, mk, tab);
                 const params_ptr kp = kernarg_params();
                 acc = sense3<WD>(cur_a, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
                 gyr = sense3<WD>(cur_g, &kp->gyro, dg, Vec3{z0[3], z1[3], z0[4]}, Vec3{z1[4], z0[5], z1[5]});
             } else if (need_acc) {
                 double z0[3], z1[3];
-                normal_pairs<3>(key, S_ACC_D_XY, jj, z0, z1, mk, tab);
+                normal_pairs<S_ACC_D_XY, 3>(key, jj, z0, z1, mk, tab);
                 acc = sense3<WD>(cur_a, &kernarg_params()->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             } else if (need_gyr) {
                 double z0[3], z1[3];
-                normal_pairs<3>(key, S_GYR_D_XY, jj, z0, z1, mk, tab);
+                normal_pairs<S_GYR_D_XY, 3>(key, jj, z0, z1, mk, tab);
                 gyr = sense3<WD>(cur_g, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             }
             if (need_acc && a.out_accel) store3(a.out_accel, plane, off, acc);
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
 // and there are no more runs to give the SIMD a second wavefront.  So the work of one step is split across TWO
 // wavefronts per 64 runs, at the point where the normal generator changes character:
 //
-//   waves 4-7 of a 512-thread workgroup (producers): the four Philox blocks of a step and the RADIUS half of the six
+//   waves 4-7 of a 512-thread workgroup (producers): the three Philox blocks of a step and the RADIUS half of the six
 //                                                    Box-Muller transforms (uniform, log, sqrt) -> LDS ring, per step
 //                                                    and run 6 doubles r and 6 angle words  (72 B)
 //   waves 0-3 (consumers)                          : read tile i-1 from LDS, the DIRECTION half (sin/cos of the angle
@@ -359,8 +359,7 @@ __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a)
                     if (j < n_noise) {
                         double u[6];
                         uint32_t ang[6];
-                        draw_group(key, 0, (uint32_t)j, u, ang, mk);
-                        draw_group(key, 1, (uint32_t)j, u + 3, ang + 3, mk);
+                        draw_streams<S_ACC_D_XY, 6>(key, (uint32_t)j, u, ang, mk);
 #pragma unroll
                         for (int k = 0; k < 6; ++k) u[k] = neg2_log_u01(u[k], mk, tab);
 #pragma unroll
@@ -408,7 +407,7 @@ __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a)
                 for (int k = 0; k < 6; ++k) {
                     const double rad = rb[k * kSplitRuns];
                     double sn, cs;
-                    sincos_turn32(ab[k * kSplitRuns], sn, cs, mk, tab);
+                    sincos_turn24(ab[k * kSplitRuns], sn, cs, mk, tab);
                     p0[k] = rad * cs;
                     p1[k] = rad * sn;
                 }
@@ -573,7 +572,7 @@ __global__ void __launch_bounds__(256) series_kernel(const ginsim_mc_params a, c
         Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
         for (int64_t j = j0; j < j1; ++j) {
             double z0[6], z1[6];
-            normal_pairs<6>(key, S_ACC_D_XY, (uint32_t)j, z0, z1, mk, tab);
+            normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)j, z0, z1, mk, tab);
             da.x = __builtin_fma(kp->accel.gm_a[0], da.x, kp->accel.gm_b[0] * z0[0]);
             da.y = __builtin_fma(kp->accel.gm_a[1], da.y, kp->accel.gm_b[1] * z1[0]);
             da.z = __builtin_fma(kp->accel.gm_a[2], da.z, kp->accel.gm_b[2] * z0[1]);
@@ -588,7 +587,7 @@ __global__ void __launch_bounds__(256) series_kernel(const ginsim_mc_params a, c
         for (int64_t j = j0; j < j1; ++j) {
             const int64_t off = j * a.runs + r;
             double z0[6], z1[6];
-            normal_pairs<6>(key, S_ACC_D_XY, (uint32_t)j, z0, z1, mk, tab);
+            normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)j, z0, z1, mk, tab);
             const Vec3 ta{a.ref_accel[3 * j], a.ref_accel[3 * j + 1], a.ref_accel[3 * j + 2]};
             const Vec3 tg{a.ref_gyro[3 * j], a.ref_gyro[3 * j + 1], a.ref_gyro[3 * j + 2]};
             const Vec3 acc = sense3(ta, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
@@ -668,7 +667,7 @@ __global__ void __launch_bounds__(256) aux_gps_kernel(const ginsim_aux_params a)
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     double z0[3], z1[3];
-    normal_pairs<3>(key, S_GPS_P_XY, (uint32_t)k, z0, z1, mk, tab);
+    normal_pairs<S_GPS_P_XY, 3>(key, (uint32_t)k, z0, z1, mk, tab);
     const double z[6] = {z0[0], z1[0], z0[1], z1[1], z0[2], z1[2]};     // pos x,y,z  vel x,y,z
     const int64_t plane = a.m * a.runs;
 #pragma unroll
@@ -687,9 +686,9 @@ __global__ void __launch_bounds__(256) aux_mag_kernel(const ginsim_aux_params a)
     const int64_t r = idx % a.runs, j = idx / a.runs;
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
-    double z0[3], z1[3];
-    normal_pairs<3>(key, S_ODO, (uint32_t)j, z0, z1, mk, tab);          // group 2: odometer, mag xy, mag z
-    const double z[3] = {z0[1], z1[1], z0[2]};
+    double z0[2], z1[2];
+    normal_pairs<S_MAG_XY, 2>(key, (uint32_t)j, z0, z1, mk, tab);
+    const double z[3] = {z0[0], z1[0], z0[1]};
     const double v[3] = {a.ref_mag[3 * j] + a.mag_hi[0], a.ref_mag[3 * j + 1] + a.mag_hi[1], a.ref_mag[3 * j + 2] + a.mag_hi[2]};
     const int64_t plane = a.n * a.runs;
 #pragma unroll
@@ -723,7 +722,7 @@ __global__ void rng_probe_kernel(uint64_t seed, uint64_t run, uint32_t stream, i
     z0[j] = a;
     z1[j] = b;
     if (words) {
-        const u32x4 w = philox4x32_10((uint32_t)j, stream, key.r0, key.r1, key.k0, key.k1);
+        const u32x4 w = philox4x32((uint32_t)j, stream, key.r0, key.r1, key.k0, key.k1);      // raw block (j, stream)
         words[4 * j + 0] = w.x; words[4 * j + 1] = w.y; words[4 * j + 2] = w.z; words[4 * j + 3] = w.w;
     }
 }
@@ -757,7 +756,8 @@ __global__ void gather_runs_kernel(const double* __restrict__ series, int C, int
     out[idx] = series[((int64_t)c * n + j) * runs + ids[k]];
 }
 
-// Box-Muller on given words (test hook): radius uniform from words 0-1, angle from word 2 (word 3 unused).
+// Box-Muller on given words (test hook): words 0-1 are taken as one half block -- 40-bit radius uniform from word 0 and the
+// top byte of word 1, angle from the low 24 bits of word 1 (words 2-3 unused).
 __global__ void box_muller_kernel(const uint32_t* __restrict__ words, int64_t count, double* __restrict__ z0, double* __restrict__ z1) {
     __shared__ double2 ntab[kLogBins + kAngBins];
     fill_normal_tables(ntab, threadIdx.x, blockDim.x);
@@ -767,8 +767,8 @@ __global__ void box_muller_kernel(const uint32_t* __restrict__ words, int64_t co
     mk.init<true>();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    double r[1] = {uniform53(words[4 * i], words[4 * i + 1], mk)}, a[1], b[1];
-    const uint32_t ang[1] = {words[4 * i + 2]};
+    double r[1] = {uniform40(words[4 * i], words[4 * i + 1], mk)}, a[1], b[1];
+    const uint32_t ang[1] = {words[4 * i + 1]};
     box_muller<1>(r, ang, a, b, mk, tab);
     z0[i] = a[0];
     z1[i] = b[0];

@@ -5,7 +5,7 @@
 //     velocity components) are Kahan-compensated so that 1e5 forward-Euler steps do not random-walk in the last bit;
 //   * POSITION is accumulated in fp64 (3 adds per step): ECEF (4.7e6 m) and LLA radians do not fit fp32 (ulp 0.5 m /
 //     6e-8 rad), and the series written to HBM is the fp32 DISPLACEMENT from the initial position;
-//   * noise: the same Philox4x32-10 generator, but a Box-Muller pair takes a 23-bit radius uniform
+//   * noise: the same Philox4x32-7 generator, but a Box-Muller pair takes a 23-bit radius uniform
 //     u = (2 (w >> 9) + 1) 2^-24 and an 18-bit angle, so TWO blocks give the six pairs (12 normals) of a step, evaluated with the
 //     hardware v_log_f32 / v_sin_f32 / v_cos_f32 units.  |z| <= 5.77 sigma.  This is a different (coarser) noise
 //     stream than the fp64 path; run-by-run comparison with fp64 is therefore done noise-free and in given-data
@@ -111,7 +111,7 @@ __device__ __forceinline__ float uniform23(uint32_t w) {
 // four standard normals from one Philox block (two Box-Muller pairs on the hardware transcendental units:
 // v_log_f32, v_sqrt_f32 -- 1 ulp, the argument -2 ln u is in [1.2e-7, 33.3] -- and v_sin_f32 / v_cos_f32)
 __device__ __forceinline__ void normals4(const RngKey& key, uint32_t stream, uint32_t j, float (&z)[4]) {
-    const u32x4 w = philox4x32_10(j, stream, key.r0, key.r1, key.k0, key.k1);
+    const u32x4 w = philox4x32(j, stream, key.r0, key.r1, key.k0, key.k1);
     const float u0 = uniform23(w.x), u1 = uniform23(w.y), u2 = uniform23(w.z), u3 = uniform23(w.w);
     // -2 ln u = -2 ln2 log2 u ; v_sin_f32 / v_cos_f32 take the angle in revolutions
     const float r0 = __builtin_amdgcn_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u0));
@@ -126,8 +126,8 @@ __device__ __forceinline__ void normals4(const RngKey& key, uint32_t stream, uin
 // (top 23 bits of A0..A3, B0, B1) and an 18-bit angle uniform cut from B2, B3 and the spare low bits of the radius
 // words.  z[2p] = r_p cos, z[2p+1] = r_p sin.
 __device__ __forceinline__ void normals12(const RngKey& key, uint32_t j, float (&z)[12]) {
-    const u32x4 A = philox4x32_10(j, 0u, key.r0, key.r1, key.k0, key.k1);
-    const u32x4 B = philox4x32_10(j, 1u, key.r0, key.r1, key.k0, key.k1);
+    const u32x4 A = philox4x32(j, 0u, key.r0, key.r1, key.k0, key.k1);
+    const u32x4 B = philox4x32(j, 1u, key.r0, key.r1, key.k0, key.k1);
     const uint32_t rw[6] = {A.x, A.y, A.z, A.w, B.x, B.y};
     const uint32_t aw[6] = {B.z >> 14, B.w >> 14,
                             ((B.z & 0x3fffu) << 4) | (A.x & 0xfu), ((B.w & 0x3fffu) << 4) | (A.y & 0xfu),

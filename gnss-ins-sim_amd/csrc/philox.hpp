@@ -1,8 +1,11 @@
 // Counter-based normal generator of the MC engine (device side).
 //
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11; Random123 constants) + Box-Muller in fp64.  A pair of normals
-// takes a 53-bit radius uniform and a 32-bit angle uniform; three pairs (streams 3g, 3g+1, 3g+2) are cut from the 256
-// bits of the two blocks (j, 2g) and (j, 2g+1) -- the cut is spelled out in oracle/philox.py.
+// Philox4x32-7 (Salmon, Moraes, Dror, Shaw, SC'11: seven rounds is the paper's Crush-resistant Philox4x32, ten its
+// conservative default; Random123 constants and known-answer vectors for both round counts are in the tests) +
+// Box-Muller in fp64.  A pair of normals takes 64 bits -- a 40-bit radius uniform (|z| up to 7.5 sigma) and a 24-bit
+// angle uniform -- so one 128-bit block yields TWO pairs, and the six pairs (twelve normals) of an IMU step cost
+// exactly three blocks:
+//     stream s at sample j  =  half (s & 1) of block  philox4x32_7(counter = (j, s >> 1, run_lo, run_hi), key = seed)
 // It replaces the reference's serial global np.random.randn stream
 // (gnss_ins_sim/pathgen/pathgen.py:495,557,588,593,621-622,639,660): every (run, stream, sample)
 // triple owns its variates, so lanes never share RNG state and only variates that are consumed are
@@ -14,6 +17,7 @@
 
 namespace ginsim {
 
+// stream ids: one stream -> two normals (z0, z1) per sample
 enum : uint32_t {
     S_ACC_D_XY = 0, S_ACC_DZ_WX = 1, S_ACC_W_YZ = 2,
     S_GYR_D_XY = 3, S_GYR_DZ_WX = 4, S_GYR_W_YZ = 5,
@@ -26,10 +30,13 @@ struct u32x4 { uint32_t x, y, z, w; };
 // a ^ b ^ c in one v_bitop3_b32 (truth table 0x96); the compiler emits two v_xor_b32 when c is a scalar register
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
-__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                               uint32_t k0, uint32_t k1) {
+constexpr int kPhiloxRounds = 7;
+
+template <int ROUNDS = kPhiloxRounds>
+__device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
@@ -44,32 +51,16 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return u32x4{c0, c1, c2, c3};
 }
 
-// (0,1] uniform with 53 significant bits from two words: u = ((hi:lo >> 11) + 0.5) * 2^-53, rounded once (the largest
-// of the 2^53 values rounds to 1.0).  top 2^-21 + (low 2^-53 + 2^-54): the inner FMA is exact (33 bits), the outer one
-// rounds the exact sum once -- the bits of (v + 0.5) 2^-53 in two FMAs on three register constants.
-__device__ __forceinline__ double uniform53(uint32_t lo, uint32_t hi, const MathConsts& k) {
-    const uint32_t top = hi >> 11;                         // 21 bits
-    const uint32_t low = (hi << 21) | (lo >> 11);          // 32 bits (one v_alignbit_b32)
-    return __builtin_fma((double)top, k.u_hi, __builtin_fma((double)low, k.u_lo, k.u_half));
+// (0,1) uniform with 40 significant bits from the two words (a, b) of a half block: u = ((a << 8 | b >> 24) + 0.5) 2^-40,
+// exact in fp64: a 2^-32 + ((b >> 24) 2^-40 + 2^-41) as two FMAs on three register constants.
+__device__ __forceinline__ double uniform40(uint32_t a, uint32_t b, const MathConsts& k) {
+    return __builtin_fma((double)a, k.u_hi, __builtin_fma((double)(b >> 24), k.u_lo, k.u_half));
 }
 
 struct RngKey {
     uint32_t k0, k1;    // seed
     uint32_t r0, r1;    // global run id
 };
-
-// The three streams of group g at sample j: radius uniforms u[3] and angle words ang[3] from two Philox blocks.
-__device__ __forceinline__ void draw_group(const RngKey& key, uint32_t g, uint32_t j, double* u, uint32_t* ang,
-                                           const MathConsts& mk) {
-    const u32x4 A = philox4x32_10(j, 2 * g, key.r0, key.r1, key.k0, key.k1);
-    const u32x4 B = philox4x32_10(j, 2 * g + 1, key.r0, key.r1, key.k0, key.k1);
-    u[0] = uniform53(A.x, A.y, mk);
-    ang[0] = A.z;
-    u[1] = uniform53(A.w, B.x, mk);
-    ang[1] = B.y;
-    u[2] = uniform53(((A.x & 0x7ffu) << 21) | ((A.w & 0x7ffu) << 10), B.z, mk);     // the spare low bits of A.x and A.w
-    ang[2] = B.w;
-}
 
 // Box-Muller on N (radius uniform, angle word) draws, phase by phase -- all logarithms, then all square roots, then
 // all sin/cos -- instead of N complete transforms in a row: each phase is N independent dependency chains (ILP for
@@ -84,41 +75,48 @@ __device__ __forceinline__ void box_muller(double (&r)[N], const uint32_t (&ang)
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         double s, c;
-        sincos_turn32(ang[k], s, c, mk, tab);
+        sincos_turn24(ang[k], s, c, mk, tab);
         z0[k] = r[k] * c;
         z1[k] = r[k] * s;
     }
 }
 
-// N consecutive streams first .. first+N-1 of one sample (whole groups: first and N multiples of 3) -> N normal pairs
-template <int N>
-__device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t first, uint32_t j, double (&z0)[N], double (&z1)[N],
+// Radius uniforms u[N] and angle words ang[N] (the low 24 bits count) of the N consecutive streams FIRST .. FIRST+N-1
+// at sample j: blocks FIRST >> 1 .. (FIRST+N-1) >> 1, each computed once.
+template <uint32_t FIRST, int N>
+__device__ __forceinline__ void draw_streams(const RngKey& key, uint32_t j, double* u, uint32_t* ang, const MathConsts& mk) {
+    constexpr uint32_t B0 = FIRST >> 1, B1 = (FIRST + N - 1) >> 1;
+#pragma unroll
+    for (uint32_t b = B0; b <= B1; ++b) {
+        const u32x4 w = philox4x32(j, b, key.r0, key.r1, key.k0, key.k1);
+        if (2 * b >= FIRST) {
+            u[2 * b - FIRST] = uniform40(w.x, w.y, mk);
+            ang[2 * b - FIRST] = w.y;
+        }
+        if (2 * b + 1 < FIRST + N) {
+            u[2 * b + 1 - FIRST] = uniform40(w.z, w.w, mk);
+            ang[2 * b + 1 - FIRST] = w.w;
+        }
+    }
+}
+
+// N consecutive streams FIRST .. FIRST+N-1 of one sample -> N normal pairs
+template <uint32_t FIRST, int N>
+__device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t j, double (&z0)[N], double (&z1)[N],
                                              const MathConsts& mk, const NormalTables& tab) {
-    static_assert(N % 3 == 0, "streams come in groups of three");
     double r[N];
     uint32_t ang[N];
-#pragma unroll
-    for (int g = 0; g < N / 3; ++g) draw_group(key, first / 3 + g, j, r + 3 * g, ang + 3 * g, mk);
+    draw_streams<FIRST, N>(key, j, r, ang, mk);
     box_muller<N>(r, ang, z0, z1, mk, tab);
 }
 
-// Two standard normals of one stream.  Slot 0 of a group needs the first block only.
+// Two standard normals of one stream (run-time stream id).
 __device__ __forceinline__ void normal_pair(const RngKey& key, uint32_t stream, uint32_t j, double& z0, double& z1,
                                             const MathConsts& mk, const NormalTables& tab) {
-    const uint32_t g = stream / 3, slot = stream - 3 * g;
-    double r[1], a[1], b[1];
-    uint32_t ang[1];
-    if (slot == 0) {
-        const u32x4 A = philox4x32_10(j, 2 * g, key.r0, key.r1, key.k0, key.k1);
-        r[0] = uniform53(A.x, A.y, mk);
-        ang[0] = A.z;
-    } else {
-        double u[3];
-        uint32_t w[3];
-        draw_group(key, g, j, u, w, mk);
-        r[0] = slot == 1 ? u[1] : u[2];
-        ang[0] = slot == 1 ? w[1] : w[2];
-    }
+    const u32x4 w = philox4x32(j, stream >> 1, key.r0, key.r1, key.k0, key.k1);
+    const bool hi = (stream & 1u) != 0;
+    double r[1] = {uniform40(hi ? w.z : w.x, hi ? w.w : w.y, mk)}, a[1], b[1];
+    const uint32_t ang[1] = {hi ? w.w : w.y};
     box_muller<1>(r, ang, a, b, mk, tab);
     z0 = a[0];
     z1 = b[0];

@@ -16,7 +16,7 @@
  *   geo_param / lla2ecef              gnss_ins_sim/geoparams/geoparams.py:25-53 / 70-87
  *   array_error (end point)           gnss_ins_sim/sim/ins_data_manager.py:537-541, 737
  *
- * The noise source is the engine's Philox4x32-10 + Box-Muller stream (see oracle/philox.py for the
+ * The noise source is the engine's Philox4x32-7 + Box-Muller stream (see oracle/philox.py for the
  * definition and why the reference's own np.random stream is "parity unpinned").
  * Pinned against the NumPy oracle (itself pinned against the executed reference) in
  * tests/test_oracle_c.py.  Compile with -ffp-contract=off.
@@ -33,9 +33,9 @@
 #define ESQ (ECC * ECC)
 #define WIE 7292115e-11
 
-/* ---------------------------------------------------------------- Philox4x32-10 + Box-Muller */
-static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-    for (int r = 0; r < 10; ++r) {
+/* ---------------------------------------------------------------- Philox4x32-7 + Box-Muller */
+static void philox4x32_7(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 7; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
@@ -49,26 +49,16 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
     }
 }
 
-static double uniform53(uint32_t lo, uint32_t hi) {
-    uint64_t v = (((uint64_t)hi << 32) | lo) >> 11;
-    return ((double)v + 0.5) * 0x1.0p-53;
-}
-
-/* stream = 3 g + slot: three streams are cut from the two Philox blocks (j, 2g) and (j, 2g+1) -- oracle/philox.py */
+/* stream s at sample j = half (s & 1) of block (j, s >> 1): 40-bit radius uniform + 24-bit angle -- oracle/philox.py */
 static void normal_pair(uint64_t seed, uint64_t run, uint32_t stream, uint32_t j, double* z0, double* z1) {
-    const uint32_t g = stream / 3, slot = stream % 3;
-    uint32_t A[4] = {j, 2 * g, (uint32_t)run, (uint32_t)(run >> 32)};
-    uint32_t B[4] = {j, 2 * g + 1, (uint32_t)run, (uint32_t)(run >> 32)};
-    philox4x32_10(A, (uint32_t)seed, (uint32_t)(seed >> 32));
-    if (slot != 0) philox4x32_10(B, (uint32_t)seed, (uint32_t)(seed >> 32));
-    uint32_t lo, hi, aw;
-    if (slot == 0) { lo = A[0]; hi = A[1]; aw = A[2]; }
-    else if (slot == 1) { lo = A[3]; hi = B[0]; aw = B[1]; }
-    else { lo = ((A[0] & 0x7ffu) << 21) | ((A[3] & 0x7ffu) << 10); hi = B[2]; aw = B[3]; }
-    const double u1 = uniform53(lo, hi), u2 = ((double)aw + 0.5) * 0x1.0p-32;
-    double r = sqrt(-2.0 * log(u1)), a = (2.0 * PI) * u2;
-    *z0 = r * cos(a);
-    *z1 = r * sin(a);
+    uint32_t W[4] = {j, stream >> 1, (uint32_t)run, (uint32_t)(run >> 32)};
+    philox4x32_7(W, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t a = (stream & 1u) ? W[2] : W[0], b = (stream & 1u) ? W[3] : W[1];
+    const double u1 = ((double)(((uint64_t)a << 8) | (b >> 24)) + 0.5) * 0x1.0p-40;
+    const double u2 = ((double)(b & 0xffffffu) + 0.5) * 0x1.0p-24;
+    double r = sqrt(-2.0 * log(u1)), ang = (2.0 * PI) * u2;
+    *z0 = r * cos(ang);
+    *z1 = r * sin(ang);
 }
 
 void oracle_normals(uint64_t seed, uint64_t run, uint32_t stream, int64_t count, double* z0, double* z1) {

@@ -3,33 +3,31 @@
 The reference draws its noise from the global legacy ``np.random.randn`` stream
 (/root/reference/gnss_ins_sim/pathgen/pathgen.py:495,557,588,593,621-622,639,660)
 which is serial and unseeded: "parity unpinned" for the stream itself.  The
-engine therefore defines its own stream -- Philox4x32-10 (Salmon et al., SC'11,
-"Parallel random numbers: as easy as 1, 2, 3"; Random123 v1.14 constants) followed
-by Box-Muller in fp64 -- and parity is "identical injected normals": the
+engine therefore defines its own stream -- Philox4x32-7 (Salmon et al., SC'11,
+"Parallel random numbers: as easy as 1, 2, 3": seven rounds is the Crush-resistant
+Philox4x32 of the paper, ten its conservative default; Random123 v1.14 constants and
+known-answer vectors for both round counts are checked in the tests) followed by
+Box-Muller in fp64 -- and parity is "identical injected normals": the
 unmodified reference is fed THESE normals through a ``np.random.randn`` shim
 (``oracle/ref_shim.py``).
 
 Stream definition (shared by this file, ``oracle/c/ginsim_oracle.c`` and
-``gnss-ins-sim_amd/csrc/philox.hpp``).  A normal pair needs a 53-bit uniform for the radius (tails to 8.5 sigma,
-as NumPy's doubles) and a 32-bit uniform for the angle: 85 bits, so THREE pairs ("streams" 3g, 3g+1, 3g+2 of
-group g) are cut from the 256 bits of TWO Philox blocks:
+``gnss-ins-sim_amd/csrc/philox.hpp``).  A normal pair takes 64 bits: a 40-bit uniform for the radius
+(|z| up to 7.5 sigma) and a 24-bit uniform for the angle, so one 128-bit block gives TWO pairs and the six pairs
+of an IMU step are exactly three blocks:
 
     key     = (seed & 0xffffffff, seed >> 32)
-    A       = philox4x32_10((j, 2g,   run & 0xffffffff, run >> 32), key)      j = sample index
-    B       = philox4x32_10((j, 2g+1, run & 0xffffffff, run >> 32), key)
-    slot 0:  radius words (lo, hi) = (A0, A1)                                        angle word A2
-    slot 1:  radius words (lo, hi) = (A3, B0)                                        angle word B1
-    slot 2:  radius words (lo, hi) = ((A0 & 0x7ff) << 21 | (A3 & 0x7ff) << 10, B2)   angle word B3
-             (a radius uses all of hi and the top 21 bits of lo: the low 11 bits of A0 and A3 are the spare ones)
-    u1 = (((hi<<32 | lo) >> 11) + 0.5) * 2**-53 ;  u2 = (angle word + 0.5) * 2**-32
+    W       = philox4x32_7((j, s >> 1, run & 0xffffffff, run >> 32), key)      j = sample index, s = stream id
+    (a, b)  = (W0, W1) if s is even else (W2, W3)
+    u1 = ((a << 8 | b >> 24) + 0.5) * 2**-40 ;  u2 = ((b & 0xffffff) + 0.5) * 2**-24
     r  = sqrt(-2 ln u1) ;  z0 = r cos(2 pi u2) ;  z1 = r sin(2 pi u2)
 
 Stream ids (one stream -> two normals (z0, z1)):
 
-    0: accel drift x, y     1: accel drift z, accel white x    2: accel white y, z        (group 0)
-    3: gyro  drift x, y     4: gyro  drift z, gyro  white x    5: gyro  white y, z        (group 1)
-    6: odometer, -          7: mag x, y                        8: mag z, -                (group 2)
-    15: gps pos x, y       16: gps pos z, vel x               17: gps vel y, z            (group 5; j = GPS sample index)
+    0: accel drift x, y     1: accel drift z, accel white x    2: accel white y, z
+    3: gyro  drift x, y     4: gyro  drift z, gyro  white x    5: gyro  white y, z
+    6: odometer, -          7: mag x, y                        8: mag z, -
+    15: gps pos x, y       16: gps pos z, vel x               17: gps vel y, z            (j = GPS sample index)
 """
 import numpy as np
 
@@ -46,8 +44,12 @@ S_ODO, S_MAG_XY, S_MAG_Z = 6, 7, 8
 S_GPS_P_XY, S_GPS_PZ_VX, S_GPS_V_YZ = 15, 16, 17
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Philox4x32 with 10 rounds.  All arguments broadcastable uint32-valued arrays.
+ROUNDS = 7
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=ROUNDS):
+    """Philox4x32 with `rounds` rounds (7: the engine's generator; 10: Random123's default, kept for its
+    known-answer vectors).  All arguments broadcastable uint32-valued arrays.
 
     Returns four uint64 arrays holding 32-bit words.
     """
@@ -58,7 +60,7 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     k0 = int(k0) & 0xFFFFFFFF
     k1 = int(k1) & 0xFFFFFFFF
     c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
-    for rnd in range(10):
+    for rnd in range(rounds):
         p0 = M0 * c0            # 32x32 -> 64, cannot overflow uint64
         p1 = M1 * c2
         hi0, lo0 = p0 >> np.uint64(32), p0 & MASK32
@@ -71,38 +73,34 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def uniform53(lo, hi):
-    """Open-interval (0,1) uniform from two 32-bit words (53 significant bits)."""
-    v = ((hi << np.uint64(32)) | lo) >> np.uint64(11)
-    return (v.astype(np.float64) + 0.5) * (2.0 ** -53)
+def uniform40(a, b):
+    """Open-interval (0,1) uniform with 40 significant bits from the two words of a half block (exact in fp64)."""
+    v = (a << np.uint64(8)) | (b >> np.uint64(24))
+    return (v.astype(np.float64) + 0.5) * (2.0 ** -40)
 
 
 def stream_words(seed, run, stream, j):
-    """(lo, hi, angle) words of one stream: the radius uniform is uniform53(lo, hi), the angle uniform is
-    (angle + 0.5) 2^-32.  See the module docstring for the cut of two Philox blocks into three streams."""
+    """The two words (a, b) of one stream at sample(s) j: half (stream & 1) of block (j, stream >> 1)."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     run = np.asarray(run, dtype=np.uint64)
-    g, slot = divmod(int(stream), 3)
     jj = np.asarray(j, dtype=np.uint64)
     k0, k1 = seed & 0xFFFFFFFF, seed >> 32
-    A = philox4x32_10(jj, np.uint64(2 * g), run & MASK32, run >> np.uint64(32), k0, k1)
-    if slot == 0:
-        return A[0], A[1], A[2]
-    B = philox4x32_10(jj, np.uint64(2 * g + 1), run & MASK32, run >> np.uint64(32), k0, k1)
-    if slot == 1:
-        return A[3], B[0], B[1]
-    lo = ((A[0] & np.uint64(0x7FF)) << np.uint64(21)) | ((A[3] & np.uint64(0x7FF)) << np.uint64(10))
-    return lo, B[2], B[3]
+    w = philox4x32(jj, np.uint64(int(stream) >> 1), run & MASK32, run >> np.uint64(32), k0, k1)
+    return (w[2], w[3]) if int(stream) & 1 else (w[0], w[1])
+
+
+def box_muller(a, b):
+    """(z0, z1) from the two words of a half block."""
+    u1 = uniform40(a, b)
+    u2 = ((b & np.uint64(0xFFFFFF)).astype(np.float64) + 0.5) * (2.0 ** -24)
+    r = np.sqrt(-2.0 * np.log(u1))
+    ang = (2.0 * np.pi) * u2
+    return r * np.cos(ang), r * np.sin(ang)
 
 
 def normal_pair(seed, run, stream, j):
     """Two standard normals (z0, z1) for (run, stream, sample j); arrays broadcast."""
-    lo, hi, aw = stream_words(seed, run, stream, j)
-    u1 = uniform53(lo, hi)
-    u2 = (aw.astype(np.float64) + 0.5) * (2.0 ** -32)
-    r = np.sqrt(-2.0 * np.log(u1))
-    a = (2.0 * np.pi) * u2
-    return r * np.cos(a), r * np.sin(a)
+    return box_muller(*stream_words(seed, run, stream, j))
 
 
 def imu_normals(seed, run, n):

@@ -34,8 +34,8 @@ def test_rng_words_bit_exact_and_normals(ctx):
     for seed, run, stream in ((0, 0, 0), (20260923, 3, 5), (2 ** 63 + 12345, 2 ** 40 + 7, 17), (99, 12, 7)):
         z0, z1, w = ginsim.rng_normals(ctx, seed, run, stream, 65536, words=True)     # every table bin many times over
         j = np.arange(65536, dtype=np.uint64)
-        ref = philox.philox4x32_10(j, np.uint64(stream), np.uint64(run & 0xFFFFFFFF), np.uint64(run >> 32),
-                                   seed & 0xFFFFFFFF, seed >> 32)
+        ref = philox.philox4x32(j, np.uint64(stream), np.uint64(run & 0xFFFFFFFF), np.uint64(run >> 32),
+                                seed & 0xFFFFFFFF, seed >> 32)
         for k in range(4):
             assert np.array_equal(w[:, k].astype(np.uint64), ref[k]), 'Philox word %d differs' % k
         r0, r1 = philox.normal_pair(seed, run, stream, j)
@@ -44,31 +44,32 @@ def test_rng_words_bit_exact_and_normals(ctx):
 
 
 def test_box_muller_corner_cases(ctx):
-    """Words no seed will produce in a test: u = 1 (rounds up from 1 - 2^-54), the smallest u, mantissas on the
+    """Words no seed will produce in a test: the largest u (1 - 2^-41), the smallest u (2^-41), mantissas on the
     edges of the log table's bins (around 1 and around sqrt(1/2) / sqrt(2)), angles on sector edges of the sin/cos
-    table, plus a dense random sample -- all against NumPy's log / sqrt / cos / sin on the same uniforms."""
+    table, plus a dense random sample -- all against NumPy's log / sqrt / cos / sin on the same uniforms.
+    A row is (a, b, -, -): the two words of a half block (40-bit radius = a and the top byte of b, angle = low 24 bits of b)."""
     import ginsim
     from oracle import philox
     rng = np.random.default_rng(7)
     rows = []
     full, zero = 0xFFFFFFFF, 0
-    rows += [(full, full, zero, zero), (zero, zero, full, full), (zero, zero, zero, zero), (full, full, full, full)]
+    rows += [(full, full, zero, zero), (zero, zero, full, full), (zero, 0x00FFFFFF, zero, zero), (full, 0xFF000000, full, full)]
     # radius uniforms around u = 1/2, 1/4 (exponent change), around m = sqrt(2) and around every bin edge of the log table
-    for hi in (0x7FFFFFFF, 0x80000000, 0x3FFFFFFF, 0x40000000, 0xB504F333, 0xB504F334, 0x5A827999, 0x5A82799A):
-        for lo in (zero, full, 0x12345678):
-            rows.append((lo, hi, 0x9E3779B9, 0x3C6EF372))
-    for k in range(0, 2048, 7):                       # mantissa bins: top 11 bits of hi sweep, lo at both ends
-        rows.append((zero, (k << 21) | 0x100000, 1, 2))
-        rows.append((full, (k << 21) | 0x0FFFFF, 3, 4))
-    for i in range(256):                              # sector edges of the angle word: i 2^24 - 1 and i 2^24
-        rows.append((0xDEADBEEF, 0x6789ABCD, (i << 24), zero))
-        rows.append((0xDEADBEEF, 0x6789ABCD, ((i << 24) - 1) & full, full))
+    for a in (0x7FFFFFFF, 0x80000000, 0x3FFFFFFF, 0x40000000, 0xB504F333, 0xB504F334, 0x5A827999, 0x5A82799A):
+        for b in (zero, full, 0x12345678, 0xFF000000, 0x00FFFFFF):
+            rows.append((a, b, 0x9E3779B9, 0x3C6EF372))
+    for k in range(0, 2048, 7):                       # mantissa bins: top 11 bits of a sweep, the rest at both ends
+        rows.append(((k << 21) | 0x100000, zero, 1, 2))
+        rows.append(((k << 21) | 0x0FFFFF, full, 3, 4))
+    for i in range(512):                              # sector edges of the 24-bit angle: i 2^15 - 1 and i 2^15
+        rows.append((0xDEADBEEF, 0x67000000 | (i << 15), zero, zero))
+        rows.append((0xDEADBEEF, 0x67000000 | (((i << 15) - 1) & 0xFFFFFF), full, full))
     w = np.array(rows, dtype=np.uint64)
     w = np.vstack([w, rng.integers(0, 2 ** 32, size=(200000, 4), dtype=np.uint64)])
     z0, z1 = ginsim.box_muller(ctx, w.astype(np.uint32))
-    u1 = philox.uniform53(w[:, 0], w[:, 1])
-    u2 = (w[:, 2].astype(np.float64) + 0.5) * 2.0 ** -32
-    assert u1.max() == 1.0 and u1.min() == 2.0 ** -54
+    u1 = philox.uniform40(w[:, 0], w[:, 1])
+    u2 = ((w[:, 1] & np.uint64(0xFFFFFF)).astype(np.float64) + 0.5) * 2.0 ** -24
+    assert u1.max() == 1.0 - 2.0 ** -41 and u1.min() == 2.0 ** -41
     r = np.sqrt(-2.0 * np.log(u1))
     a = (2.0 * np.pi) * u2
     assert np.isfinite(z0).all() and np.isfinite(z1).all()

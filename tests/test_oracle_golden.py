@@ -8,14 +8,20 @@ from conftest import load_golden, assert_traj_close, ang_close
 
 
 def test_philox_known_answers():
-    # Random123 kat_vectors, philox4x32 10 rounds
-    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
-           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
-           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
-            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
-    for c, k, want in kat:
-        got = philox.philox4x32_10(*[np.uint64(x) for x in c], k[0], k[1])
-        assert tuple(int(x) for x in got) == want
+    # Random123 kat_vectors: philox4x32 with 7 rounds (the engine's generator) and with 10 (Random123's default)
+    kat = {7: [((0, 0, 0, 0), (0, 0), (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)),
+               ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)),
+               ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+                (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a))],
+           10: [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+                ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+                ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+                 (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]}
+    assert philox.ROUNDS == 7
+    for rounds, vectors in kat.items():
+        for c, k, want in vectors:
+            got = philox.philox4x32(*[np.uint64(x) for x in c], k[0], k[1], rounds=rounds)
+            assert tuple(int(x) for x in got) == want
 
 
 def test_normals_moments():
@@ -27,14 +33,14 @@ def test_normals_moments():
 
 
 def test_stream_cut_statistics():
-    """Three normal pairs are cut from two Philox blocks (oracle/philox.py): the six normals of a group must be
-    standard normal (Kolmogorov-Smirnov), mutually uncorrelated -- also in their squares, which would expose shared
-    radius bits -- and uncorrelated along the sample index and across runs."""
+    """Two normal pairs are cut from one Philox block (oracle/philox.py): the six normals of three consecutive streams
+    (two of them halves of the same block) must be standard normal (Kolmogorov-Smirnov), mutually uncorrelated -- also in
+    their squares, which would expose shared radius bits -- and uncorrelated along the sample index and across runs."""
     from scipy import stats
     n = 200000
     j = np.arange(n, dtype=np.uint64)
     z = []
-    for stream in (3, 4, 5):                      # group 1: slots 0, 1, 2
+    for stream in (3, 4, 5):                      # block 1 half 1, block 2 halves 0 and 1
         a, b = philox.normal_pair(12345, 77, stream, j)
         z += [a, b]
     z = np.array(z)
@@ -51,12 +57,13 @@ def test_stream_cut_statistics():
         assert abs(np.corrcoef(z[a][:-1], z[a][1:])[0, 1]) < lim            # consecutive samples
     other = philox.normal_pair(12345, 78, 5, j)[0]                             # the neighbouring run
     assert abs(np.corrcoef(z[4], other)[0, 1]) < lim
-    # the radius uniform of slot 2 is built from the spare low bits of the words that feed slots 0 and 1
-    w0 = philox.stream_words(12345, 77, 3, j)
-    w2 = philox.stream_words(12345, 77, 5, j)
-    u0, u2 = philox.uniform53(w0[0], w0[1]), philox.uniform53(w2[0], w2[1])
-    assert abs(np.corrcoef(u0, u2)[0, 1]) < lim
-    assert stats.kstest(u2, 'uniform').pvalue > 1e-3
+    # radius and angle uniforms of one stream share the word b (top byte / low 24 bits): independent all the same
+    w = philox.stream_words(12345, 77, 4, j)
+    u1 = philox.uniform40(w[0], w[1])
+    u2 = ((w[1] & np.uint64(0xFFFFFF)).astype(np.float64) + 0.5) * 2.0 ** -24
+    assert abs(np.corrcoef(u1, u2)[0, 1]) < lim
+    assert stats.kstest(u1, 'uniform').pvalue > 1e-3 and stats.kstest(u2, 'uniform').pvalue > 1e-3
+    assert u1.min() > 0.0 and u1.max() < 1.0
 
 
 @pytest.mark.parametrize('name', ['bosch', 'nxp', 'tumble'])

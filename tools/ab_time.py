@@ -9,7 +9,7 @@ ctx = ginsim.Context(0)
 acc, gyr = workloads.imu_grade('mid-accuracy')
 res = []
 P = os.environ.get('AB_PREC', 'f64')
-for rf, R, keep, prec in ((1, 65536, True, P), (1, 65536, False, P), (1, 262144, False, P), (0, 65536, True, P)):
+for rf, R, keep, prec in ((1, 65536, True, P), (1, 65536, False, P), (1, 262144, True, P), (1, 262144, False, P), (0, 65536, True, P)):
     ini, truth, _ = workloads.truth_from_profile('turn_90deg', 100.0, rf)
     job = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc, gyr, ini, runs=R, seed=1, keep_sensors=keep, keep_traj=keep, precision=prec)
     job.run()
