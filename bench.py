@@ -12,16 +12,32 @@ end-point statistics -> (N > 1) one all-reduce of the per-GPU statistics records
 The host-side part of a step (waiting for the 28-double record, the all-reduce, the Chan merge) is done while the
 next batches integrate (the record one step later, the non-blocking all-reduce two steps later): K timed steps =
 K launches + K reductions + K exchanges, all inside the timed region.
-Workload = BASELINE.json configs[1]: 90-degree-turn profile @100 Hz (n = 1000), 'mid-accuracy' 6-axis IMU,
-ref_frame = 1, 65 536 runs per GPU, fp64.  Weak scaling: every rank integrates its own 65 536 runs
-(global run ids are disjoint, the Philox counter carries the global id).
 
-Prints ONE JSON line (rank 0).  Inputs (truth, parameters) are resident in HBM before the timed region.
+Workload (config.workload names it):
+  N = 1   BASELINE.json configs[1] (C2): 90-degree-turn profile @100 Hz (n = 1000), 'mid-accuracy' 6-axis IMU,
+          ref_frame = 1, 65 536 runs, fp64 -- the configuration the metric is quoted on.
+  N > 1   BASELINE.json configs[3] (C4): the same profile, 131 072 runs per GPU (1 048 576 over 8 GPUs), one RCCL
+          all-reduce of the statistics records per step (backend nccl).  Weak scaling: every rank integrates its own
+          runs (global run ids are disjoint, the Philox counter carries the global id).
+
+The JSON line (rank 0) also carries, measured in the same process after the timed region (N = 1 only):
+  roofline             dominant kernel: algorithmic bytes / HIP-event launch time, vs 8 TB/s; `traffic` = HBM bytes per
+                       launch from rocprofv3 PMC passes (WRITE_SIZE, FETCH_SIZE x 2 on gfx950) run live on this build,
+                       or from profiles/pmc_traffic.json when that file carries this build's library hash, else null
+  configs[]            the other BASELINE configurations as legs: C3 (long_drive @200 Hz, 262 144 runs, stats-only),
+                       C4's per-GPU share, C5 fp32, Allan end-to-end (3600 s @ 400 Hz) and the mechanisation alone
+  cpu_baseline         the C port of the same path on the host cores (bounded sample) + the reference's own Python
+                       path (timed here when /root/reference is importable, otherwise the BASELINE.md figure, labelled)
+Inputs (truth, parameters) are resident in HBM before every timed region.
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -29,9 +45,38 @@ sys.path[:0] = [os.path.join(REPO, 'gnss-ins-sim_amd'), REPO]
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_SAMPLE_MC = 120   # accel3 + gyro3 + att3 + pos3 + vel3 doubles, all writes
+SEED = 20260923
 
 
-def cpu_baseline(fs, rf, ini, truth, acc, gyr, seed, budget_s):
+def lib_hash():
+    import ginsim
+    with open(ginsim.LIB_PATH, 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def roofline(alg_bytes, ms, kernel, traffic=None, **extra):
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    out = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+           'traffic': traffic, 'kernel': kernel, 'kernel_ms_avg': ms, 'algorithmic_bytes_per_launch': alg_bytes}
+    out.update(extra)
+    return out
+
+
+def time_launches(ctx, launch, reps, warm=2):
+    """(average, minimum) HIP-event time of `reps` launches issued BACK TO BACK on the context's stream, as the timed
+    region of the headline issues them: an event pair around every launch, no host synchronisation in between."""
+    for _ in range(warm):
+        launch()
+    for i in range(reps):
+        ctx.event_record(2 * i)
+        launch()
+        ctx.event_record(2 * i + 1)
+    ms = [ctx.event_elapsed(2 * i, 2 * i + 1) for i in range(reps)]
+    return sum(ms) / len(ms), min(ms)
+
+
+# --------------------------------------------------------------------------------------------- CPU baselines
+def cpu_baseline(fs, rf, ini, truth, acc, gyr, budget_s):
     """oracle/c/ginsim_oracle.c (kind 'port') on the host cores, same workload, bounded sample."""
     import ctypes
     from oracle import c_oracle
@@ -43,66 +88,220 @@ def cpu_baseline(fs, rf, ini, truth, acc, gyr, seed, budget_s):
         cores = 1
     n = truth['ref_accel'].shape[0]
     t0 = time.perf_counter()
-    c_oracle.mc_run(seed, 0, 64 * cores, fs, rf, truth, acc, gyr, ini)
+    c_oracle.mc_run(SEED, 0, 64 * cores, fs, rf, truth, acc, gyr, ini)
     probe = time.perf_counter() - t0
     runs = int(max(64 * cores, min(2_000_000, budget_s / max(probe, 1e-6) * 64 * cores)))
     t0 = time.perf_counter()
-    c_oracle.mc_run(seed, 0, runs, fs, rf, truth, acc, gyr, ini)
+    c_oracle.mc_run(SEED, 0, runs, fs, rf, truth, acc, gyr, ini)
     dt = time.perf_counter() - t0
-    return {'value': runs * n / dt, 'unit': 'sample*MC/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d runs x %d samples of the same workload through oracle/c/ginsim_oracle.c '
-                      '(OpenMP over runs, %.1f s)' % (runs, n, dt)}
+    out = {'value': runs * n / dt, 'unit': 'sample*MC/s', 'cores': cores, 'kind': 'port',
+           'sample': '%d runs x %d samples of the same workload through oracle/c/ginsim_oracle.c '
+                     '(OpenMP over runs, %.1f s)' % (runs, n, dt)}
+    out['reference_python'] = reference_python_baseline(min(budget_s, 15.0))
+    return out
 
 
-def mechanisation_only(ginsim, ctx, job, fs, rf, truth, ini, R, n, reps=10):
-    """Outside the timed region: FreeIntegration.run alone for the whole batch -- the given-sensors kernel reads the
-    accel/gyro series the last step materialised (48 B) and writes att/pos/vel (72 B) per sample*MC.  This is the
-    HBM-bound piece of the path; the fused kernel above is fp64-VALU-bound."""
-    rep = ginsim.MonteCarloJob(ctx, fs, rf, truth, None, None, ini, runs=R, keep_traj=True,
-                               given={'gyro': job.buffer('gyro'), 'accel': job.buffer('accel')})
-    rep.run()
-    ms = []
-    for _ in range(reps):
-        ctx.timer_begin()
-        rep.launch()
-        ms.append(ctx.timer_end())
-    same = bool((rep.end_errors('free') == job.end_errors('free')).all())
-    name = rep.kernel_name()
-    rep.release()
-    avg = sum(ms) / len(ms)
-    b = 120 * R * n + 72 * R
-    return {'kernel': name, 'kernel_ms_avg': avg, 'algorithmic_bytes_per_launch': b, 'achieved': b / avg / 1e6, 'unit': 'GB/s',
-            'peak': HBM_PEAK_GBS, 'frac': b / avg / 1e6 / HBM_PEAK_GBS, 'traffic': pmc_traffic('mc_kernel_rf%d_free_given' % rf),
-            'sample_MC_per_s': R * n / avg * 1e3,
-            'bit_identical_to_fused_kernel': same}
+def reference_python_baseline(budget_s):
+    """The reference's own CPU path (Sim.run on config 1, it is single-threaded): timed here when the reference is
+    importable (the build container), otherwise the figure BASELINE.md measured, labelled as quoted."""
+    ref = '/root/reference'
+    if os.path.isdir(os.path.join(ref, 'gnss_ins_sim')):
+        code = (
+            "import sys, time, os, io, contextlib\n"
+            "sys.dont_write_bytecode = True\n"
+            "os.environ.setdefault('MPLBACKEND', 'Agg')\n"
+            "sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from gnss_ins_sim.sim import imu_model, ins_sim\n"
+            "from demo_algorithms import free_integration\n"
+            "csv = %r + '/demo_motion_def_files/motion_def-90deg_turn.csv'\n"
+            "ini = np.genfromtxt(csv, delimiter=',', skip_header=1, max_rows=1)\n"
+            "ini[0:2] *= np.pi / 180; ini[6:9] *= np.pi / 180\n"
+            "R = %d\n"
+            "np.random.seed(2024)\n"
+            "imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False)\n"
+            "sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, algorithm=free_integration.FreeIntegration(ini))\n"
+            "t0 = time.perf_counter()\n"
+            "with contextlib.redirect_stdout(io.StringIO()):\n"
+            "    sim.run(R)\n"
+            "print(R, 1000, time.perf_counter() - t0)\n")
+        runs = max(10, int(budget_s * 4.76e4 / 1000))
+        try:
+            out = subprocess.run([sys.executable, '-c', code % (ref, ref, runs)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                 timeout=20 * budget_s + 60, universal_newlines=True, cwd=tempfile.gettempdir())
+            r, n, dt = out.stdout.split()[-3:]
+            return {'value': int(r) * int(n) / float(dt), 'unit': 'sample*MC/s', 'cores': 1, 'kind': 'reference',
+                    'sample': 'unmodified reference Sim.run(%s) on config 1 (90-degree turn @100 Hz, mid-accuracy, ref_frame 1), '
+                              '%.1f s, single-threaded by construction' % (r, float(dt))}
+        except Exception as e:                                     # noqa: BLE001 -- a baseline must not fail the bench
+            return {'value': None, 'kind': 'reference', 'error': repr(e)[:200]}
+    return {'value': 4.76e4, 'unit': 'sample*MC/s', 'cores': 1, 'kind': 'quoted',
+            'sample': 'BASELINE.md section 2: unmodified reference Sim.run(1000) on config 1 in the survey container (Xeon 2.1 GHz, '
+                      '1 core; the reference is single-threaded); /root/reference does not exist on this host, so it is not timed here'}
 
 
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
-    path = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
+# --------------------------------------------------------------------------------------------- PMC traffic
+def pmc_traffic_live(kernels, timeout_s=150):
+    """HBM bytes per launch of `kernels` (names as rocprofv3 reports them, without arguments) from two rocprofv3 --pmc
+    passes of this script's --pmc-child mode (same build, same workload, 3 launches each): WRITE_SIZE and FETCH_SIZE in
+    KiB; FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section).  Returns {kernel: {...}} or None."""
+    import sqlite3
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None
+    vals = {}
+    work = tempfile.mkdtemp(prefix='ginsim_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
     try:
-        with open(path) as f:
-            return json.load(f).get(kernel_key, {}).get('hbm_bytes_per_launch')
+        for counter in ('WRITE_SIZE', 'FETCH_SIZE'):
+            d = os.path.join(work, counter)
+            cmd = [exe, '--pmc', counter, '--kernel-trace', '-d', d, '-o', 'pmc', '--', sys.executable,
+                   os.path.abspath(__file__), '--pmc-child']
+            subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith('.db')]
+            if not dbs:
+                return None
+            con = sqlite3.connect(dbs[0])
+            for name, cnt, avg in con.execute("select kernel_name, count(*), avg(value) from counters_collection "
+                                              "where counter_name = ? group by kernel_name", (counter,)):
+                for k in kernels:
+                    if name.startswith('void ' + k + '(') or name.startswith(k + '('):
+                        vals.setdefault(k, {})[counter] = (avg, cnt)
+            con.close()
+        out = {}
+        for k, c in vals.items():
+            if 'WRITE_SIZE' in c and 'FETCH_SIZE' in c:
+                w, f = c['WRITE_SIZE'][0] * 1024.0, 2.0 * c['FETCH_SIZE'][0] * 1024.0
+                out[k] = {'hbm_bytes_per_launch': w + f, 'write_bytes': w, 'fetch_bytes_corrected': f,
+                          'dispatches': int(c['WRITE_SIZE'][1])}
+        return out or None
+    except Exception:                                              # noqa: BLE001 -- profiling is evidence, not the product
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def pmc_traffic_file(build):
+    """profiles/pmc_traffic.json, only if it was measured on THIS build of libginsim.so."""
+    try:
+        with open(os.path.join(REPO, 'profiles', 'pmc_traffic.json')) as f:
+            d = json.load(f)
+        return d.get('kernels') if d.get('libginsim_sha256') == build else None
     except (OSError, ValueError):
         return None
 
 
+# --------------------------------------------------------------------------------------------- legs (N = 1)
+def leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, reps=10):
+    """FreeIntegration.run alone for the whole batch: the given-sensors kernel reads the accel/gyro series the last step
+    materialised (48 B) and writes att/pos/vel (72 B) per sample*MC -- the HBM-bound piece of the path."""
+    rep = ginsim.MonteCarloJob(ctx, fs, rf, truth, None, None, ini, runs=R, keep_traj=True,
+                               given={'gyro': job.buffer('gyro'), 'accel': job.buffer('accel')})
+    rep.run()
+    avg, mn = time_launches(ctx, rep.launch, reps)
+    same = bool((rep.end_errors('free') == job.end_errors('free')).all())
+    name = rep.kernel_name()
+    rep.release()
+    b = 120 * R * n + 72 * R
+    return {'name': 'mechanisation_only', 'workload': 'FreeIntegration.run alone on the device-resident sensors of the C2 batch '
+            '(%d runs x %d samples; 48 B read + 72 B written per sample*MC)' % (R, n), 'dtype': 'f64',
+            'sample_MC_per_s': R * n / avg * 1e3, 'kernel_ms_min': mn,
+            'roofline': roofline(b, avg, name, (traffic or {}).get(name, {}).get('hbm_bytes_per_launch')),
+            'bit_identical_to_fused_kernel': same}
+
+
+def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precision, reps, gps=False):
+    ini, truth, _ = workloads.truth_from_profile(profile, fs, rf, fs_gps=10.0 if gps else 0.0, gps=gps)
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    n = truth['ref_accel'].shape[0]
+    job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, seed=SEED, keep_sensors=keep, keep_traj=keep,
+                               precision=precision)
+    job.run()
+    avg, mn = time_launches(ctx, job.launch, reps)
+    st = job.stats('free')
+    unit = (BYTES_PER_SAMPLE_MC if precision == 'f64' else BYTES_PER_SAMPLE_MC // 2) if keep else 0
+    alg = unit * R * n + 72 * R
+    out = {'name': name, 'workload': desc, 'dtype': precision, 'runs': R, 'samples_per_run': n, 'materialised': keep,
+           'sample_MC_per_s': R * n / avg * 1e3, 'kernel_ms_min': mn,
+           'roofline': roofline(alg, avg, job.kernel_name(), None, **({} if keep else {
+               'note': 'stats-only: nothing is written per sample (72 B per RUN), the kernel is fp64-VALU-bound by construction'})),
+           'result': {'att_std_deg': (st.std[:3] * 57.29577951308232).tolist(), 'vel_std_mps': st.std[6:9].tolist(), 'runs': st.count}}
+    job.release()
+    return out
+
+
+def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0):
+    """BASELINE config 5, second half, END TO END on the device: static truth for 3600 s @ 400 Hz (n = 1 440 000) ->
+    accel + gyro series of `runs` runs generated by the time-parallel sensor kernels -> re-layout -> ONE Allan call over all
+    6 x runs series (46 averaging factors).  Algorithmic bytes of the Allan call: 8 B per sample (one read of the series)."""
+    import numpy as np
+    from ginsim._lib import check
+    text = open(workloads.profile_path('static_1800s')).read().split('\n')
+    ini, _ = workloads.parse_motion('\n'.join(text[:4]))
+    seg = np.array([[1.0, 0, 0, 0, 0, 0, 0, seconds, 0.0]])
+    raw = ginsim.pathgen(ini, seg, fs, 0.0, workloads.HIGH_MOBILITY, 1)
+    truth = {'ref_accel': np.ascontiguousarray(raw['imu'][:, 1:4]), 'ref_gyro': np.ascontiguousarray(raw['imu'][:, 4:7]),
+             'ref_pos': raw['nav'][:, 1:4], 'ref_vel': raw['nav'][:, 4:7], 'ref_att': raw['nav'][:, 7:10]}
+    n = truth['ref_accel'].shape[0]
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    job = ginsim.MonteCarloJob(ctx, fs, 1, truth, acc, gyr, None, runs=runs, algos=(), seed=SEED, keep_sensors=True)
+    job.run()
+    tau, ad = job.allan(fs)                                        # warm-up (scratch allocation)
+    ctx.timer_begin()
+    job.launch()
+    gen_ms = ctx.timer_end()
+    t0 = time.perf_counter()
+    tau, ad = job.allan(fs)
+    e2e_wall_ms = (time.perf_counter() - t0) * 1e3
+    S = 6 * runs
+    tmp = ctx.malloc(8 * S * n)
+    for i, nm in enumerate(('accel', 'gyro')):
+        check(ginsim.lib.ginsim_runs_to_series(ctx.handle, job.buffer(nm).ptr, 3, n, runs, tmp.at(i * 24 * n * runs)))
+    ginsim.allan_var(ctx, tmp, n, S, n, fs)
+    ms = []
+    for _ in range(8):          # every call ends with the copy of the sums to the host: the calls cannot overlap
+        ctx.timer_begin()
+        ginsim.allan_var(ctx, tmp, n, S, n, fs)
+        ms.append(ctx.timer_end())
+    tmp.free()
+    avg = sum(ms) / len(ms)
+    # white-noise known answer: AD(tau) = ARW / sqrt(tau) at tau = 1 s (SURVEY 8(c) T6)
+    k1 = int(np.argmin(np.abs(tau - 1.0)))
+    arw = float(np.asarray(gyr['arw'])[0])
+    out = {'name': 'C5_allan_end_to_end', 'dtype': 'f64',
+           'workload': 'static %g s @ %g Hz (n = %d), mid-accuracy IMU, %d runs: sensor generation -> re-layout -> Allan variance '
+                       'of %d series, %d averaging factors' % (seconds, fs, n, runs, S, tau.size),
+           'sensor_generation_ms': gen_ms, 'relayout_plus_allan_wall_ms': e2e_wall_ms, 'allan_call_ms_min': min(ms),
+           'samples_per_s_allan_call': S * n / avg * 1e3,
+           'roofline': roofline(8.0 * S * n, avg, 'ginsim_allan (allan_level_kernel + tail, whole call incl. the copy of the sums)', None),
+           'result': {'ad_gyro_x_at_1s_over_arw': float(ad['gyro'][:, k1, 0].mean() / arw * np.sqrt(tau[k1]))}}
+    job.release()
+    return out
+
+
+# --------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--runs-per-gpu', type=int, default=65536)
+    ap.add_argument('--runs-per-gpu', type=int, default=0, help='default: 65 536 at N = 1 (C2), 131 072 at N > 1 (C4)')
     ap.add_argument('--profile', default='turn_90deg')
     ap.add_argument('--fs', type=float, default=100.0)
     ap.add_argument('--ref-frame', type=int, default=1)
     ap.add_argument('--stats-only', action='store_true', help='do not materialise sensors/trajectories')
     ap.add_argument('--precision', choices=['f64', 'f32'], default='f64', help="f32 = BASELINE config 5's single-precision kernel")
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
+    ap.add_argument('--no-legs', action='store_true', help='skip the configs[] legs (C3, C4 share, C5, Allan, mechanisation)')
+    ap.add_argument('--pmc', choices=['live', 'file', 'off'], default='live',
+                    help='roofline.traffic: rocprofv3 PMC passes of this build (live), the stamped profiles/pmc_traffic.json, or null')
+    ap.add_argument('--pmc-child', action='store_true', help='internal: the short workload the live PMC passes profile')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for tests)')
     ap.add_argument('--shared-device', action='store_true',
                     help='TEST ONLY: every rank uses GPU 0 (exercises the N > 1 control flow on a one-GPU box)')
     args = ap.parse_args()
+    if args.pmc_child:
+        args.steps, args.warmup, args.cpu_baseline_seconds, args.no_legs, args.pmc = 3, 1, 0.0, True, 'off'
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -130,12 +329,13 @@ def main():
             dist.init_process_group(args.backend)
     ctx = ginsim.Context(local_rank)
 
-    fs, rf, R, seed = args.fs, args.ref_frame, args.runs_per_gpu, 20260923
+    fs, rf = args.fs, args.ref_frame
+    R = args.runs_per_gpu or (65536 if world == 1 else 131072)
     ini, truth, _ = workloads.truth_from_profile(args.profile, fs, rf)
     acc, gyr = workloads.imu_grade('mid-accuracy')
     n = truth['ref_accel'].shape[0]
     keep = not args.stats_only
-    job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, algos=('free',), seed=seed,
+    job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, algos=('free',), seed=SEED,
                                keep_sensors=keep, keep_traj=keep, precision=args.precision)
     unit_bytes = BYTES_PER_SAMPLE_MC if args.precision == 'f64' else BYTES_PER_SAMPLE_MC // 2
     group = dist.group.WORLD if world > 1 else None
@@ -204,39 +404,75 @@ def main():
     kern_avg_ms = float(np.mean(kern_ms))
     assert merged.count == world * R, (merged.count, world * R)
 
+    if args.pmc_child:                                      # the given-sensors kernel is profiled in the same pass
+        if keep and args.precision == 'f64':
+            leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, None, reps=3)
+        job.release()
+        ctx.close()
+        return
+
     if rank == 0:
         total_units = float(world) * R * n * args.steps
         alg_bytes = (unit_bytes if keep else 0) * R * n + 72 * R      # per launch, per GPU
-        achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
         r2d = 180.0 / np.pi
+        build = lib_hash()
+        kname = job.kernel_name()
+        given_name = 'ginsim::mc_kernel<%d, 1, true, false>' % rf
+        traffic, traffic_source = None, None
+        if world == 1 and args.precision == 'f64' and keep:
+            if args.pmc == 'live':
+                traffic, traffic_source = pmc_traffic_live([kname, given_name]), 'live: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of `bench.py --pmc-child` on this build'
+            if traffic is None and args.pmc in ('live', 'file'):
+                traffic, traffic_source = pmc_traffic_file(build), 'profiles/pmc_traffic.json (same libginsim.so hash)'
+            if traffic is None:
+                traffic_source = None
+        cfg_name = ('BASELINE configs[1] (C2)' if (world == 1 and R == 65536) else
+                    'BASELINE configs[3] (C4: %d runs over %d GPUs)' % (world * R, world) if R == 131072 else 'custom')
         out = {
             'metric': 'Monte-Carlo IMU samples integrated/sec', 'value': total_units / elapsed,
             'unit': 'sample*MC/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: %s @%g Hz (n=%d), mid-accuracy 6-axis IMU, ref_frame=%d, '
-                                   'free_integration, %d MC runs per GPU, %s' %
-                                   (args.profile, fs, n, rf, R,
+            'config': {'workload': '%s: %s @%g Hz (n=%d), mid-accuracy 6-axis IMU, ref_frame=%d, free_integration, '
+                                   '%d MC runs per GPU, %s' %
+                                   (cfg_name, args.profile, fs, n, rf, R,
                                     'sensors+trajectories materialised (%d B/sample*MC)' % unit_bytes if keep else 'stats-only'),
                        'runs_per_gpu': R, 'samples_per_run': n, 'total_runs_per_step': world * R,
-                       'parallelism': 'mc-shard x%d, one all-reduce of the 28-double stats record' % world,
-                       'device': ctx.name()},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': pmc_traffic('mc_kernel_rf%d_free_%s' % (rf, 'keep' if keep else 'stats')) if args.precision == 'f64' else None,
-                         'kernel': job.kernel_name(), 'kernel_ms_avg': kern_avg_ms,
-                         'algorithmic_bytes_per_launch': alg_bytes,
-                         'note': 'fp64 transcendental/VALU-bound, not HBM-bound: see DESIGN.md (roofline)'},
+                       'parallelism': 'mc-shard x%d, one all-reduce (%s) of the 28-double stats record per step' % (
+                           world, 'RCCL' if args.backend == 'nccl' else args.backend),
+                       'device': ctx.name(), 'libginsim_sha256': build,
+                       'rng': 'Philox4x32-7, 64 bits per Box-Muller pair (3 blocks per IMU step)'},
+            'roofline': roofline(alg_bytes, kern_avg_ms, kname, (traffic or {}).get(kname, {}).get('hbm_bytes_per_launch'),
+                                 traffic_source=traffic_source,
+                                 note='writes exactly its algorithmic bytes; limited by fp64/integer VALU issue at the power-capped clock, '
+                                      'see DESIGN.md section 4.1'),
             'result': {'att_std_deg': (merged.std[:3] * r2d).tolist(), 'vel_std_mps': merged.std[6:9].tolist(),
                        'runs': merged.count},
         }
-        if world == 1 and keep and args.precision == 'f64':
-            out['mechanisation_only'] = mechanisation_only(ginsim, ctx, job, fs, rf, truth, ini, R, n)
+        if world == 1 and not args.no_legs:
+            legs = []
+            if keep and args.precision == 'f64':
+                legs.append(leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic))
+                out['mechanisation_only'] = legs[-1]
+            job.release()
+            job = None
+            legs.append(leg_mc(ginsim, workloads, ctx, 'C4_per_gpu_share', 'BASELINE configs[3] per-GPU share: turn_90deg @100 Hz, '
+                               '131 072 runs, fp64, materialised', 'turn_90deg', 100.0, 1, 131072, True, 'f64', 10))
+            legs.append(leg_mc(ginsim, workloads, ctx, 'C3', 'BASELINE configs[2]: long_drive @200 Hz (n = 193 036), ref_frame 0, 262 144 '
+                               'runs, fp64, stats-only (6-axis fused kernel; trajectories would be 6 TB)', 'long_drive', 200.0, 0,
+                               262144, False, 'f64', 2, gps=True))
+            legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32', 'BASELINE configs[4]: fp32 kernel on the C2 workload, 65 536 runs, '
+                               'materialised (60 B/sample*MC)', 'turn_90deg', 100.0, 1, 65536, True, 'f32', 20))
+            legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32_262144', 'fp32 kernel, 262 144 runs, materialised', 'turn_90deg', 100.0, 1,
+                               262144, True, 'f32', 10))
+            legs.append(leg_allan(ginsim, workloads, ctx))
+            out['configs'] = legs
         if world == 1 and args.cpu_baseline_seconds > 0:
-            out['cpu_baseline'] = cpu_baseline(fs, rf, ini, truth, acc, gyr, seed, args.cpu_baseline_seconds)
+            out['cpu_baseline'] = cpu_baseline(fs, rf, ini, truth, acc, gyr, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
 
-    job.release()
+    if job is not None:
+        job.release()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -46,6 +46,19 @@ class DeviceBuffer(object):
             pass
 
 
+class DeviceView(object):
+    """A sub-range of a DeviceBuffer (not owning)."""
+
+    def __init__(self, parent, byte_offset, nbytes):
+        self.parent, self.ptr, self.nbytes = parent, parent.ptr + int(byte_offset), int(nbytes)
+
+    def at(self, byte_offset):
+        return self.ptr + int(byte_offset)
+
+    def free(self):
+        self.ptr = None
+
+
 class Context(object):
     """One GPU (one HIP stream).  Raises GinsimError when no GPU is visible -- there is no CPU path."""
 
@@ -308,8 +321,10 @@ class MonteCarloJob(object):
         # outputs
         plane = self.n * self.runs * self._esize
         if self.keep_sensors:
-            self._bufs['accel'] = ctx.malloc(3 * plane)
-            self._bufs['gyro'] = ctx.malloc(3 * plane)
+            # one allocation, accel then gyro: for a single run that IS the [sensor][axis][n] layout ginsim_allan reads
+            self._bufs['imu'] = ctx.malloc(6 * plane)
+            self._bufs['accel'] = DeviceView(self._bufs['imu'], 0, 3 * plane)
+            self._bufs['gyro'] = DeviceView(self._bufs['imu'], 3 * plane, 3 * plane)
             p.out_accel, p.out_gyro = self._bufs['accel'].ptr, self._bufs['gyro'].ptr
             if self.want_odo:
                 self._bufs['odo'] = ctx.malloc(plane)
@@ -325,25 +340,29 @@ class MonteCarloJob(object):
     # bytes the launch writes to HBM (the algorithmic traffic of SURVEY 8(d))
     def allan(self, fs=None, names=('accel', 'gyro')):
         """Allan deviation of the kept sensor series on the device (allan_analysis.py:33-49 for every run at once):
-        returns (tau (ntau,), {name: (runs, ntau, 3)}).  One run is already laid out as three contiguous series; more
-        runs are re-laid out [3][n][runs] -> [runs][3][n] on the device first."""
+        returns (tau (ntau,), {name: (runs, ntau, 3)}).  The series of all named sensors are laid out as
+        [sensor][run][axis][n] (one run is already three contiguous series; more runs are re-laid out
+        [3][n][runs] -> [runs][3][n] on the device) and go through ONE ginsim_allan call."""
         if not self.keep_sensors or self.precision != 'f64':
             raise ValueError('Allan analysis needs the fp64 sensor series (keep_sensors=True)')
         fs = float(self.params.fs if fs is None else fs)
-        out, tau = {}, None
-        for nm in names:
-            src = self._bufs[nm]
-            if self.runs == 1:
-                ptr, tmp = src.ptr, None
-            else:
-                tmp = self.ctx.malloc(3 * self.n * self.runs * 8)
-                check(lib.ginsim_runs_to_series(self.ctx.handle, src.ptr, 3, self.n, self.runs, tmp.ptr))
-                ptr = tmp.ptr
-            avar, tau = allan_var(self.ctx, ptr, self.n, 3 * self.runs, self.n, fs)
-            if tmp is not None:
-                tmp.free()
-            out[nm] = np.sqrt(avar).reshape(self.runs, 3, -1).transpose(0, 2, 1).copy()
-        return tau, out
+        names = tuple(names)
+        per = 3 * self.n * self.runs * 8
+        contiguous = self.runs == 1 and all(self._bufs[names[i + 1]].ptr == self._bufs[names[i]].ptr + per
+                                            for i in range(len(names) - 1))
+        tmp = None
+        if contiguous:
+            ptr = self._bufs[names[0]].ptr
+        else:
+            tmp = self.ctx.malloc(per * len(names))
+            for i, nm in enumerate(names):      # one run: C = 3, R = 1 makes the re-layout a plain copy
+                check(lib.ginsim_runs_to_series(self.ctx.handle, self._bufs[nm].ptr, 3, self.n, self.runs, tmp.at(i * per)))
+            ptr = tmp.ptr
+        avar, tau = allan_var(self.ctx, ptr, self.n, 3 * self.runs * len(names), self.n, fs)
+        if tmp is not None:
+            tmp.free()
+        ad = np.sqrt(avar).reshape(len(names), self.runs, 3, -1)
+        return tau, {nm: ad[i].transpose(0, 2, 1).copy() for i, nm in enumerate(names)}
 
     def buffer(self, name):
         """Device buffer of a materialised series ('accel', 'gyro', 'odo', 'traj_free', ...), e.g. to feed given=."""

@@ -36,7 +36,7 @@ def _bench(nproc, extra):
 
 
 def test_bench_two_ranks_share_the_work():
-    common = ['--steps', '2', '--warmup', '1', '--runs-per-gpu', '8192', '--cpu-baseline-seconds', '0']
+    common = ['--steps', '2', '--warmup', '1', '--runs-per-gpu', '8192', '--cpu-baseline-seconds', '0', '--no-legs', '--pmc', 'off']
     one = _bench(1, common)
     two = _bench(2, common + ['--backend', 'gloo', '--shared-device'])
     assert two['n_gpus'] == 2 and two['scaling'] == 'weak' and two['config']['total_runs_per_step'] == 16384
