@@ -214,6 +214,11 @@ class StatsResult(object):
         self.m2 = np.array(s.m2[:])
         self.maxabs = np.array(s.maxabs[:])
 
+    @staticmethod
+    def zero():
+        """The record of a rank that holds no runs (neutral element of the merge)."""
+        return StatsResult(_lib.Stats())
+
     @property
     def std(self):      # np.std(ddof=0), ins_data_manager.py:808
         return np.sqrt(self.m2 / self.count)
@@ -234,6 +239,8 @@ class StatsResult(object):
     def merge(packed_rows):
         """Merge packed partials (one row per device) with the library's Chan merge."""
         rows = [r for r in packed_rows if r[0] > 0]
+        if not rows:
+            return StatsResult.zero()
         arr = (_lib.Stats * len(rows))(*[StatsResult.unpack(r) for r in rows])
         out = _lib.Stats()
         check(lib.ginsim_stats_merge(arr, len(rows), C.byref(out)))

@@ -143,40 +143,53 @@ class InsDataMgr(object):
         self._mc = mc
 
     def get_error_stats(self, data_name, err_stats_start=0, angle=False, use_output_units=False, extra_opt=''):
-        """InsDataMgr.get_error_stats (ins_data_manager.py:385-452)."""
+        """InsDataMgr.get_error_stats (ins_data_manager.py:385-452).
+
+        Outputs of plugins inside the fused kernel are reduced on the device (their series may not even be kept);
+        outputs of hosted plugins (user code, host arrays) and logged data get the reference's host computation
+        (array_error :519-553, __end_point_error_stats :717-759, __process_error_stats :761-795).  When both kinds
+        produced `data_name`, the groups are reported side by side as the reference does (:810-832)."""
         if data_name not in self.available:
             print('error stats: %s is not available.' % data_name)
             return None
         if 'ref_' + data_name not in self.available:
             print('%s has no reference.' % data_name)
             return None
-        if self._mc is None or data_name not in _END_SLICE:
-            raise NotImplementedError('error statistics are computed on the device for att_euler/pos/vel of a '
-                                      'Monte-Carlo Sim.run(); %r is outside that path' % data_name)
         src = self._all[data_name]
         units, out_units = list(src.units), list(src.output_units)
         ned = data_name == 'pos' and self.ref_frame.data == 0 and extra_opt == 'ned'
         if ned:
             units, out_units = list(_XYZ), list(_XYZ)
-        names = list(self._mc.algo_names)
-        if err_stats_start == -1:                            # end-point statistics, :717-759
-            per_algo = {a: self._mc.end_stats(a, ned=ned) for a in names}
-            sl = _END_SLICE[data_name]
-            pick = lambda st: {'max': st.maxabs[sl].copy(), 'avg': st.mean[sl].copy(), 'std': st.std[sl].copy()}
-            if len(names) == 1:
-                stat = pick(per_algo[names[0]])
-            else:                                            # one group per algorithm name, :810-832
-                stat = {'max': {}, 'avg': {}, 'std': {}}
-                for a in names:
-                    p = pick(per_algo[a])
-                    for s in stat:
-                        stat[s][a] = p[s]
-        else:                                                # process error of every run, :761-795
-            t = np.asarray(self.time.data)
-            hit = np.where(t >= max(err_stats_start, 0))[0]
-            if hit.shape[0] == 0:
-                print('err_stats_start exceeds max data points.')
-            stat = self._mc.process_stats(data_name, int(hit[0]) if hit.shape[0] else 0, ned=ned)
+        on_device = self._mc is not None and data_name in _END_SLICE
+        names = list(self._mc.algo_names) if on_device else []
+        host = self._host_part(src.data, names)                 # {key: array} (or {None: array}) computed on the host
+        end_point = err_stats_start == -1
+        stat = None
+        if names:
+            if end_point:                                        # end-point statistics, :717-759
+                per_algo = {a: self._mc.end_stats(a, ned=ned) for a in names}
+                sl = _END_SLICE[data_name]
+                pick = lambda st: {'max': st.maxabs[sl].copy(), 'avg': st.mean[sl].copy(), 'std': st.std[sl].copy()}
+                stat = {s: {a: pick(per_algo[a])[s] for a in names} for s in ('max', 'avg', 'std')}
+            else:                                                # process error of every run, :761-795
+                t = np.asarray(self.time.data)
+                hit = np.where(t >= max(err_stats_start, 0))[0]
+                if hit.shape[0] == 0:
+                    print('err_stats_start exceeds max data points.')
+                stat = self._mc.process_stats(data_name, int(hit[0]) if hit.shape[0] else 0, ned=ned)
+        if host:
+            hstat = self._host_error_stats(data_name, host, err_stats_start, angle, ned)
+            if hstat is None:
+                return None
+            if stat is None:
+                stat = hstat
+            else:
+                for s in ('max', 'avg', 'std'):
+                    stat[s].update(hstat[s] if isinstance(hstat[s], dict) else {'data': hstat[s]})
+        if stat is None:
+            return None
+        if end_point and isinstance(stat['max'], dict) and len(stat['max']) == 1:     # one group: plain arrays, :727-735
+            stat = {s: next(iter(stat[s].values())) for s in ('max', 'avg', 'std')}
         if use_output_units:
             for s in stat:
                 if isinstance(stat[s], dict):
@@ -186,19 +199,96 @@ class InsDataMgr(object):
         stat['units'] = str(out_units)
         return stat
 
+    @staticmethod
+    def _host_part(data, device_names):
+        """The host-resident part of a series: everything that is not a device view of a fused plugin."""
+        if isinstance(data, sim_data.McSeries):
+            return {}
+        if isinstance(data, sim_data.ChainSeries):
+            return dict(data.extra)
+        if isinstance(data, dict):                              # a plain dict only ever holds host arrays
+            return dict(data)
+        if isinstance(data, np.ndarray):
+            return {None: data}
+        return {}
+
+    def array_error(self, x, r, angle=False, lla=0):
+        """InsDataMgr.array_error (ins_data_manager.py:519-553) for host arrays."""
+        from ..attitude import attitude
+        from ..geoparams import geoparams
+        x, r = np.asarray(x, dtype=np.float64), np.asarray(r, dtype=np.float64)
+        if lla == 0:
+            err = x - r
+            return attitude.angle_range_pi(err) if angle else err
+        err = geoparams.lla2ecef_batch(x) - geoparams.lla2ecef_batch(r)
+        if lla == 1:                                            # attitude.ecef_to_ned, attitude.py:596-603
+            sl, cl, so, co = np.sin(r[:, 0]), np.cos(r[:, 0]), np.sin(r[:, 1]), np.cos(r[:, 1])
+            err = np.stack([-sl * co * err[:, 0] - sl * so * err[:, 1] + cl * err[:, 2],
+                            -so * err[:, 0] + co * err[:, 1],
+                            -cl * co * err[:, 0] - cl * so * err[:, 1] - sl * err[:, 2]], axis=1)
+        return err
+
+    def _host_error_stats(self, data_name, data, err_stats_start, angle, ned):
+        """Reference statistics of host arrays: data = {key: (n,k) array} or {None: array}."""
+        ref_all = np.asarray(self._all['ref_' + data_name].data)
+        t = np.asarray(self.time.data) if 'time' in self.available else None
+        errs, starts = {}, {}
+        for k, x in data.items():
+            x = np.asarray(x, dtype=np.float64)
+            ref, tk = ref_all, t
+            if ref.shape[0] != x.shape[0]:                      # interpolate the reference, :489-497, 835-849
+                at = self.algo_time.data if 'algo_time' in self.available else None
+                at = at.get(k) if isinstance(at, dict) else at
+                if at is None or t is None:
+                    print('%s or %s is not available.' % (self.algo_time.name, self.time.name))
+                    return None
+                tk = np.asarray(at, dtype=np.float64)
+                ref = np.interp(tk, t, ref) if ref.ndim == 1 else np.stack([np.interp(tk, t, ref[:, c]) for c in range(ref.shape[1])], 1)
+            errs[k] = self.array_error(x, ref, angle, 1 if ned else 0)
+            idx = 0
+            if err_stats_start != -1 and tk is not None:
+                hit = np.where(tk >= err_stats_start)[0]
+                if hit.shape[0] == 0:
+                    print('err_stats_start exceeds max data points.')
+                idx = int(hit[0]) if hit.shape[0] else 0
+            starts[k] = idx
+        arr_stats = lambda e: {'max': np.max(np.abs(e), 0), 'avg': np.average(e, 0), 'std': np.std(e, 0)}
+        if None in errs:                                        # a plain array: statistics over time, :752-754 / :790-793
+            e = errs[None]
+            return arr_stats(e[-1, :] if err_stats_start == -1 else e)
+        if err_stats_start == -1:                               # end points of every key, grouped by '<group>_<idx>'
+            groups = {}
+            for k, e in errs.items():
+                g = k.rpartition('_')[0] if isinstance(k, str) and '_' in k else 'data'
+                groups.setdefault(g, []).append(e[-1, :] if e.ndim > 1 else e[-1:])
+            per = {g: arr_stats(np.array(v)) for g, v in groups.items()}
+            return {s: {g: per[g][s] for g in per} for s in ('max', 'avg', 'std')}
+        stat = {'max': {}, 'avg': {}, 'std': {}}
+        for k, e in errs.items():
+            tmp = arr_stats(e[starts[k]:])
+            for s in stat:
+                stat[s][k] = tmp[s]
+        return stat
+
     # ------------------------------------------------------------------ files
     def save_data(self, data_dir, max_runs=None):
         """InsDataMgr.save_data: every available series to '<name>[-<key>].csv'.  For Monte-Carlo series only
-        the first ``max_runs`` runs are written (None = all) -- a million CSV files help nobody."""
+        runs below ``max_runs`` are written (None = all) -- a million CSV files help nobody.  The run id is read off
+        the key itself (an int, or the suffix after the last '_' of '<algo>_<run>')."""
+        def run_of(key):
+            if isinstance(key, (int, np.integer)):
+                return int(key)
+            tail = str(key).rpartition('_')[2]
+            return int(tail) if tail.isdigit() else 0
+
         saved = []
         for name in self.available:
             if name in self._do_not_save:
                 continue
             sd = self._all[name]
             keys = None
-            if isinstance(sd.data, sim_data.McSeries) and max_runs is not None:
-                keys = [k for i, k in enumerate(sd.data) if i < max_runs * max(1, len(self._mc.algo_names)) and
-                        self._mc.run_of_key(k) < max_runs]
+            if isinstance(sd.data, (sim_data.McSeries, sim_data.ChainSeries)) and max_runs is not None:
+                keys = [k for k in sd.data if run_of(k) < max_runs]
             sd.save_to_file(data_dir, keys)
             saved.append(name)
         return saved

@@ -31,7 +31,7 @@ import numpy as np
 
 from .ins_data_manager import InsDataMgr
 from .ins_algo_manager import InsAlgoMgr
-from .sim_data import McSeries
+from .sim_data import McSeries, ChainSeries
 from ..attitude import attitude
 
 NAME = 'gnss-ins-sim'
@@ -54,10 +54,14 @@ class _McResults(object):
         key = (name, bool(ned))
         if key not in self._stats:
             from ginsim import distributed
+            import ginsim
             job, kind = self.job_of(name), self.kinds[self.algo_names.index(name)]
-            if ned and not job.keep_traj:
+            if job is None:                         # this rank holds no runs (world > sim_count): an empty record
+                part = ginsim.StatsResult.zero()
+            elif ned and not job.keep_traj:
                 raise NotImplementedError("extra_opt='ned' needs the trajectories: run with keep_trajectories=True")
-            part = job.stats_from_traj(kind, pos_ned=True) if ned else job.stats(kind)
+            else:
+                part = job.stats_from_traj(kind, pos_ned=True) if ned else job.stats(kind)
             self._stats[key] = distributed.allreduce_stats(part, self._group, self._device)
         return self._stats[key]
 
@@ -66,6 +70,8 @@ class _McResults(object):
         sl = {'att_euler': slice(0, 3), 'pos': slice(3, 6), 'vel': slice(6, 9)}[data_name]
         stat = {'max': {}, 'avg': {}, 'std': {}}
         for name, job, kind in zip(self.algo_names, self.jobs, self.kinds):
+            if job is None:
+                continue
             if not job.keep_traj:
                 raise NotImplementedError('process-error statistics need the trajectories: run with keep_trajectories=True')
             key = ('proc', name, int(start_sample), bool(ned))
@@ -296,7 +302,11 @@ class Sim(object):
                     merged[j].update(out[j])
             for j, oname in enumerate(self.amgr.output):
                 if merged[j]:
-                    d.add_data(oname, merged[j])
+                    cur = d.get_data_all(oname).data if oname in d.available else None
+                    if isinstance(cur, McSeries):           # a fused plugin produced this output too: keep its device view
+                        d.add_data(oname, ChainSeries(cur, merged[j]))
+                    else:
+                        d.add_data(oname, merged[j])
 
     def _output_view(self, jobs_by_algo, fused, kinds, names, comp, first, count, quat=False):
         """Mapping '<algo>_<run>' -> (n,3) (or (n,4) quaternion) over the trajectory buffers of all fused plugins."""
@@ -391,7 +401,7 @@ class Sim(object):
         header = False
         self.err_stats = {}
         for data_name, kind in self.interested_error.items():
-            if data_name not in d.available or self.mc is None:
+            if data_name not in d.available:
                 continue
             st = d.get_error_stats(data_name, err_stats_start=err_stats_start, angle=(kind == 'angle'),
                                    use_output_units=True, extra_opt=extra_opt)

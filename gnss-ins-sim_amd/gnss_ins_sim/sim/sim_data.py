@@ -104,6 +104,32 @@ class McSeries(Mapping):
         return a[:, :, 0] if self._squeeze else a
 
 
+class ChainSeries(Mapping):
+    """A device view (McSeries) followed by host arrays under further keys: the outputs of fused and hosted plugins
+    that share an output name (e.g. 'pos' from FreeIntegration in the kernel and from a user's EKF on the host)."""
+
+    def __init__(self, first, extra):
+        self.first, self.extra = first, dict(extra)
+
+    def __len__(self):
+        return len(self.first) + len(self.extra)
+
+    def __iter__(self):
+        for k in self.first:
+            yield k
+        for k in self.extra:
+            yield k
+
+    def __contains__(self, key):
+        return key in self.extra or key in self.first
+
+    def __getitem__(self, key):
+        return self.extra[key] if key in self.extra else self.first[key]
+
+    def copy(self):
+        return self
+
+
 class Sim_data(object):
     def __init__(self, name, description, units=None, output_units=None, plottable=True, logx=False, logy=False,
                  grid='on', legend=None):

@@ -93,3 +93,21 @@ def test_sim_shards_runs_across_ranks(tmp_path):
     sim.results(err_stats_start=-1)
     np.testing.assert_allclose(a[:3], sim.err_stats['vel']['std'], rtol=1e-10)
     np.testing.assert_array_equal(a[3:6], sim.err_stats['att_euler']['max'])
+
+
+def test_more_ranks_than_runs(tmp_path):
+    """Sim.run(1) under 2 ranks -- rank 1 holds no runs, contributes an empty record to the all-reduce and
+    must neither crash nor leave rank 0 waiting in the collective."""
+    script = tmp_path / 'w1.py'
+    script.write_text((_SIM_WORKER % {'pkg': PKG, 'repo': REPO, 'port': _port()}).replace('sim.run(1001)', 'sim.run(1)').replace(
+        "keys = list(sim.dmgr.accel.data.keys())", "keys = list(sim.dmgr.accel.data.keys()) if 'accel' in sim.dmgr.available else []").replace(
+        "[keys[0], keys[-1], len(keys)]", "[len(keys)]"))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(tmp_path / ('s%d.npy' % r))], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    a, b = np.load(tmp_path / 's0.npy'), np.load(tmp_path / 's1.npy')
+    np.testing.assert_array_equal(a[:6], b[:6])
+    assert np.all(a[:3] == 0.0) and np.all(a[3:6] > 0.0)       # one run: std 0, max |e| > 0
+    assert (a[6], b[6]) == (1, 0)
