@@ -296,6 +296,17 @@ int ginsim_mc_run(ginsim_ctx* c, const ginsim_mc_params* p) {
         if (rc) return rc;
     }
     REQUIRE(p->precision == 0 || p->precision == 1, "mc_run: precision must be 0 (fp64) or 1 (fp32)");
+    if (p->out_proc[0] || p->out_proc[1]) {
+        REQUIRE(!p->given_sensors && p->precision == 0, "mc_run: online process statistics need generate mode and fp64");
+        REQUIRE((p->algo_mask == GINSIM_ALGO_FREE && p->out_proc[0] && !p->out_proc[1]) ||
+                (p->algo_mask == GINSIM_ALGO_ODO && p->out_proc[1] && !p->out_proc[0]),
+                "mc_run: online process statistics take ONE algorithm per launch (out_proc of that algorithm only)");
+        REQUIRE(p->ref_nav, "mc_run: online process statistics need ref_nav");
+        REQUIRE(p->proc_first >= 0 && p->proc_first < p->n, "mc_run: proc_first out of range");
+        REQUIRE(!p->proc_pos_ned || p->ref_frame == 0, "mc_run: NED position errors exist in ref_frame 0 only");
+    }
+    REQUIRE(!(p->out_end_ned[0] || p->out_end_ned[1]) || (p->ref_frame == 0 && p->precision == 0 && !p->given_sensors),
+            "mc_run: out_end_ned needs ref_frame 0, fp64, generate mode");
     HIP_TRY(hipSetDevice(c->device));
     if (p->precision == 1) {
         REQUIRE(!p->given_sensors && p->algo_mask != 0, "mc_run: the fp32 kernel supports generate mode with an algorithm only");

@@ -144,6 +144,23 @@ __device__ __forceinline__ void store3(double* __restrict__ base, int64_t plane,
     st(base + 2 * plane + off, v.z);
 }
 
+// the second end-point record of ref_frame 0 launches: same attitude / velocity errors, position error in NED metres
+__device__ __forceinline__ void store_end_ned(double* __restrict__ out, int64_t runs, int64_t r, const Nav& s) {
+    const params_ptr kp = kernarg_params();
+    const double ref_end[9] = {kp->ref_end[0], kp->ref_end[1], kp->ref_end[2], kp->ref_end[3], kp->ref_end[4],
+                               kp->ref_end[5], kp->ref_end[6], kp->ref_end[7], kp->ref_end[8]};
+    out[0 * runs + r] = angle_range_pi(s.att.yaw - ref_end[0]);
+    out[1 * runs + r] = angle_range_pi(s.att.pit - ref_end[1]);
+    out[2 * runs + r] = angle_range_pi(s.att.rol - ref_end[2]);
+    const Vec3 ep = lla_error_ned(s.pos, Vec3{ref_end[3], ref_end[4], ref_end[5]});
+    out[3 * runs + r] = ep.x;
+    out[4 * runs + r] = ep.y;
+    out[5 * runs + r] = ep.z;
+    out[6 * runs + r] = s.vel.x - ref_end[6];
+    out[7 * runs + r] = s.vel.y - ref_end[7];
+    out[8 * runs + r] = s.vel.z - ref_end[8];
+}
+
 __device__ __forceinline__ void store_end(double* __restrict__ out, int64_t runs, int64_t r, const Nav& s) {
     const params_ptr kp = kernarg_params();
     const double ref_end[9] = {kp->ref_end[0], kp->ref_end[1], kp->ref_end[2], kp->ref_end[3], kp->ref_end[4],
@@ -161,6 +178,62 @@ __device__ __forceinline__ void store_end(double* __restrict__ out, int64_t runs
     out[7 * runs + r] = s.vel.y - ref_end[7];
     out[8 * runs + r] = s.vel.z - ref_end[8];
 }
+
+// attitude.angle_range_pi with the division by 2 pi replaced by a multiplication, exactly as process_stats_kernel
+// (stats.hip) evaluates it: the two statistics paths agree to the bit
+__device__ __forceinline__ double angle_range_pi_mul(double x) {
+    double m = x - kTwoPi * floor(x * (1.0 / kTwoPi));
+    if (m >= kTwoPi) m -= kTwoPi;
+    if (m < 0.0) m += kTwoPi;
+    return m > kPi ? m - kTwoPi : m;
+}
+
+// Online process-error statistics of one run (InsDataMgr.__process_error_stats, ins_data_manager.py:761-795, on
+// array_error :519-553): Welford mean / M2 and max|e| of the nine error components over the samples >= proc_first.
+// The same recurrence, in the same order, as process_stats_kernel applies to kept trajectories -- here the samples
+// never leave the registers, which is what makes the statistics available when the trajectories are not kept.
+struct Proc {
+    double mean[9], m2[9], mx[9];
+    double cnt;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { mean[c] = 0.0; m2[c] = 0.0; mx[c] = 0.0; }
+        cnt = 0.0;
+    }
+    // t = truth att3, pos3, vel3 of this sample (wave-uniform); NED: position error in local NED metres (:542-552)
+    template <bool NED>
+    __device__ __forceinline__ void add(const Nav& s, const double (&t)[9]) {
+        double e[9];
+        e[0] = angle_range_pi_mul(s.att.yaw - t[0]);
+        e[1] = angle_range_pi_mul(s.att.pit - t[1]);
+        e[2] = angle_range_pi_mul(s.att.rol - t[2]);
+        if (NED) {
+            const Vec3 d = lla_error_ned(s.pos, Vec3{t[3], t[4], t[5]});
+            e[3] = d.x; e[4] = d.y; e[5] = d.z;
+        } else {
+            e[3] = s.pos.x - t[3]; e[4] = s.pos.y - t[4]; e[5] = s.pos.z - t[5];
+        }
+        e[6] = s.vel.x - t[6]; e[7] = s.vel.y - t[7]; e[8] = s.vel.z - t[8];
+        cnt += 1.0;
+        const double icnt = rcp_nr(cnt);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const double d = e[c] - mean[c];
+            mean[c] = __builtin_fma(d, icnt, mean[c]);
+            m2[c] = __builtin_fma(d, e[c] - mean[c], m2[c]);
+            const double a = fabs(e[c]);
+            mx[c] = a > mx[c] ? a : mx[c];
+        }
+    }
+    __device__ __forceinline__ void store(double* __restrict__ out, int64_t runs, int64_t r) const {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            out[(0 * 9 + c) * runs + r] = mx[c];
+            out[(1 * 9 + c) * runs + r] = mean[c];
+            out[(2 * 9 + c) * runs + r] = cnt > 0.0 ? sqrt(m2[c] / cnt) : 0.0;
+        }
+    }
+};
 
 // Truth samples are the same for every lane.  Reading them through the constant address space tells the
 // compiler the data are invariant, so a wave-uniform index becomes an s_load (scalar cache, lgkmcnt) instead
@@ -205,8 +278,11 @@ __device__ __forceinline__ Vec3 sense3(const Vec3& truth, model_ptr m, Vec3& dri
 // Two workgroups per CU is what the launch geometry below counts on: tell the register allocator (variants had grown
 // to 256 VGPRs + a few AGPRs = one wavefront per SIMD, 30 % slower at 262 144 runs, with no functional symptom;
 // tests/test_host_cpu.py now reads the compiler's resource report).
-template <int RF, int ALGOS, bool GIVEN, bool WD>
+// PS: 0 = no process statistics; 1 = online process-error statistics of the (single) algorithm; 2 = the same with the
+// position error in NED metres (ref_frame 0).
+template <int RF, int ALGOS, bool GIVEN, bool WD, int PS = 0>
 __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
+    static_assert(PS == 0 || (!GIVEN && (ALGOS == GINSIM_ALGO_FREE || ALGOS == GINSIM_ALGO_ODO)), "process statistics: one algorithm, generate mode");
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t* trace = nullptr;
     if (a.wave_trace && (threadIdx.x & 63) == 0) {
@@ -241,10 +317,20 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
     Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
     MathConsts mk;
     // constants pinned in VGPRs except where that variant would spill to scratch (measured per variant)
-    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO))>();
+    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO)) && PS == 0>();
 
     if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
     if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
+    Proc ps;
+    const uniform_ptr nav_truth = as_uniform(a.ref_nav);
+    if (PS) {
+        ps.clear();
+        if (a.proc_first <= 0) {                    // sample 0 is the initial state (free_integration.py:96-102)
+            const double t[9] = {nav_truth[0], nav_truth[1], nav_truth[2], nav_truth[3], nav_truth[4], nav_truth[5],
+                                 nav_truth[6], nav_truth[7], nav_truth[8]};
+            ps.template add<PS == 2>(FREE ? fi : od, t);
+        }
+    }
 
     for (int64_t j = 0; j < n; ++j) {
         const int64_t off = j * runs + r;
@@ -300,9 +386,21 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
             nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot, resync, mk);
             if (a.out_traj[1]) store9(a.out_traj[1], plane, off + runs, od);
         }
+        if (PS) {
+            if (j + 1 >= a.proc_first) {            // wave-uniform
+                const uniform_ptr q = nav_truth + 9 * (j + 1);
+                const double t[9] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
+                ps.template add<PS == 2>(FREE ? fi : od, t);
+            }
+        }
     }
     if (FREE && a.out_end[0]) store_end(a.out_end[0], runs, r, fi);
     if (ODO && a.out_end[1]) store_end(a.out_end[1], runs, r, od);
+    if (RF == 0) {
+        if (FREE && a.out_end_ned[0]) store_end_ned(a.out_end_ned[0], runs, r, fi);
+        if (ODO && a.out_end_ned[1]) store_end_ned(a.out_end_ned[1], runs, r, od);
+    }
+    if (PS) ps.store(a.out_proc[FREE ? 0 : 1], runs, r);
     if (trace) trace[3] = __builtin_amdgcn_s_memtime();
 }
 
@@ -441,6 +539,10 @@ __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a)
     if (active) {
         if (FREE && a.out_end[0]) store_end(a.out_end[0], runs, r, fi);
         if (ODO && a.out_end[1]) store_end(a.out_end[1], runs, r, od);
+        if (RF == 0) {
+            if (FREE && a.out_end_ned[0]) store_end_ned(a.out_end_ned[0], runs, r, fi);
+            if (ODO && a.out_end_ned[1]) store_end_ned(a.out_end_ned[1], runs, r, od);
+        }
     }
 }
 
@@ -462,6 +564,7 @@ static int split_policy() {        // GINSIM_SPLIT=0 / 1 forces the plain / wave
 // 1 = wave-specialised kernel (mc_kernel_split), 0 = one wavefront does everything for its 64 runs (mc_kernel)
 int mc_variant(const ginsim_mc_params& p) {
     if (!(p.algo_mask & GINSIM_ALGO_FREE) || p.given_sensors || p.block_threads != 0 || p.wave_trace || p.n < 2) return 0;
+    if (p.out_proc[0] || p.out_proc[1]) return 0;      // online process statistics live in the plain kernel
     const int pol = split_policy();
     if (pol >= 0) return pol != 0;
     return (p.runs + kWave - 1) / kWave <= 1024 ? 1 : 0;
@@ -496,6 +599,13 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream) {
     // strictly more than 1/(k+1) of the LDS so that k+1 workgroups do not fit: 81 KB (k = 1), 54 KB (k = 2)
     const size_t lds = p.block_threads > 0 ? 0 : kLdsPerCu / (per_cu + 1) + 1024;
     const dim3 grid((unsigned)((p.runs + tb - 1) / tb)), block(tb);
+    if constexpr (WD && (ALGOS == GINSIM_ALGO_FREE || ALGOS == GINSIM_ALGO_ODO)) {
+        if (p.out_proc[ALGOS == GINSIM_ALGO_FREE ? 0 : 1]) {       // the general sensor model serves all PS launches
+            if (RF == 0 && p.proc_pos_ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1>), grid, block, lds, stream, p);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, WD>), grid, block, lds, stream, p);
     return hipGetLastError();
 }
@@ -515,7 +625,7 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
     }
     // the simple-model variant of the two-algorithm ref_frame 0 kernels is the one instantiation that spills: use the general one
     constexpr bool kSimpleFits = !(RF == 0 && ALGOS == (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO));
-    if (any_white_drift(p) || !kSimpleFits) return launch3<RF, ALGOS, true>(p, stream);
+    if (any_white_drift(p) || !kSimpleFits || p.out_proc[0] || p.out_proc[1]) return launch3<RF, ALGOS, true>(p, stream);
     if constexpr (kSimpleFits) return launch3<RF, ALGOS, false>(p, stream);
     return hipErrorInvalidValue;
 }

@@ -40,7 +40,9 @@ class McParams(C.Structure):
                 ('out_accel', C.c_void_p), ('out_gyro', C.c_void_p), ('out_odo', C.c_void_p),
                 ('out_traj', C.c_void_p * 2), ('out_end', C.c_void_p * 2),
                 ('wave_trace', C.c_void_p), ('block_threads', C.c_int32), ('end_pos_ned', C.c_int32),
-                ('precision', C.c_int32), ('reserved', C.c_int32)]
+                ('precision', C.c_int32), ('proc_pos_ned', C.c_int32),
+                ('ref_nav', C.c_void_p), ('proc_first', C.c_int64), ('out_proc', C.c_void_p * 2),
+                ('out_end_ned', C.c_void_p * 2)]
 
 
 class PathgenParams(C.Structure):

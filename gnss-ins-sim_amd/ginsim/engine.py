@@ -253,6 +253,12 @@ class MonteCarloJob(object):
     truth: dict with 'ref_accel' (n,3), 'ref_gyro' (n,3), 'ref_att'/'ref_pos'/'ref_vel' (n,3) and, for
     the odometer algorithm, 'ref_odo' (n,).  algos: subset of ('free', 'odo').
 
+    proc_first: None, or the first sample of the process-error window: max|e| / mean / std of the error over the samples
+    >= proc_first are accumulated online inside the kernel (InsDataMgr.__process_error_stats, ins_data_manager.py:761-795)
+    -- the statistics Sim.results() prints by default, without keeping a single trajectory.  One algorithm per job.
+    proc_ned / end_ned (ref_frame 0): position errors of those statistics / of a second end-point record in local NED
+    metres (extra_opt='ned', ins_data_manager.py:542-552).
+
     given: None (sensors are generated), or a dict of DeviceBuffers {'gyro', 'accel'[, 'odo']} holding sensor series
     that are already on the device in the engine's [component][sample][run] fp64 layout -- e.g. the 'gyro'/'accel'
     buffers another job materialised -- which are then integrated as they are (the plugin's run(set_of_input)
@@ -261,7 +267,8 @@ class MonteCarloJob(object):
 
     def __init__(self, ctx, fs, ref_frame, truth, accel_err, gyro_err, ini, runs, algos=('free',),
                  odo_err=None, earth_rot=True, seed=0, run_offset=0, ini_first=0,
-                 keep_sensors=False, keep_traj=False, end_pos_ned=False, precision='f64', given=None):
+                 keep_sensors=False, keep_traj=False, end_pos_ned=False, precision='f64', given=None,
+                 proc_first=None, proc_ned=False, end_ned=False):
         self.ctx = ctx
         self.algos = tuple(algos)
         for a in self.algos:
@@ -336,10 +343,28 @@ class MonteCarloJob(object):
             if self.want_odo:
                 self._bufs['odo'] = ctx.malloc(plane)
                 p.out_odo = self._bufs['odo'].ptr
+        self.proc_first, self.proc_ned, self.end_ned = proc_first, bool(proc_ned), bool(end_ned)
+        if proc_first is not None:
+            if len(self.algos) != 1 or given is not None or precision != 'f64':
+                raise ValueError('online process statistics: one algorithm per job, generated sensors, fp64')
+            if not 0 <= int(proc_first) < self.n:
+                raise ValueError('proc_first must be a sample index of the run')
+            if proc_ned and int(ref_frame) != 0:
+                raise ValueError('NED position errors exist in ref_frame 0 only')
+            self._bufs['ref_nav'] = ctx.upload(self._ref_nav)
+            p.ref_nav, p.proc_first, p.proc_pos_ned = self._bufs['ref_nav'].ptr, int(proc_first), int(bool(proc_ned))
+        if end_ned and (int(ref_frame) != 0 or precision != 'f64' or given is not None):
+            raise ValueError('end_ned: ref_frame 0, fp64, generated sensors')
         for a in self.algos:
             s = ALGO_SLOT[a]
             self._bufs['end_' + a] = ctx.malloc(9 * self.runs * 8)
             p.out_end[s] = self._bufs['end_' + a].ptr
+            if end_ned:
+                self._bufs['endned_' + a] = ctx.malloc(9 * self.runs * 8)
+                p.out_end_ned[s] = self._bufs['endned_' + a].ptr
+            if proc_first is not None:
+                self._bufs['proc_' + a] = ctx.malloc(27 * self.runs * 8)
+                p.out_proc[s] = self._bufs['proc_' + a].ptr
             if self.keep_traj:
                 self._bufs['traj_' + a] = ctx.malloc(9 * plane)
                 p.out_traj[s] = self._bufs['traj_' + a].ptr
@@ -408,10 +433,19 @@ class MonteCarloJob(object):
         self.ctx.sync()
         return self
 
-    def stats(self, algo):
+    def stats(self, algo, ned=False):
+        """End-point statistics of the last launch; ned=True: position error in NED metres (needs end_ned=True)."""
+        if ned and not self.end_ned:
+            raise ValueError('the NED end-point record was not requested (end_ned=True)')
         s = _lib.Stats()
-        check(lib.ginsim_end_stats(self.ctx.handle, self._bufs['end_' + algo].ptr, self.runs, C.byref(s)))
+        check(lib.ginsim_end_stats(self.ctx.handle, self._bufs[('endned_' if ned else 'end_') + algo].ptr, self.runs, C.byref(s)))
         return StatsResult(s)
+
+    def process_stats_online(self, algo):
+        """(runs, 3, 9) = max|e|, mean, std of the error over samples >= proc_first, as the kernel accumulated them."""
+        if self.proc_first is None:
+            raise ValueError('online process statistics were not requested (proc_first=...)')
+        return self.ctx.download(self._bufs['proc_' + algo], (3, 9, self.runs)).transpose(2, 0, 1).copy()
 
     def stats_begin(self, algo, slot=0):
         """Enqueue the end-point reduction of the last launch() into pinned slot 0..7 without waiting for it."""
@@ -446,9 +480,9 @@ class MonteCarloJob(object):
                                              self.n, self.runs, int(bool(pos_ned)), C.byref(s)))
         return StatsResult(s)
 
-    def end_errors(self, algo):
-        """(runs, 9) end-point errors [att3 wrapped, pos3, vel3]."""
-        return self.ctx.download(self._bufs['end_' + algo], (9, self.runs)).T.copy()
+    def end_errors(self, algo, ned=False):
+        """(runs, 9) end-point errors [att3 wrapped, pos3, vel3]; ned=True: the NED record (end_ned=True)."""
+        return self.ctx.download(self._bufs[('endned_' if ned else 'end_') + algo], (9, self.runs)).T.copy()
 
     def _gather(self, ptr, ncomp, run_ids):
         ids = np.ascontiguousarray(np.asarray(run_ids, dtype=np.int64).reshape(-1))

@@ -192,7 +192,9 @@ class InsDataMgr(object):
             stat = {s: next(iter(stat[s].values())) for s in ('max', 'avg', 'std')}
         if use_output_units:
             for s in stat:
-                if isinstance(stat[s], dict):
+                if isinstance(stat[s], sim_data.RunStats):
+                    stat[s] = stat[s].scaled(sim_data.unit_conversion_scale(units, out_units))
+                elif isinstance(stat[s], dict):
                     stat[s] = {k: sim_data.convert_unit(v, units, out_units) for k, v in stat[s].items()}
                 else:
                     stat[s] = sim_data.convert_unit(stat[s], units, out_units)

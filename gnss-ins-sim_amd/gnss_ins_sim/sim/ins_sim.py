@@ -18,6 +18,11 @@ Keyword-only extras (defaults keep the reference behaviour):
     keep_trajectories  'auto' | True | False: materialise sensors + outputs in HBM ('auto': when they fit
                        ``max_device_bytes``), else keep only per-run end-point errors (stats-only).
     max_device_bytes   budget for materialised series on one GPU (default 64 GiB of the 288 GB).
+    keep_runs          stats-only mode: still materialise sensors (incl. GPS / magnetometer), outputs and CSV files of the
+                       first K runs of this rank (the counter RNG reproduces them exactly in a second, small launch).
+    stats_start        stats-only mode: the ``err_stats_start`` that ``results()`` will be asked for (default 0 s, the
+                       reference's default; -1 = end-point only).  The process-error statistics of that window are
+                       accumulated inside the kernel; asking ``results()`` for another window integrates once more.
     device             GPU index (default LOCAL_RANK or 0).
     geo_mag_n          geomagnetic field [uT] in the N frame at the initial position, needed for a 9-axis IMU.  The
                        reference evaluates the WMM model once per run for this vector (pathgen.py:164-168,
@@ -40,12 +45,17 @@ high_mobility = np.array([1.0, 0.5, 2.0])       # m/s/s, rad/s/s, rad/s  (ins_si
 
 
 class _McResults(object):
-    """Device results of one Sim.run: per-algorithm jobs + cross-rank merge of the statistics."""
+    """Device results of one Sim.run: per-algorithm jobs + cross-rank merge of the statistics.
 
-    def __init__(self, jobs, names, kinds, first_run, runs_local, total_runs, group, device):
-        self.jobs, self.algo_names, self.kinds = jobs, names, kinds
+    jobs[i] integrates ALL runs of this rank for fused algorithm i (statistics); kept[i] is the job whose series are
+    materialised (the same object when everything is kept, a job over the first ``keep_runs`` runs otherwise, or None).
+    """
+
+    def __init__(self, jobs, kept, names, kinds, first_run, runs_local, total_runs, group, device, make_ps_job=None):
+        self.jobs, self.kept, self.algo_names, self.kinds = jobs, kept, names, kinds
         self.first_run, self.runs_local, self.total_runs = first_run, runs_local, total_runs
         self._group, self._device, self._stats = group, device, {}
+        self._make_ps_job = make_ps_job
 
     def job_of(self, name):
         return self.jobs[self.algo_names.index(name)]
@@ -53,35 +63,54 @@ class _McResults(object):
     def end_stats(self, name, ned=False):
         key = (name, bool(ned))
         if key not in self._stats:
-            from ginsim import distributed
             import ginsim
+            from ginsim import distributed
             job, kind = self.job_of(name), self.kinds[self.algo_names.index(name)]
             if job is None:                         # this rank holds no runs (world > sim_count): an empty record
                 part = ginsim.StatsResult.zero()
-            elif ned and not job.keep_traj:
-                raise NotImplementedError("extra_opt='ned' needs the trajectories: run with keep_trajectories=True")
+            elif not ned:
+                part = job.stats(kind)
+            elif job.end_ned:                       # second end-point record written by the kernel (no trajectories needed)
+                part = job.stats(kind, ned=True)
+            elif job.keep_traj and job.precision == 'f64':
+                part = job.stats_from_traj(kind, pos_ned=True)
             else:
-                part = job.stats_from_traj(kind, pos_ned=True) if ned else job.stats(kind)
+                raise NotImplementedError("extra_opt='ned' is available in fp64 only")
             self._stats[key] = distributed.allreduce_stats(part, self._group, self._device)
+        return self._stats[key]
+
+    def _process_array(self, idx, start_sample, ned):
+        """(runs, 3, 9) process statistics of fused algorithm idx over this rank's runs."""
+        job, kind = self.jobs[idx], self.kinds[idx]
+        key = ('proc', idx, int(start_sample), bool(ned))
+        if key not in self._stats:
+            if job.precision != 'f64':
+                raise NotImplementedError("process-error statistics (err_stats_start >= 0) are computed in fp64: use "
+                                          "results(err_stats_start=-1) with precision='f32'")
+            if job.keep_traj:
+                self._stats[key] = job.process_stats(kind, start_sample, pos_ned=ned)
+            elif job.proc_first == int(start_sample) and job.proc_ned == bool(ned):
+                self._stats[key] = job.process_stats_online(kind)
+            else:       # another window than the one run() accumulated: integrate again with that window (same counter
+                        # RNG, same runs, nothing kept) -- costs one more launch
+                ps = self._make_ps_job(idx, int(start_sample), bool(ned))
+                ps.run()
+                self._stats[key] = ps.process_stats_online(kind)
+                ps.release()
         return self._stats[key]
 
     def process_stats(self, data_name, start_sample, ned=False):
         """{'max'|'avg'|'std': {'<algo>_<run>': (3,)}} for data_name in att_euler/pos/vel (ins_data_manager.py:761-795)."""
+        from .sim_data import RunStats
         sl = {'att_euler': slice(0, 3), 'pos': slice(3, 6), 'vel': slice(6, 9)}[data_name]
-        stat = {'max': {}, 'avg': {}, 'std': {}}
-        for name, job, kind in zip(self.algo_names, self.jobs, self.kinds):
-            if job is None:
+        parts = {'max': [], 'avg': [], 'std': []}
+        for idx, name in enumerate(self.algo_names):
+            if self.jobs[idx] is None:
                 continue
-            if not job.keep_traj:
-                raise NotImplementedError('process-error statistics need the trajectories: run with keep_trajectories=True')
-            key = ('proc', name, int(start_sample), bool(ned))
-            if key not in self._stats:
-                self._stats[key] = job.process_stats(kind, start_sample, pos_ned=ned)
-            arr = self._stats[key]
-            for i in range(self.runs_local):
-                k = name + '_' + str(self.first_run + i)
-                stat['max'][k], stat['avg'][k], stat['std'][k] = arr[i, 0, sl].copy(), arr[i, 1, sl].copy(), arr[i, 2, sl].copy()
-        return stat
+            arr = self._process_array(idx, start_sample, ned)
+            for row, s in enumerate(('max', 'avg', 'std')):
+                parts[s].append((name, self.first_run, arr[:, row, sl]))
+        return {s: RunStats(parts[s]) for s in parts}
 
     def run_of_key(self, key):
         return int(str(key).rsplit('_', 1)[-1]) if isinstance(key, str) else int(key)
@@ -89,7 +118,8 @@ class _McResults(object):
 
 class Sim(object):
     def __init__(self, fs, motion_def, ref_frame=0, imu=None, mode=None, env=None, algorithm=None, *,
-                 seed=None, keep_trajectories='auto', max_device_bytes=64 * 2 ** 30, device=None, geo_mag_n=None, precision='f64'):
+                 seed=None, keep_trajectories='auto', max_device_bytes=64 * 2 ** 30, device=None, geo_mag_n=None, precision='f64',
+                 keep_runs=0, stats_start=0):
         self.name, self.version = NAME, VERSION
         self.fs, self.imu, self.mode, self.env = fs, imu, mode, env
         self.ref_frame = ref_frame if ref_frame in (0, 1) else 0
@@ -105,6 +135,7 @@ class Sim(object):
         self.seed, self.keep_trajectories, self.max_device_bytes, self.device = seed, keep_trajectories, max_device_bytes, device
         self.geo_mag_n = geo_mag_n
         self.precision = precision      # 'f32': single-precision kernel (tolerances: tests/test_gpu_fp32.py)
+        self.keep_runs, self.stats_start = max(int(keep_runs), 0), stats_start
         self.mc = None
         if env is not None:
             raise NotImplementedError('vibration models (env) are outside the accelerated hot path; every BASELINE '
@@ -221,23 +252,57 @@ class Sim(object):
                     break
             else:
                 groups.append({'ini': a.ini, 'earth_rot': a.earth_rot, 'kinds': [kinds[i]], 'idx': [i], 'first': a.run_times})
-        jobs_by_algo = {}
+        # Which runs have their series materialised: all of this rank's runs (keep), or the first keep_runs of them next to
+        # a stats-only launch over all runs (the counter RNG makes the small launch reproduce exactly those runs).
+        kcount = count if keep else min(self.keep_runs, count)
+        t_axis = nav[:, 0] / fs_imu
+
+        def sample_of(start_s):
+            hit = np.where(t_axis >= max(float(start_s), 0.0))[0]
+            return int(hit[0]) if hit.shape[0] else 0
+
+        def make_job(g, kinds_, runs_, keep_sens, keep_traj, **kw):
+            return ginsim.MonteCarloJob(ctx, fs_imu, self.ref_frame, truth, self.imu.accel_err, self.imu.gyro_err,
+                                        g['ini'], runs=runs_, algos=tuple(kinds_), odo_err=self.imu.odo_err,
+                                        earth_rot=g['earth_rot'], seed=seed, run_offset=first,
+                                        ini_first=g['first'] + first, keep_sensors=keep_sens, keep_traj=keep_traj,
+                                        precision=self.precision, **kw)
+
+        f64 = self.precision == 'f64'
+        online = (not keep) and f64 and self.stats_start is not None and self.stats_start != -1
+        end_ned = (not keep) and f64 and self.ref_frame == 0
+        stats_jobs, kept_jobs, group_of = {}, {}, {}
         sensor_job = None
         if count > 0:
-            for gi, g in enumerate(groups):
-                job = ginsim.MonteCarloJob(ctx, fs_imu, self.ref_frame, truth, self.imu.accel_err, self.imu.gyro_err,
-                                           g['ini'], runs=count, algos=tuple(g['kinds']), odo_err=self.imu.odo_err,
-                                           earth_rot=g['earth_rot'], seed=seed, run_offset=first,
-                                           ini_first=g['first'] + first, keep_sensors=bool(keep) and sensor_job is None,
-                                           keep_traj=bool(keep), precision=self.precision)
-                job.launch()
-                if sensor_job is None and keep:
-                    sensor_job = job
+            for g in groups:
                 for i in g['idx']:
-                    jobs_by_algo[i] = job
-            if not groups and keep:            # Sim without algorithm: sensor generation only (demo_no_algo.py)
+                    group_of[i] = g
+                if keep:
+                    job = make_job(g, g['kinds'], count, sensor_job is None, True)
+                    job.launch()
+                    sensor_job = sensor_job or job
+                    for i in g['idx']:
+                        stats_jobs[i] = kept_jobs[i] = job
+                    continue
+                if online:      # process-error statistics accumulated inside the kernel: one algorithm per launch
+                    for i, kind in zip(g['idx'], g['kinds']):
+                        stats_jobs[i] = make_job(g, [kind], count, False, False, proc_first=sample_of(self.stats_start),
+                                                 end_ned=end_ned)
+                        stats_jobs[i].launch()
+                else:
+                    job = make_job(g, g['kinds'], count, False, False, end_ned=end_ned)
+                    job.launch()
+                    for i in g['idx']:
+                        stats_jobs[i] = job
+                if kcount > 0:
+                    kj = make_job(g, g['kinds'], kcount, sensor_job is None, True)
+                    kj.launch()
+                    sensor_job = sensor_job or kj
+                    for i in g['idx']:
+                        kept_jobs[i] = kj
+            if not groups and kcount > 0:      # Sim without algorithm: sensor generation only (demo_no_algo.py)
                 sensor_job = ginsim.MonteCarloJob(ctx, fs_imu, self.ref_frame, truth, self.imu.accel_err,
-                                                  self.imu.gyro_err, None, runs=count, algos=(), odo_err=self.imu.odo_err,
+                                                  self.imu.gyro_err, None, runs=kcount, algos=(), odo_err=self.imu.odo_err,
                                                   seed=seed, run_offset=first, keep_sensors=True)
                 sensor_job.launch()
             ctx.sync()
@@ -245,26 +310,24 @@ class Sim(object):
             algos[i].run_times += self.sim_count
 
         # expose device series through the data manager
-        runs = range(first, first + count)
+        runs = range(first, first + kcount)
+        in_kept = lambda k: int(k) - first if isinstance(k, (int, np.integer)) and first <= int(k) < first + kcount else None
         if sensor_job is not None:
             def sens(name, squeeze=False, job=sensor_job):
-                return McSeries(count, lambda pos, j=job, nm=name: j.sensors(nm, pos)[..., None] if nm == 'odo'
-                                else j.sensors(nm, pos), key_of=lambda i: first + i,
-                                pos_of=lambda k: int(k) - first if isinstance(k, (int, np.integer)) and
-                                first <= int(k) < first + count else None, squeeze=squeeze)
+                return McSeries(kcount, lambda pos, j=job, nm=name: j.sensors(nm, pos)[..., None] if nm == 'odo'
+                                else j.sensors(nm, pos), key_of=lambda i: first + i, pos_of=in_kept, squeeze=squeeze)
             d.add_data(d.accel.name, sens('accel'))
             d.add_data(d.gyro.name, sens('gyro'))
             if self.imu.odo:
                 d.add_data(d.odo.name, sens('odo', squeeze=True))
-        if keep and count > 0 and (self.imu.gps or self.imu.magnetometer):      # ins_sim.py:497-503
-            aux = ginsim.AuxSensorJob(ctx, count, seed=seed, run_offset=first,
+        if kcount > 0 and (self.imu.gps or self.imu.magnetometer):      # ins_sim.py:497-503
+            aux = ginsim.AuxSensorJob(ctx, kcount, seed=seed, run_offset=first,
                                       ref_gps=d.ref_gps.data if self.imu.gps else None, gps_err=self.imu.gps_err,
                                       ref_frame=self.ref_frame,
                                       ref_mag=d.ref_mag.data if self.imu.magnetometer else None, mag_err=self.imu.mag_err).run()
             self._aux = aux
-            view = lambda nm: McSeries(count, lambda pos, a=aux, nm=nm: a.series(nm, pos), key_of=lambda i: first + i,
-                                       pos_of=lambda k: int(k) - first if isinstance(k, (int, np.integer)) and
-                                       first <= int(k) < first + count else None)
+            view = lambda nm: McSeries(kcount, lambda pos, a=aux, nm=nm: a.series(nm, pos), key_of=lambda i: first + i,
+                                       pos_of=in_kept)
             if self.imu.gps:
                 d.add_data(d.gps.name, view('gps'))
             if self.imu.magnetometer:
@@ -272,16 +335,20 @@ class Sim(object):
         if self.amgr.algo is not None:
             d.set_algo_output(self.amgr.output)
         names = [self.amgr.get_algo_name(i) for i in fused]
-        if fused and keep and count > 0:
+        if fused and kcount > 0:
             for out_name, comp in (('att_euler', 0), ('pos', 1), ('vel', 2)):
-                d.add_data(out_name, self._output_view(jobs_by_algo, fused, kinds, names, comp, first, count))
-            d.add_data('att_quat', self._output_view(jobs_by_algo, fused, kinds, names, 0, first, count, quat=True))
+                d.add_data(out_name, self._output_view(kept_jobs, fused, kinds, names, comp, first, kcount))
+            d.add_data('att_quat', self._output_view(kept_jobs, fused, kinds, names, 0, first, kcount, quat=True))
         elif fused:
             for out_name in ('att_euler', 'pos', 'vel'):       # stats-only: names are known, series are not kept
                 d.add_data(out_name, {})
         if fused:
-            self.mc = _McResults([jobs_by_algo.get(i) for i in fused], names, [kinds[i] for i in fused], first, count,
-                                 self.sim_count, group, xdev)
+            def make_ps_job(idx, start_sample, ned):
+                i = fused[idx]
+                return make_job(group_of[i], [kinds[i]], count, False, False, proc_first=start_sample,
+                                proc_ned=ned, end_ned=False)
+            self.mc = _McResults([stats_jobs.get(i) for i in fused], [kept_jobs.get(i) for i in fused], names,
+                                 [kinds[i] for i in fused], first, count, self.sim_count, group, xdev, make_ps_job)
             d.set_mc_results(self.mc)
         # plugins outside the fused kernel: the reference's per-run loop over host copies (user code)
         if hosted:
@@ -370,8 +437,10 @@ class Sim(object):
                 d.add_data(oname, out[j])
 
     # ------------------------------------------------------------------------------------ results
-    def results(self, data_dir=None, err_stats_start=0, gen_kml=False, extra_opt='', *, max_saved_runs=16):
-        """Sim.results (ins_sim.py:194-251).  CSV files are written for at most ``max_saved_runs`` Monte-Carlo runs."""
+    def results(self, data_dir=None, err_stats_start=0, gen_kml=False, extra_opt='', *, max_saved_runs=16, max_summary_runs=32):
+        """Sim.results (ins_sim.py:194-251).  CSV files are written for at most ``max_saved_runs`` Monte-Carlo runs and the
+        printed summary lists the per-run process statistics of at most ``max_summary_runs`` runs (``sim.err_stats``
+        holds all of them)."""
         if not self.sim_complete:
             print("Call Sim.run() to run the simulaltion first.")
             return None
@@ -381,11 +450,15 @@ class Sim(object):
             data_saved = self.dmgr.save_data(data_dir, max_runs=max_saved_runs)
         if gen_kml is True:
             self.dmgr.save_kml_files(data_dir)
-        self._summary(data_dir, data_saved, err_stats_start, extra_opt)
+        if self.mc is not None and self.precision == 'f32' and err_stats_start != -1:
+            print("precision='f32': process-error statistics are an fp64 product; reporting end-point statistics "
+                  "(err_stats_start=-1) instead.")
+            err_stats_start = -1
+        self._summary(data_dir, data_saved, err_stats_start, extra_opt, max_summary_runs)
         self.sim_results = True
         return self.dmgr.available
 
-    def _summary(self, data_dir, data_saved, err_stats_start=0, extra_opt=''):
+    def _summary(self, data_dir, data_saved, err_stats_start=0, extra_opt='', max_summary_runs=32):
         """Same text as Sim.__summary (ins_sim.py:339-413)."""
         d = self.dmgr
         line = '\n------------------------------------------------------------\n'
@@ -413,12 +486,15 @@ class Sim(object):
                 s += line + 'The following are error statistics.'
             s += '\n-----------statistics for ' + d.get_data_all(data_name).description + \
                  ' (in units of ' + st['units'] + ')\n'
-            if isinstance(st['max'], dict):
-                for k in sorted(st['max'].keys()):
+            if hasattr(st['max'], 'keys'):
+                keys = sorted(st['max'].keys())
+                for k in keys[:max_summary_runs]:
                     s += '\tSimulation run ' + str(k) + ':\n'
                     s += '\t\t--Max error: ' + str(st['max'][k]) + '\n'
                     s += '\t\t--Avg error: ' + str(st['avg'][k]) + '\n'
                     s += '\t\t--Std of error: ' + str(st['std'][k]) + '\n'
+                if len(keys) > max_summary_runs:
+                    s += '\t... %d more runs: sim.err_stats[%r]\n' % (len(keys) - max_summary_runs, data_name)
             else:
                 s += '\t--Max error: ' + str(st['max']) + '\n'
                 s += '\t--Avg error: ' + str(st['avg']) + '\n'

@@ -104,6 +104,39 @@ class McSeries(Mapping):
         return a[:, :, 0] if self._squeeze else a
 
 
+class RunStats(Mapping):
+    """{'<algo>_<run>': (k,) statistics} over per-algorithm (runs, k) arrays: the per-run dicts of
+    InsDataMgr.__process_error_stats (ins_data_manager.py:761-795) without building 10^5 dict entries up front."""
+
+    def __init__(self, parts):
+        self.parts = [(name, int(first), np.asarray(a)) for name, first, a in parts]      # (algo name, first run id, (runs, k))
+
+    def __len__(self):
+        return sum(a.shape[0] for _, _, a in self.parts)
+
+    def __iter__(self):
+        for name, first, a in self.parts:
+            for i in range(a.shape[0]):
+                yield name + '_' + str(first + i)
+
+    def __getitem__(self, key):
+        nm, _, r = str(key).rpartition('_')
+        if r.isdigit():
+            for name, first, a in self.parts:
+                if name == nm and first <= int(r) < first + a.shape[0]:
+                    return a[int(r) - first]
+        raise KeyError(key)
+
+    def scaled(self, scale):
+        return RunStats([(name, first, a * scale[:a.shape[1]]) for name, first, a in self.parts])
+
+    def update(self, other):
+        """append host-computed entries ({key: array}) as single-run parts"""
+        for k, v in other.items():
+            nm, _, r = str(k).rpartition('_')
+            self.parts.append((nm, int(r) if r.isdigit() else 0, np.asarray(v)[None]))
+
+
 class ChainSeries(Mapping):
     """A device view (McSeries) followed by host arrays under further keys: the outputs of fused and hosted plugins
     that share an output name (e.g. 'pos' from FreeIntegration in the kernel and from a user's EKF on the host)."""

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define GINSIM_ABI_VERSION 1
+#define GINSIM_ABI_VERSION 2
 
 /* status codes */
 #define GINSIM_OK          0
@@ -127,7 +127,16 @@ typedef struct {
                                * buffers of the same [component][sample][run] shape; the position planes of out_traj hold
                                * the displacement from the run's initial position (ECEF-based for ref_frame 1, LLA for 0);
                                * out_end stays double.  Generate mode only. */
-    int32_t   reserved;
+    int32_t   proc_pos_ned;   /* process statistics of the position error in local NED metres (ref_frame 0 only) */
+    /* ---- statistics WITHOUT trajectories (ABI 2): what Sim.results() needs when the series are not materialised ---- */
+    const double* ref_nav;    /* [n][9] truth att3, pos3, vel3 of every sample; needed when out_proc is set */
+    int64_t   proc_first;     /* first sample of the process-error window (err_stats_start, ins_data_manager.py:771-781) */
+    double*   out_proc[2];    /* per algorithm bit: [3][9][runs] = max|e|, mean, std(ddof=0) of the error over samples
+                               * >= proc_first, accumulated online in the fused kernel (InsDataMgr.__process_error_stats,
+                               * ins_data_manager.py:761-795, on array_error :519-553), or NULL.  ONE algorithm bit per launch,
+                               * generate mode, fp64. */
+    double*   out_end_ned[2]; /* per algorithm bit: [9][runs] end-point error with the position error in local NED metres
+                               * (extra_opt='ned', ins_data_manager.py:542-552) next to out_end, or NULL (ref_frame 0 only) */
 } ginsim_mc_params;
 
 int ginsim_mc_run(ginsim_ctx* ctx, const ginsim_mc_params* p);

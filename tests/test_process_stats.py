@@ -113,3 +113,136 @@ def test_sim_results_process_mode_and_ned():
     assert st['pos']['units'] == "['m', 'm', 'm']"
     end = sim.dmgr.get_error_stats('pos', err_stats_start=-1, extra_opt='ned')
     np.testing.assert_allclose(end['max'], g['ned_end_max_algo0'], rtol=1e-6, atol=2e-8)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Statistics WITHOUT trajectories (SURVEY 8(f) rank 2 "at scale"): the fused kernel accumulates the
+# process-error statistics online and writes a second, NED end-point record.
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CASES)
+def test_online_process_stats_match_reference_and_the_kept_path(name):
+    import ginsim
+    g = load_golden(name)
+    ctx = ginsim.default_context()
+    R, fs, rf = int(g['R']), float(g['fs']), int(g['ref_frame'])
+    acc, gyr = _errs(g)
+    truth = {'ref_accel': g['ref_accel'], 'ref_gyro': g['ref_gyro'], 'ref_pos': g['ref_pos'], 'ref_vel': g['ref_vel'],
+             'ref_att': g['ref_att']}
+    odo_err = None
+    if 'odo' in g:
+        truth['ref_odo'] = g['ref_odo']
+        odo_err = {'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])}
+    j0 = int(round(float(g['proc_start_s']) * fs))
+    for ai, a in enumerate(_algos(g)[name]):
+        kept = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, g['ini'], runs=R, algos=(a,), odo_err=odo_err,
+                                    seed=int(g['seed']), keep_traj=True).run()
+        for first in (j0, 0):
+            job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, g['ini'], runs=R, algos=(a,), odo_err=odo_err,
+                                       seed=int(g['seed']), proc_first=first, end_ned=(rf == 0)).run()
+            st = job.process_stats_online(a)
+            if first == j0:
+                np.testing.assert_allclose(st, _want(g, ai, R), rtol=1e-6, atol=1e-10)          # the reference's numbers
+            # the same recurrence over the same samples as the kernel that reads kept trajectories: equal to the bit,
+            # except that one splits the window into four segments and Chan-merges them
+            np.testing.assert_allclose(st, kept.process_stats(a, first), rtol=1e-9, atol=1e-14)
+            np.testing.assert_array_equal(job.end_errors(a), kept.end_errors(a))                 # same trajectories
+            if rf == 0:
+                grp = 'algo%d' % ai
+                end = job.stats(a, ned=True)
+                np.testing.assert_allclose(end.maxabs[3:6], g['ned_end_max_' + grp], rtol=1e-6, atol=2e-8)
+                np.testing.assert_allclose(end.std[3:6], g['ned_end_std_' + grp], rtol=1e-5, atol=2e-8)
+                np.testing.assert_array_equal(end.maxabs[[0, 1, 2, 6, 7, 8]], job.stats(a).maxabs[[0, 1, 2, 6, 7, 8]])
+            job.release()
+        if rf == 0:
+            job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, g['ini'], runs=R, algos=(a,), odo_err=odo_err,
+                                       seed=int(g['seed']), proc_first=j0, proc_ned=True).run()
+            ned = job.process_stats_online(a)
+            for si, s in enumerate(('max', 'avg', 'std')):
+                np.testing.assert_allclose(ned[:, si, 3:6], g['ned_proc_' + s][ai * R:(ai + 1) * R], rtol=1e-6, atol=2e-8)
+            job.release()
+        kept.release()
+
+
+@pytest.mark.gpu
+def test_online_process_stats_argument_checks():
+    import ginsim
+    from ginsim import workloads
+    ctx = ginsim.default_context()
+    ini, truth, _ = workloads.truth_from_profile('turn_90deg', 100.0, 1)
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    with pytest.raises(ValueError, match='one algorithm'):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4, algos=('free', 'odo'),
+                             odo_err={'scale': 1.0, 'stdv': 0.1}, proc_first=0)
+    with pytest.raises(ValueError, match='ref_frame 0'):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4, proc_first=0, proc_ned=True)
+    with pytest.raises(ValueError, match='sample index'):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4, proc_first=1000)
+
+
+@pytest.mark.gpu
+def test_sim_stats_only_results_with_reference_defaults_and_keep_runs(tmp_path):
+    """Sim in stats-only mode (what a 262 144-run Sim is): results() with the reference's defaults (process statistics from
+    t = 0), another window, extra_opt='ned', and keep_runs=K materialising sensors + GPS + outputs of the first K runs --
+    all equal to the same Sim with everything kept."""
+    import contextlib
+    import io
+    import os
+    from conftest import PKG
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration, free_integration_odo
+    g = load_golden('t3_mid_rf0')
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    R, K = 300, 3
+
+    def make(**kw):
+        imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=True, odo=True, odo_opt={'scale': 0.999, 'stdv': 0.1})
+        algos = [free_integration.FreeIntegration(g['ini']), free_integration_odo.FreeIntegration(g['ini'])]
+        return ins_sim.Sim([100.0, 10.0, 0.0], csv, ref_frame=0, imu=imu, algorithm=algos, seed=99, **kw)
+
+    full = make(keep_trajectories=True)
+    lean = make(keep_trajectories=False, keep_runs=K)
+    for sim in (full, lean):
+        sim.run(R)
+    assert lean.kept is False and set(lean.dmgr.accel.data.keys()) == set(range(K)) and len(full.dmgr.accel.data) == R
+    for r in range(K):
+        np.testing.assert_array_equal(lean.dmgr.gyro.data[r], full.dmgr.gyro.data[r])
+        np.testing.assert_array_equal(lean.dmgr.gps.data[r], full.dmgr.gps.data[r])
+        np.testing.assert_array_equal(lean.dmgr.odo.data[r], full.dmgr.odo.data[r])
+        for a in ('algo0', 'algo1'):
+            np.testing.assert_array_equal(lean.dmgr.pos.data['%s_%d' % (a, r)], full.dmgr.pos.data['%s_%d' % (a, r)])
+    assert 'algo0_%d' % K not in lean.dmgr.pos.data
+
+    def stats(sim, **kw):
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            sim.results(**kw)
+        return sim.err_stats, out.getvalue()
+
+    for kw in (dict(), dict(err_stats_start=2.0), dict(err_stats_start=2.0, extra_opt='ned'), dict(err_stats_start=-1),
+               dict(err_stats_start=-1, extra_opt='ned')):
+        a, text_a = stats(full, **kw)
+        b, text_b = stats(lean, **kw)
+        for name in ('att_euler', 'pos', 'vel'):
+            assert a[name]['units'] == b[name]['units']
+            # NED metres are differences of ECEF coordinates (6.4e6 m, ulp 1e-9 m): the two kernels that evaluate them
+            # are compiled with different FMA contraction and agree to 2e-10 m
+            atol = 2e-9 if (name == 'pos' and kw.get('extra_opt') == 'ned') else 1e-13
+            for s in ('max', 'avg', 'std'):
+                if kw.get('err_stats_start', 0) == -1:
+                    assert set(a[name][s].keys()) == {'algo0', 'algo1'}
+                    for grp in ('algo0', 'algo1'):
+                        np.testing.assert_allclose(b[name][s][grp], a[name][s][grp], rtol=1e-9, atol=atol)
+                else:
+                    assert len(b[name][s]) == 2 * R
+                    for key in ('algo0_0', 'algo1_7', 'algo0_%d' % (R - 1), 'algo1_%d' % (R - 1)):
+                        np.testing.assert_allclose(b[name][s][key], a[name][s][key], rtol=1e-9, atol=atol)
+        assert '... %d more runs' % (2 * R - 32) in text_b or kw.get('err_stats_start', 0) == -1
+    with contextlib.redirect_stdout(io.StringIO()):
+        lean.results(str(tmp_path), err_stats_start=-1)
+    files = set(os.listdir(tmp_path))
+    assert {'accel-0.csv', 'gps-2.csv', 'pos-algo1_2.csv', 'ref_gps.csv'} <= files and 'accel-%d.csv' % K not in files
+    # single precision: the default results() falls back to end-point statistics with a notice
+    f32 = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False),
+                      algorithm=free_integration.FreeIntegration(g['ini']), seed=99, precision='f32', keep_trajectories=False)
+    f32.run(64)
+    st, text = stats(f32)
+    assert 'end-point statistics' in text and st['vel']['std'].shape == (3,)
