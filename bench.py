@@ -210,14 +210,14 @@ def leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, reps=
             'bit_identical_to_fused_kernel': same}
 
 
-def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precision, reps, gps=False):
+def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precision, reps, gps=False, **job_kw):
     ini, truth, _ = workloads.truth_from_profile(profile, fs, rf, fs_gps=10.0 if gps else 0.0, gps=gps)
     acc, gyr = workloads.imu_grade('mid-accuracy')
     n = truth['ref_accel'].shape[0]
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, seed=SEED, keep_sensors=keep, keep_traj=keep,
-                               precision=precision)
+                               precision=precision, **job_kw)
     job.run()
-    avg, mn = time_launches(ctx, job.launch, reps)
+    avg, mn = time_launches(ctx, job.launch, reps, warm=2 if reps > 2 else 0)
     st = job.stats('free')
     unit = (BYTES_PER_SAMPLE_MC if precision == 'f64' else BYTES_PER_SAMPLE_MC // 2) if keep else 0
     alg = unit * R * n + 72 * R
@@ -459,8 +459,12 @@ def main():
             legs.append(leg_mc(ginsim, workloads, ctx, 'C4_per_gpu_share', 'BASELINE configs[3] per-GPU share: turn_90deg @100 Hz, '
                                '131 072 runs, fp64, materialised', 'turn_90deg', 100.0, 1, 131072, True, 'f64', 10))
             legs.append(leg_mc(ginsim, workloads, ctx, 'C3', 'BASELINE configs[2]: long_drive @200 Hz (n = 193 036), ref_frame 0, 262 144 '
-                               'runs, fp64, stats-only (6-axis fused kernel; trajectories would be 6 TB)', 'long_drive', 200.0, 0,
-                               262144, False, 'f64', 2, gps=True))
+                               'runs, fp64; trajectories would be 6 TB, so the kernel accumulates the per-run process-error statistics '
+                               '(what Sim.results() prints by default) and both end-point records online; GPS / magnetometer series '
+                               'are generated for the kept subset only (Sim keep_runs), they do not enter the integration',
+                               'long_drive', 200.0, 0, 262144, False, 'f64', 2, gps=True, proc_first=0, end_ned=True))
+            legs.append(leg_mc(ginsim, workloads, ctx, 'C3_end_point_only', 'the same launch with end-point statistics only (r01 form)',
+                               'long_drive', 200.0, 0, 262144, False, 'f64', 2, gps=True))
             legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32', 'BASELINE configs[4]: fp32 kernel on the C2 workload, 65 536 runs, '
                                'materialised (60 B/sample*MC)', 'turn_90deg', 100.0, 1, 65536, True, 'f32', 20))
             legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32_262144', 'fp32 kernel, 262 144 runs, materialised', 'turn_90deg', 100.0, 1,

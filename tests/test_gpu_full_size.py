@@ -163,3 +163,62 @@ def test_shard_invariance_with_steps_across_the_series_threshold(ctx):
             first += count
         assert first == R
         whole.release()
+
+
+def test_c3_sim_for_real(ctx):
+    """BASELINE config 3 through the drop-in Sim, as a user would run it: long_drive @200 Hz, 9-axis IMU + GPS error model,
+    ref_frame 0, 262 144 runs.  Nothing but statistics fits in HBM (the trajectories would be 6 TB), so: process-error
+    statistics accumulated inside the kernel (results() with the reference's defaults), the NED end-point record, and
+    keep_runs=2 materialising sensors / GPS / magnetometer / outputs of two runs.  Sampled runs against the C oracle."""
+    import contextlib
+    import io
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration
+    from ginsim import workloads
+    from oracle import c_oracle, ins_np
+    R, seed = 262144, 777
+    csv = workloads.profile_path('long_drive')
+    ini, truth, raw = workloads.truth_from_profile('long_drive', 200.0, 0, fs_gps=10.0, gps=True)
+    g9 = load_golden('t3_mag9_gps_rf0')
+    imu = imu_model.IMU(accuracy='mid-accuracy', axis=9, gps=True)
+    sim = ins_sim.Sim([200.0, 10.0, 200.0], csv, ref_frame=0, imu=imu, algorithm=free_integration.FreeIntegration(ini),
+                      seed=seed, geo_mag_n=g9['geo_mag_n'], keep_runs=2)
+    sim.run(R)
+    assert sim.kept is False
+    d = sim.dmgr
+    assert sorted(d.accel.data.keys()) == [0, 1] and d.gps.data[1].shape == (9652, 6) and d.mag.data[0].shape == (193036, 3)
+    assert d.pos.data['algo0_1'].shape == (193036, 3)
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        sim.results()                                       # the reference's defaults: err_stats_start = 0
+    text = out.getvalue()
+    st = sim.err_stats
+    assert len(st['vel']['std']) == R and ('... %d more runs' % (R - 32)) in text
+    # sampled runs vs the C oracle's trajectories -> host process statistics (oracle/ins_np.py)
+    acc, gyr = imu.accel_err, imu.gyro_err
+    worst = 0.0
+    for first, count in ((0, 3), (R // 2 + 61, 3), (R - 3, 3)):
+        end, traj, _ = c_oracle.mc_run(seed, first, count, 200.0, 0, truth, acc, gyr, ini, keep=count)
+        want = ins_np.process_error_stats(traj[:, :, 0:3], traj[:, :, 3:6], traj[:, :, 6:9], truth['ref_att'], truth['ref_pos'],
+                                          truth['ref_vel'], 0)
+        for k in range(count):
+            key = 'algo0_%d' % (first + k)
+            got = np.concatenate([np.stack([st[nm][s][key] for s in ('max', 'avg', 'std')]) / sc for nm, sc in
+                                  (('att_euler', 180 / np.pi), ('pos', np.array([180 / np.pi, 180 / np.pi, 1.0])), ('vel', 1.0))], axis=1)
+            rel = np.abs(got - want[k]) / np.maximum(np.abs(want[k]), 1e-12)
+            worst = max(worst, rel.max())
+    _record('c3_sim_process_stats_R%d' % R, rel=worst)
+    assert worst <= 1e-7, worst
+    # kept runs are the oracle's runs 0 and 1 (sensors per sample, trajectories at the end of the horizon)
+    end, traj, sens = c_oracle.mc_run(seed, 0, 2, 200.0, 0, truth, acc, gyr, ini, keep=2)
+    for r in range(2):
+        np.testing.assert_allclose(d.gyro.data[r], sens[r][:, 3:6], rtol=0, atol=1e-14)
+        np.testing.assert_allclose(d.accel.data[r], sens[r][:, 0:3], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(d.vel.data['algo0_%d' % r], traj[r][:, 6:9], rtol=1e-7, atol=1e-8)
+    # end-point statistics and their NED form need no trajectories either
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim.results(err_stats_start=-1, extra_opt='ned')
+    assert sim.err_stats['pos']['units'] == "['m', 'm', 'm']" and np.all(sim.err_stats['pos']['std'] > 100.0)
+    e = sim.mc.jobs[0].end_errors('free', ned=True)
+    np.testing.assert_allclose(sim.err_stats['pos']['std'], e[:, 3:6].std(0), rtol=1e-9)
+    first = ins_np.lla_error_ned((end[:, 3:6] + truth['ref_pos'][-1])[:2], np.broadcast_to(truth['ref_pos'][-1], (2, 3)))
+    np.testing.assert_allclose(e[:2, 3:6], first, rtol=1e-7, atol=1e-6)
