@@ -319,6 +319,72 @@ def csv_case():
     print('   csv: %d files: %s' % (len(names), ' '.join(names)))
 
 
+# ------------------------------------------------------------------ T4: the UNPATCHED reference, statistics only
+def t4_reference_statistics():
+    """SURVEY 8(c) T4.  The reference as shipped -- its own global MT19937 stream, np.random.seed(s) for repeatability --
+    on config 1 (90-degree turn @100 Hz, 'mid-accuracy' 6-axis IMU, ref_frame 1, FreeIntegration), R = 1000 runs for each
+    of five seeds.  Kept: the end-point errors' mean / std / max per seed and pooled.  No run of the engine can reproduce
+    these numbers run by run (different random stream); its 65 536-run statistics must agree within sampling error."""
+    csv = MOTION + 'motion_def-90deg_turn.csv'
+    ini = read_ini(csv)
+    R, seeds = 1000, [2024, 7, 99, 31337, 20260923]
+    per_seed = []
+    for sd in seeds:
+        np.random.seed(sd)
+        imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False)
+        sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, algorithm=free_integration.FreeIntegration(ini.copy()))
+        sim.run(R)
+        d = sim.dmgr
+        e = np.empty((R, 9))
+        for r in range(R):
+            k = 'algo0_%d' % r
+            a = d.att_euler.data[k][-1] - d.ref_att_euler.data[-1]
+            e[r, 0:3] = np.mod(a + np.pi, 2 * np.pi) - np.pi
+            e[r, 3:6] = d.pos.data[k][-1] - d.ref_pos.data[-1]
+            e[r, 6:9] = d.vel.data[k][-1] - d.ref_vel.data[-1]
+        per_seed.append(e)
+        print('   T4 seed %d: att std [deg] %s  vel std %s' % (sd, np.degrees(e[:, :3].std(0)), e[:, 6:9].std(0)))
+    allr = np.concatenate(per_seed)
+    save('t4_c1_reference_stats', seeds=np.array(seeds), runs_per_seed=R,
+         mean=np.stack([e.mean(0) for e in per_seed]), std=np.stack([e.std(0) for e in per_seed]),
+         maxabs=np.stack([np.abs(e).max(0) for e in per_seed]),
+         pooled_mean=allr.mean(0), pooled_std=allr.std(0), pooled_maxabs=np.abs(allr).max(0), pooled_runs=allr.shape[0])
+
+
+# ------------------------------------------------------------------ truth of a profile that uses every command type + custom mobility
+MIXED = """ini lat (deg),ini lon (deg),ini alt (m),ini vx_body (m/s),ini vy_body (m/s),ini vz_body (m/s),ini yaw (deg),ini pitch (deg),ini roll (deg)
+31.2,121.4,10,3,0,0,40,0,0
+command type,yaw (deg),pitch (deg),roll (deg),vx_body (m/s),vy_body (m/s),vz_body (m/s),command duration (s),GPS visibility
+1,0,0,0,0,0,0,4,1
+4,75,5,0,2,0,0,12,1
+1,0,0,0,0,0,0,3,1
+2,10,0,0,8,0,0,15,0
+3,-30,-5,10,-3,0,0,10,1
+5,20,0,-10,4,0,0,9,1
+4,-120,0,0,-1.5,0,0,14,1
+1,0,0,0,0,0,0,2,1
+"""
+
+
+def truth_mixed_types():
+    """path_gen on a profile that uses command types 1-5 (type 4 = absolute attitude + relative velocity is used by none of
+    the reference's own motion files) with a CUSTOM mobility array (Sim(mode=np.array([...])), ins_sim.py:612-640), both
+    frames, GPS + odometer."""
+    mode = np.array([2.5, 20.0, 60.0])         # m/s^2, deg/s^2, deg/s
+    for rf in (0, 1):
+        s = ins_sim.Sim([50.0, 5.0, 0.0], MIXED, ref_frame=rf, imu=None, mode=mode)
+        ini_pva, motion_def = s._Sim__parse_motion()
+        mobility = s._Sim__parse_mode(mode)
+        output_def = np.array([[1.0, 50.0], [1.0, 5.0], [1.0, 50.0]])
+        r = pathgen.path_gen(ini_pva.copy(), motion_def.copy(), output_def, mobility, ref_frame=rf, magnet=False)
+        n, m = r['imu'].shape[0], r['gps'].shape[0]
+        k, kg = rows(n, 7), rows(m, 3)
+        save('truth_mixed_types_rf%d' % rf, fs=50.0, fs_gps=5.0, n=n, m=m, rows=k, gps_rows=kg, mode=mode, text=np.array(MIXED),
+             ini_pva=ini_pva, motion_def=motion_def, mobility=mobility,
+             imu=r['imu'][k], nav=r['nav'][k], gps=r['gps'][kg], odo=r['odo'][k])
+        print('   mixed rf%d: n = %d, m = %d' % (rf, n, m))
+
+
 def allan_case():
     n, fs = 360000, 100.0
     x = 0.3 * philox.normal_pair(SEED, 7, 5, np.arange(n, dtype=np.uint64))[0] \
@@ -353,3 +419,5 @@ if __name__ == '__main__':
     csv_case()
     allan_case()
     t2_long_drive()
+    truth_mixed_types()
+    t4_reference_statistics()

@@ -222,3 +222,30 @@ def test_c3_sim_for_real(ctx):
     np.testing.assert_allclose(sim.err_stats['pos']['std'], e[:, 3:6].std(0), rtol=1e-9)
     first = ins_np.lla_error_ned((end[:, 3:6] + truth['ref_pos'][-1])[:2], np.broadcast_to(truth['ref_pos'][-1], (2, 3)))
     np.testing.assert_allclose(e[:2, 3:6], first, rtol=1e-7, atol=1e-6)
+
+
+def test_t4_statistics_against_the_unpatched_reference(ctx):
+    """SURVEY 8(c) T4.  tests/golden/t4_c1_reference_stats.npz holds the end-point statistics of the reference AS SHIPPED
+    (its own MT19937 stream, np.random.seed(s), R = 1000 runs for each of five seeds) on config 1.  The engine's stream is
+    a different one, so the comparison is statistical: with N = 65 536 engine runs and M reference runs, the means must agree
+    within 4 sigma sqrt(1/N + 1/M) and the standard deviations within a relative 4 sqrt(1/2N + 1/2M) -- per seed
+    (M = 1000) and pooled (M = 5000).  The pooled check resolves 4 % of a standard deviation."""
+    import ginsim
+    from ginsim import workloads
+    g = load_golden('t4_c1_reference_stats')
+    ini, truth, _ = workloads.truth_from_profile('turn_90deg', 100.0, 1)
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    N = 65536
+    st = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=N, seed=424242).run().stats('free')
+    worst = 0.0
+    for mean, std, M in [(g['pooled_mean'], g['pooled_std'], int(g['pooled_runs']))] + \
+            [(g['mean'][i], g['std'][i], int(g['runs_per_seed'])) for i in range(len(g['seeds']))]:
+        z_mean = np.abs(st.mean - mean) / (st.std * np.sqrt(1.0 / N + 1.0 / M))
+        z_std = np.abs(st.std / std - 1.0) / np.sqrt(0.5 / N + 0.5 / M)
+        worst = max(worst, z_mean.max(), z_std.max())
+        assert z_mean.max() < 4.0, (M, z_mean)
+        assert z_std.max() < 4.0, (M, z_std)
+    _record('t4_vs_unpatched_reference', worst_z=worst)
+    # the extremes of 65 536 runs exceed those of 5000 by what Gaussian tails predict (sqrt(2 ln N) ratio ~ 1.15), not more
+    ratio = st.maxabs / g['pooled_maxabs']
+    assert np.all(ratio > 0.85) and np.all(ratio < 1.6), ratio

@@ -58,6 +58,31 @@ def test_native_pathgen_matches_reference(rf):
     np.testing.assert_allclose(r['odo'][k, 2], g['ref_odo'], rtol=0, atol=1e-13)
 
 
+@pytest.mark.parametrize('rf', [0, 1])
+def test_native_pathgen_every_command_type_and_custom_mode(rf):
+    """Command types 1-5 (type 4 = absolute attitude + relative velocity appears in none of the reference's own motion
+    files) and a custom mobility array (Sim(mode=np.array([...])), ins_sim.py:612-640) against the executed reference."""
+    import ginsim
+    from gnss_ins_sim.sim import ins_sim
+    g = load_golden('truth_mixed_types_rf%d' % rf)
+    k, kg = g['rows'], g['gps_rows']
+    ini, md = __import__('ginsim.workloads', fromlist=['parse_motion']).parse_motion(str(g['text']))
+    np.testing.assert_allclose(ini, g['ini_pva'], rtol=0, atol=0)
+    np.testing.assert_allclose(md, g['motion_def'], rtol=0, atol=0)
+    assert sorted(set(md[:, 0])) == [1.0, 2.0, 3.0, 4.0, 5.0]
+    mob = ins_sim.Sim._parse_mode(g['mode'])
+    np.testing.assert_allclose(mob, g['mobility'], rtol=0, atol=0)
+    r = ginsim.pathgen(ini, md, float(g['fs']), float(g['fs_gps']), mob, rf, gps=True)
+    assert r['imu'].shape[0] == int(g['n']) and r['gps'].shape[0] == int(g['m'])
+    np.testing.assert_allclose(r['imu'][k], g['imu'], rtol=0, atol=2e-13)
+    np.testing.assert_allclose(r['nav'][k, 0:4], g['nav'][:, 0:4], rtol=1e-15, atol=0)
+    np.testing.assert_allclose(r['nav'][k, 4:10], g['nav'][:, 4:10], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(r['gps'][kg], g['gps'], rtol=1e-15, atol=1e-13)
+    np.testing.assert_allclose(r['odo'][k], g['odo'], rtol=1e-14, atol=1e-13)
+    with pytest.raises(TypeError):
+        ins_sim.Sim._parse_mode(np.array([1.0, 2.0]))
+
+
 def test_pathgen_error_behaviour():
     """Same exception type and wording as pathgen.py:117-125 for bad motion definitions."""
     import ginsim

@@ -102,6 +102,19 @@ def test_t2_pathgen_and_noise_free_loop(rf):
                       rtol=1e-11, what='odo')
 
 
+@pytest.mark.parametrize('rf', [0, 1])
+def test_oracle_pathgen_every_command_type(rf):
+    g = load_golden('truth_mixed_types_rf%d' % rf)
+    k, kg = g['rows'], g['gps_rows']
+    r = ins_np.path_gen(g['ini_pva'], g['motion_def'], float(g['fs']), float(g['fs_gps']), g['mobility'], rf, gps=True, odo=True)
+    assert r['imu'].shape[0] == int(g['n']) and r['gps'].shape[0] == int(g['m'])
+    np.testing.assert_allclose(r['imu'][k], g['imu'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r['nav'][k, 1:4], g['nav'][:, 1:4], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(r['nav'][k, 4:7], g['nav'][:, 4:7], rtol=0, atol=1e-12)
+    assert ang_close(r['nav'][k, 7:10], g['nav'][:, 7:10], 1e-13)
+    np.testing.assert_allclose(r['gps'][kg, 1:7], g['gps'][:, 1:7], rtol=1e-14, atol=1e-12)
+
+
 def _errs(g):
     acc = {k[6:]: g[k] for k in g if k.startswith('accel_') and k != 'accel'}
     gyr = {k[5:]: g[k] for k in g if k.startswith('gyro_') and k != 'gyro'}
