@@ -42,17 +42,12 @@ def parse_motion(src):
     return ini, seg
 
 
-# built-in IMU grades in internal units, gnss_ins_sim/sim/imu_model.py:18-52
 def imu_grade(name):
-    table = {'low-accuracy': (10.0, 0.75, 2.0e-4, 0.05), 'mid-accuracy': (3.5, 0.25, 5.0e-5, 0.03),
-             'high-accuracy': (0.1, 2.0e-3, 3.6e-6, 2.5e-5)}
-    if name not in table:
-        raise ValueError('accuracy is not a valid string.')
-    gd, arw, ad, vrw = table[name]
-    gyro = {'b': np.zeros(3), 'b_drift': np.full(3, gd) * D2R / 3600.0, 'b_corr': np.full(3, 100.0),
-            'arw': np.full(3, arw) * D2R / 60.0}
-    accel = {'b': np.zeros(3), 'b_drift': np.full(3, ad), 'b_corr': np.full(3, 100.0), 'vrw': np.full(3, vrw) / 60.0}
-    return accel, gyro
+    """(accel_err, gyro_err) of a built-in IMU grade in internal units.  Single source: the drop-in package's
+    gnss_ins_sim.sim.imu_model (which restates gnss_ins_sim/sim/imu_model.py:18-52 and its unit conversions :138-143)."""
+    from gnss_ins_sim.sim import imu_model
+    imu = imu_model.IMU(accuracy=name, axis=6, gps=False)
+    return imu.accel_err, imu.gyro_err
 
 
 def truth_from_profile(name, fs, ref_frame, fs_gps=0.0, gps=False, mobility=HIGH_MOBILITY):
