@@ -1,19 +1,37 @@
 #!/bin/bash
-# Run on the GPU box via gpurun: tests, smoke, bench, rocprofv3 kernel trace + PMC passes.
+# Evidence run on the GPU box (via gpurun): GPU tests, smoke, the default bench, and the rocprofv3 passes whose summaries are
+# committed under profiles/.  Everything of ONE invocation lands in gpurun_out/round_<tag>/ (raw rocprofv3 databases
+# included), and tools/summarize_prof.py regenerates profiles/<tag>_* from exactly that directory -- so a summary can
+# always be traced back to the raw run it came from, and every file carries the sha256 of the libginsim.so that ran.
+#   usage: tools/gpu_round.sh <tag>        e.g. r02a   (one tag per box / invocation; all of them are kept)
 set -u
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out
-mkdir -p $OUT
+OUT=$ROOT/gpurun_out/round_$TAG
+rm -rf $OUT; mkdir -p $OUT
 cd $ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-python __graft_entry__.py --smoke 2>&1 | tail -3
-python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench.json; tail -5 $OUT/bench.err
+sha256sum gnss-ins-sim_amd/lib/libginsim.so | cut -c1-16 > $OUT/lib_sha256.txt
+(rocm-smi --showproductname 2>/dev/null | grep -i "card series\|GFX" | head -2; uname -n) > $OUT/box.txt 2>&1
+python -X faulthandler -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+cp gpurun_out/parity_margins.json $OUT/ 2>/dev/null
+python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+python bench.py > $OUT/bench.json 2> $OUT/bench.err; python - <<PY
+import json
+d = json.load(open("$OUT/bench.json"))
+print("bench: %.4g %s, %.3f ms/step, kernel %.3f ms, frac %.3f, traffic %s" % (d["value"], d["unit"], d["ms_per_step"],
+      d["roofline"]["kernel_ms_avg"], d["roofline"]["frac"], d["roofline"]["traffic"]))
+for l in d.get("configs", []):
+    print("  leg %-22s kernel %.3f ms  frac %.3f" % (l["name"], l["roofline"]["kernel_ms_avg"], l["roofline"]["frac"]))
+PY
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --steps 10 --warmup 2 --cpu-baseline-seconds 0"
-rocprofv3 --kernel-trace --stats -d $OUT/prof_trace -o bench -- python $ROOT/bench.py --cpu-baseline-seconds 0 > $OUT/prof_trace.log 2>&1    # the default command: 200 + 10 steps
+B="python $ROOT/bench.py --pmc-child"
+# the default command (200 + 10 steps, all legs) under the kernel trace: per-kernel averages that must agree with the HIP events
+rocprofv3 --kernel-trace --stats -d $OUT/prof_trace -o bench -- python $ROOT/bench.py --cpu-baseline-seconds 0 --pmc off > $OUT/prof_trace.json 2> $OUT/prof_trace.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/prof_pmc_write -o bench -- $B > $OUT/prof_pmc_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_pmc_fetch -o bench -- $B > $OUT/prof_pmc_fetch.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/prof_pmc_sq -o bench -- $B > $OUT/prof_pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --kernel-trace -d $OUT/prof_pmc_mix -o bench -- $B > $OUT/prof_pmc_mix.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace -d $OUT/prof_pmc_lds -o bench -- $B > $OUT/prof_pmc_lds.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace -d $OUT/prof_pmc_grbm -o bench -- $B > $OUT/prof_pmc_grbm.log 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/prof_allan -o bench -- python $ROOT/tools/bench_allan.py > $OUT/prof_allan.log 2>&1
-ls $OUT
+rocprofv3 --kernel-trace --stats -d $OUT/prof_allan -o bench -- python $ROOT/tools/bench_allan.py > $OUT/prof_allan.json 2> $OUT/prof_allan.log
+du -sh $OUT

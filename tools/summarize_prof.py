@@ -1,39 +1,62 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 result databases under gpurun_out/prof_* into the small text summaries committed under
-profiles/ (kernel trace stats, PMC counters, HBM traffic per launch)."""
+"""Regenerate the committed evidence under profiles/ from ONE raw evidence run (gpurun_out/round_<tag>/, made by
+tools/gpu_round.sh <tag>).  Every output carries the sha256 of the libginsim.so that ran and the tag of the raw run.
+
+    python tools/summarize_prof.py <tag> [--traffic]
+
+--traffic also (re)writes profiles/pmc_traffic.json, the file bench.py falls back to when it cannot run rocprofv3 itself; it
+is only honoured by bench.py when its `libginsim_sha256` equals the hash of the library being benchmarked.
+"""
 import csv
-import re
+import glob
 import json
 import os
+import shutil
 import sqlite3
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(REPO, 'gpurun_out')
+tag = sys.argv[1]
+SRC = os.path.join(REPO, 'gpurun_out', 'round_' + tag)
 DST = os.path.join(REPO, 'profiles')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+sha = open(os.path.join(SRC, 'lib_sha256.txt')).read().strip()
+os.makedirs(DST, exist_ok=True)
+stamp = '# raw run: gpurun_out/round_%s ; libginsim.so sha256[:16] = %s' % (tag, sha)
 
 
 def db(name):
-    p = os.path.join(SRC, name, 'bench_results.db')
-    return sqlite3.connect(p) if os.path.exists(p) else None
+    hits = sorted(glob.glob(os.path.join(SRC, name, '**', '*.db'), recursive=True))
+    return sqlite3.connect(hits[0]) if hits else None
 
 
-os.makedirs(DST, exist_ok=True)
+# --- bench line + parity margins + test log tail
+for f, out in (('bench.json', tag + '_bench_n1.json'), ('parity_margins.json', tag + '_parity_margins.json')):
+    if os.path.exists(os.path.join(SRC, f)):
+        shutil.copy(os.path.join(SRC, f), os.path.join(DST, out))
+bench = json.load(open(os.path.join(SRC, 'bench.json')))
+assert bench['config']['libginsim_sha256'] == sha, 'bench.json was produced by another library build'
+with open(os.path.join(DST, tag + '_gpu_tests.txt'), 'w') as f:
+    f.write(stamp + '\n')
+    f.write(open(os.path.join(SRC, 'pytest_gpu.log')).read()[-600:])
+    f.write(open(os.path.join(SRC, 'smoke.log')).read()[-200:])
+
+# --- kernel trace of the default bench command
 con = db('prof_trace')
-if con:
-    rows = list(con.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start), "
-                            "max(vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(workgroup_x) "
-                            "from kernels group by name order by sum(end-start) desc"))
-    total = sum(r[2] for r in rows)
-    with open(os.path.join(DST, tag + '_kernel_trace_stats.csv'), 'w', newline='') as f:
-        w = csv.writer(f)
-        w.writerow(['# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-baseline-seconds 0   (default: 200 timed + 10 warm-up steps)'])
-        w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'min_ns', 'max_ns', 'percent', 'vgpr', 'sgpr', 'lds_bytes',
-                    'grid_x', 'workgroup_x'])
-        for r in rows:
-            w.writerow([r[0], r[1], int(r[2]), int(r[3]), int(r[4]), int(r[5]), '%.2f' % (100.0 * r[2] / total)] + list(r[6:]))
-    print(open(os.path.join(DST, tag + '_kernel_trace_stats.csv')).read())
+rows = list(con.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start), "
+                        "max(vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(workgroup_x) "
+                        "from kernels group by name order by sum(end-start) desc"))
+total = sum(r[2] for r in rows)
+with open(os.path.join(DST, tag + '_kernel_trace_stats.csv'), 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow([stamp])
+    w.writerow(['# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-baseline-seconds 0 --pmc off   (200 timed + 10 warm-up steps, all legs)'])
+    w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'min_ns', 'max_ns', 'percent', 'vgpr', 'sgpr', 'lds_bytes', 'grid_x', 'workgroup_x'])
+    for r in rows:
+        w.writerow([r[0], r[1], int(r[2]), int(r[3]), int(r[4]), int(r[5]), '%.2f' % (100.0 * r[2] / total)] + list(r[6:]))
+traced = {r[0]: r[3] / 1e6 for r in rows}
+k = bench['roofline']['kernel']
+tr = [v for n, v in traced.items() if n.startswith('void ' + k + '(')]
+print('dominant kernel %s: HIP events %.4f ms (bench.json) vs rocprofv3 trace avg %.4f ms' % (k, bench['roofline']['kernel_ms_avg'], tr[0] if tr else float('nan')))
 
 con = db('prof_allan')
 if con:
@@ -41,50 +64,50 @@ if con:
                             "from kernels where name like '%allan%' group by name, grid_x, grid_y order by avg(end-start) desc"))
     with open(os.path.join(DST, tag + '_allan_kernel_trace.csv'), 'w', newline='') as f:
         w = csv.writer(f)
+        w.writerow([stamp])
         w.writerow(['# rocprofv3 --kernel-trace --stats -- python tools/bench_allan.py  (192 series x 1 440 000 samples, 11 calls)'])
         w.writerow(['kernel', 'grid_x', 'grid_y', 'calls', 'avg_ns', 'min_ns', 'max_ns', 'vgpr', 'lds_bytes'])
         for r in rows:
             w.writerow([r[0], r[1], r[2], r[3], int(r[4]), int(r[5]), int(r[6]), r[7], r[8]])
-    print(open(os.path.join(DST, tag + '_allan_kernel_trace.csv')).read())
 
+# --- PMC passes
 pmc = {}
 for d in sorted(os.listdir(SRC)):
-    if not d.startswith('prof_pmc'):
-        continue
-    con = db(d)
-    if not con:
-        continue
-    for k, c, n, avg, mn, mx in con.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) "
-                                           "from counters_collection group by kernel_name, counter_name"):
-        pmc.setdefault(k, {})[c] = (n, avg, mn, mx)
+    if d.startswith('prof_pmc'):
+        con = db(d)
+        if con:
+            for kn, c, n, avg, mn, mx in con.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) "
+                                                     "from counters_collection group by kernel_name, counter_name"):
+                pmc.setdefault(kn, {})[c] = (n, avg, mn, mx)
 with open(os.path.join(DST, tag + '_pmc_counters.csv'), 'w', newline='') as f:
     w = csv.writer(f)
-    w.writerow(['# rocprofv3 --pmc <one group per pass> --kernel-trace -- python bench.py --steps 10 --warmup 2 '
-                '--cpu-baseline-seconds 0 ; values are per dispatch (avg/min/max over dispatches)'])
+    w.writerow([stamp])
+    w.writerow(['# rocprofv3 --pmc <one group per pass> --kernel-trace -- python bench.py --pmc-child (3 timed + 1 warm-up launches of the C2 '
+                'workload and 4 of the given-sensors kernel); values are per dispatch (avg/min/max over dispatches)'])
     w.writerow(['kernel', 'counter', 'dispatches', 'avg', 'min', 'max'])
-    for k in sorted(pmc):
-        for c in sorted(pmc[k]):
-            w.writerow([k, c] + ['%.6g' % v if isinstance(v, float) else v for v in pmc[k][c]])
+    for kn in sorted(pmc):
+        for c in sorted(pmc[kn]):
+            w.writerow([kn, c] + ['%.6g' % v if isinstance(v, float) else v for v in pmc[kn][c]])
 
 traffic = {}
-for k, c in pmc.items():
-    if 'mc_kernel' in k and 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
-        # MI355X_MICROARCH.md (HBM): rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE reads
-        # half of the bytes of a coalesced stream -> doubled.  WRITE_SIZE matched the known byte count exactly here.
-        fetch_b = 2.0 * c['FETCH_SIZE'][1] * 1024
-        write_b = c['WRITE_SIZE'][1] * 1024
-        key = 'mc_kernel_rf1_free_given' if re.search(r'mc_kernel<\d, \d, true', k) else 'mc_kernel_rf1_free_keep'
-        traffic[key] = {'kernel': k, 'hbm_bytes_per_launch': fetch_b + write_b, 'fetch_bytes_corrected': fetch_b,
-                        'write_bytes': write_b, 'source': 'profiles/%s_pmc_counters.csv' % tag}
-with open(os.path.join(DST, 'pmc_traffic.json'), 'w') as f:
-    json.dump(traffic, f, indent=1)
-print(json.dumps(traffic, indent=1))
-for k in pmc:
-    if 'mc_kernel' in k:
-        c = pmc[k]
-        if 'SQ_WAVE_CYCLES' in c:
-            print(k)
-            if 'GRBM_GUI_ACTIVE' in c:
-                print('  GRBM_GUI_ACTIVE (summed over the 8 XCDs) per launch: %.4g' % c['GRBM_GUI_ACTIVE'][1])
-            print('VALU active / wave cycles: %.3f ; busy cycles %.4g ; VALU insts/wave %.4g' % (
-                c['SQ_ACTIVE_INST_VALU'][1] / c['SQ_WAVE_CYCLES'][1], c['SQ_BUSY_CYCLES'][1], c['SQ_INSTS_VALU'][1] / c['SQ_WAVES'][1]))
+for kn, c in pmc.items():
+    if 'mc_kernel' in kn and 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+        # MI355X_MICROARCH.md (HBM): rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE reads half of the
+        # bytes of a coalesced stream -> doubled.  WRITE_SIZE matches the known byte count of these kernels exactly.
+        fetch_b, write_b = 2.0 * c['FETCH_SIZE'][1] * 1024, c['WRITE_SIZE'][1] * 1024
+        name = kn[len('void '):] if kn.startswith('void ') else kn
+        name = name[:name.index('(')]
+        traffic[name] = {'hbm_bytes_per_launch': fetch_b + write_b, 'fetch_bytes_corrected': fetch_b, 'write_bytes': write_b,
+                         'dispatches': c['WRITE_SIZE'][0]}
+summary = {'raw_run': 'gpurun_out/round_' + tag, 'libginsim_sha256': sha, 'kernels': traffic}
+with open(os.path.join(DST, tag + '_pmc_traffic.json'), 'w') as f:
+    json.dump(summary, f, indent=1)
+if '--traffic' in sys.argv:
+    with open(os.path.join(DST, 'pmc_traffic.json'), 'w') as f:
+        json.dump(summary, f, indent=1)
+print(json.dumps(summary, indent=1))
+for kn, c in pmc.items():
+    if 'mc_kernel_split' in kn and 'SQ_INSTS_VALU' in c and 'SQ_WAVES' in c:
+        steps = 1000.0
+        groups = c['SQ_WAVES'][1] / 2.0
+        print('%s: VALU per step and 64 runs = %.1f' % (kn[:60], c['SQ_INSTS_VALU'][1] / groups / steps))
