@@ -297,6 +297,9 @@ def main():
                     help='roofline.traffic: rocprofv3 PMC passes of this build (live), the stamped profiles/pmc_traffic.json, or null')
     ap.add_argument('--pmc-child', action='store_true', help='internal: the short workload the live PMC passes profile')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for tests)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise torch.distributed and run the exchange also with ONE rank (a one-GPU box can then execute '
+                         'the RCCL code path: communicator set-up, device-tensor all-reduce, non-blocking work handles)')
     ap.add_argument('--shared-device', action='store_true',
                     help='TEST ONLY: every rank uses GPU 0 (exercises the N > 1 control flow on a one-GPU box)')
     args = ap.parse_args()
@@ -321,8 +324,12 @@ def main():
     if args.shared_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
@@ -338,7 +345,7 @@ def main():
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, algos=('free',), seed=SEED,
                                keep_sensors=keep, keep_traj=keep, precision=args.precision)
     unit_bytes = BYTES_PER_SAMPLE_MC if args.precision == 'f64' else BYTES_PER_SAMPLE_MC // 2
-    group = dist.group.WORLD if world > 1 else None
+    group = dist.group.WORLD if use_dist else None
     device = torch.device('cuda', local_rank) if args.backend == 'nccl' else torch.device('cpu')
     nsteps = args.warmup + args.steps
     # HIP events bracket the MC kernel of every `stride`-th step (the context has 8192 event slots)
@@ -380,7 +387,7 @@ def main():
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         ctx.sync()
         torch.cuda.synchronize()
@@ -395,7 +402,7 @@ def main():
     merged = drain()                                        # the last batches' exchanges are inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -478,7 +485,7 @@ def main():
     if job is not None:
         job.release()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

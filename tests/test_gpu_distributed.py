@@ -46,6 +46,17 @@ def test_bench_two_ranks_share_the_work():
     assert two['value'] > 0 and 'roofline' in two and 'cpu_baseline' not in two
 
 
+def test_rccl_exchange_executes_on_one_gpu():
+    """The box has one GPU, so the 8-rank RCCL run cannot happen here -- but its code path can: backend 'nccl' (= RCCL) with a
+    one-rank communicator executes communicator set-up, the device-tensor all-reduce of the statistics table, the
+    non-blocking work handles and the barrier exactly as N ranks would; the merged record must equal the local one."""
+    common = ['--steps', '3', '--warmup', '1', '--runs-per-gpu', '8192', '--cpu-baseline-seconds', '0', '--no-legs', '--pmc', 'off']
+    plain = _bench(1, common)
+    rccl = _bench(1, common + ['--force-dist', '--backend', 'nccl'])
+    assert rccl['n_gpus'] == 1 and 'RCCL' in rccl['config']['parallelism']
+    assert rccl['result'] == plain['result']
+
+
 _SIM_WORKER = r'''
 import os, sys
 sys.path[:0] = [%(pkg)r, %(repo)r]
