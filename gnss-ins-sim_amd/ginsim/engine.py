@@ -421,12 +421,13 @@ class MonteCarloJob(object):
         p = self.params
         if p.precision == 1:
             return 'ginsim::f32::mc_kernel_f32%s<%d, %d>' % ('_split' if v.value else '', p.ref_frame, p.algo_mask)
-        wd = (not p.given_sensors) and ((p.ref_frame == 0 and p.algo_mask == 3) or any(
+        ps = 0 if self.proc_first is None else (2 if (self.proc_ned and p.ref_frame == 0) else 1)
+        wd = (not p.given_sensors) and (ps != 0 or (p.ref_frame == 0 and p.algo_mask == 3) or any(
             p.accel.white_drift[k] or p.gyro.white_drift[k] or p.accel.bias[k] != 0.0 or p.gyro.bias[k] != 0.0 for k in range(3)))
         if v.value:
             return 'ginsim::mc_kernel_split<%d, %d, %s>' % (p.ref_frame, p.algo_mask, 'true' if wd else 'false')
-        return 'ginsim::mc_kernel<%d, %d, %s, %s>' % (p.ref_frame, p.algo_mask, 'true' if p.given_sensors else 'false',
-                                                      'true' if wd else 'false')
+        return 'ginsim::mc_kernel<%d, %d, %s, %s, %d>' % (p.ref_frame, p.algo_mask, 'true' if p.given_sensors else 'false',
+                                                          'true' if wd else 'false', ps)
 
     def run(self):
         self.launch()
