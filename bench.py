@@ -141,7 +141,7 @@ def reference_python_baseline(budget_s):
 
 
 # --------------------------------------------------------------------------------------------- PMC traffic
-def pmc_traffic_live(kernels, timeout_s=150):
+def pmc_traffic_live(kernels, timeout_s=90):
     """HBM bytes per launch of `kernels` (names as rocprofv3 reports them, without arguments) from two rocprofv3 --pmc
     passes of this script's --pmc-child mode (same build, same workload, 3 launches each): WRITE_SIZE and FETCH_SIZE in
     KiB; FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section).  Returns {kernel: {...}} or None."""
