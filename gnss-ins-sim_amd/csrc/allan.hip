@@ -25,18 +25,20 @@ constexpr int kLoads = 40;          // 40 x 64 entries >= kStage
 
 constexpr int kMaxChunksPerBlock = 4;
 
-// sum over the adjacent-bin pairs (k, k+1), k < OWN, of (S_{k+1} - S_k)^2; g0 = global index of bin 0
+// sum over the adjacent-bin pairs (k, k+1), k < OWN, of (S_{k+1} - S_k)^2; g0 = global index of bin 0.  Four interleaved
+// partial sums: a single chain of dependent fp64 FMAs runs at the FMA latency, which a wavefront that is alone on its
+// SIMD (the LDS-DMA kernel) cannot hide.
 template <int OWN, bool CHECK, int N>
 __device__ __forceinline__ double pair_sq(const double (&S)[N], int64_t g0, int64_t nb) {
     static_assert(N >= OWN + 1, "needs the first bin of the next owner");
-    double a = 0.0;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < OWN; ++k) {
         double d = S[k + 1] - S[k];
         if (CHECK) d = (g0 + k + 1 < nb) ? d : 0.0;
-        a = __builtin_fma(d, d, a);
+        a[k & 3] = __builtin_fma(d, d, a[k & 3]);
     }
-    return a;
+    return (a[0] + a[1]) + (a[2] + a[3]);
 }
 
 // One WAVEFRONT owns a chunk.  It loads the chunk coalesced (lane l takes entries q*64 + l), drops it into its
@@ -48,24 +50,31 @@ __device__ __forceinline__ double pair_sq(const double (&S)[N], int64_t g0, int6
 // No __syncthreads anywhere (wavefronts never share data), no prefix sums.  LDS bank behaviour of the lane-strided
 // reads: 63 (odd) and 42 (16-byte reads, 20-bank stride) are conflict free; 40 is read with 16-byte accesses, which
 // halves its 4-way conflict.  Eight wavefronts per CU keep ~160 KB of loads in flight per CU.
-template <bool CHECK>
-__device__ __forceinline__ void chunk_passes(const double* __restrict__ w, int lane, int64_t c, const AllanLevel& lv,
-                                             double shift, double* __restrict__ out_series, double (&acc)[9]) {
+// RAW: the stage holds the entries as they are in memory (an LDS-DMA put them there) and the chunk's origin `shift` is
+// subtracted as they are read; otherwise the stage was filled with shifted entries.  Same values either way.
+template <bool CHECK, bool RAW = false>
+__device__ __forceinline__ void pass_a(const double* __restrict__ w, int lane, int64_t c, const AllanLevel& lv, double shift,
+                                       double* __restrict__ out_series, double (&acc)[9]) {
+    const double sh = RAW ? shift : 0.0;
     if (lane < 63) {                                            // ---- pass A
         const double2* p = reinterpret_cast<const double2*>(w + 40 * lane);
         double e[48];
 #pragma unroll
-        for (int q = 0; q < 24; ++q) { const double2 t = p[q]; e[2 * q] = t.x; e[2 * q + 1] = t.y; }
+        for (int q = 0; q < 24; ++q) {
+            const double2 t = p[q];
+            e[2 * q] = RAW ? t.x - sh : t.x;
+            e[2 * q + 1] = RAW ? t.y - sh : t.y;
+        }
         {
-            double a = 0.0;
+            double a[4] = {0.0, 0.0, 0.0, 0.0};
             const int64_t g0 = c * kChunk + 40 * lane;
 #pragma unroll
             for (int q = 0; q < 40; ++q) {
                 double d = e[q + 1] - e[q];
                 if (CHECK) d = (g0 + q + 1 < lv.nb[0]) ? d : 0.0;
-                a = __builtin_fma(d, d, a);
+                a[q & 3] = __builtin_fma(d, d, a[q & 3]);
             }
-            acc[0] += a;
+            acc[0] += (a[0] + a[1]) + (a[2] + a[3]);
         }
         double s2[24], s4[12], s8[6], s5[9];
 #pragma unroll
@@ -87,13 +96,19 @@ __device__ __forceinline__ void chunk_passes(const double* __restrict__ w, int l
                 if (!CHECK || g + k < lv.n_out) out_series[g + k] = __builtin_fma(10.0, shift, s5[2 * k] + s5[2 * k + 1]);
         }
     }
+}
+
+template <bool CHECK, bool RAW = false>
+__device__ __forceinline__ void pass_bc(const double* __restrict__ w, int lane, int64_t c, const AllanLevel& lv, double shift,
+                                        double (&acc)[9]) {
+    const double sh = RAW ? shift : 0.0;
     if (lane < 40) {                                            // ---- pass B
         const double* p = w + 63 * lane;
         double s3[24], s7[10];
         {
             double e[72];
 #pragma unroll
-            for (int q = 0; q < 72; ++q) e[q] = p[q];
+            for (int q = 0; q < 72; ++q) e[q] = RAW ? p[q] - sh : p[q];
 #pragma unroll
             for (int k = 0; k < 24; ++k) s3[k] = (e[3 * k] + e[3 * k + 1]) + e[3 * k + 2];
 #pragma unroll
@@ -112,11 +127,33 @@ __device__ __forceinline__ void chunk_passes(const double* __restrict__ w, int l
         double s6[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const double2 t0 = p[3 * k], t1 = p[3 * k + 1], t2 = p[3 * k + 2];
+            double2 t0 = p[3 * k], t1 = p[3 * k + 1], t2 = p[3 * k + 2];
+            if (RAW) { t0.x -= sh; t0.y -= sh; t1.x -= sh; t1.y -= sh; t2.x -= sh; t2.y -= sh; }
             s6[k] = ((t0.x + t0.y) + (t1.x + t1.y)) + (t2.x + t2.y);
         }
         acc[5] += pair_sq<7, CHECK>(s6, c * (kChunk / 6) + 7 * lane, lv.nb[5]);
     }
+}
+
+template <bool CHECK, bool RAW = false>
+__device__ __forceinline__ void chunk_passes(const double* __restrict__ w, int lane, int64_t c, const AllanLevel& lv,
+                                             double shift, double* __restrict__ out_series, double (&acc)[9]) {
+    pass_a<CHECK, RAW>(w, lane, c, lv, shift, out_series, acc);
+    pass_bc<CHECK, RAW>(w, lane, c, lv, shift, acc);
+}
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// interior chunk: the pair (last bin of this chunk, first bin of the next) exists for every factor
+__device__ __forceinline__ bool chunk_is_interior(int64_t c, const AllanLevel& lv) {
+    bool interior = lv.n_out == 0 || (c + 1) * (kChunk / 10) <= lv.n_out;
+#pragma unroll
+    for (int j = 1; j <= 9; ++j) interior = interior && ((c + 1) * (kChunk / j) + 1 <= lv.nb[j - 1]);
+    return interior;
 }
 
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
@@ -177,6 +214,100 @@ allan_level_kernel(const double* __restrict__ in, double* __restrict__ out, doub
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
         if (lane == 0) partial[(s * nparts + part) * 9 + j] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same level pass with the chunk brought in by LDS-DMA (global_load_lds_dwordx4: memory -> LDS without passing
+// through registers) into one of TWO stages per workgroup, so that chunk c+1 is in flight while the passes run on chunk c.
+// A plain streaming read reaches 7.0-7.5 TB/s on MI355X (tools/rbench.hip), also double-buffered through LDS-DMA with four
+// requesting wavefronts per CU; the register-staged kernel above gets 4.6-4.9 TB/s out of eight because each wavefront
+// alternates between waiting for its loads and computing.  The entries land unshifted; the passes subtract the chunk's
+// origin as they read (RAW).  Chunks that do not lie wholly inside the series (the last one or two) are staged through
+// registers, unshifted as well, with the origin beyond the end.
+constexpr int kDmaPieces = 20;                      // 20 x 1 KiB (64 lanes x 16 B) >= kStage entries
+constexpr int kDmaStage = kDmaPieces * 128;         // 2560 doubles
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* global_void_ptr;
+
+// A PAIR of wavefronts per workgroup shares the two stages and splits the work on a staged chunk by PASS, not by data:
+// wavefront 0 runs pass A (factors 1, 2, 4, 8, 5 and the sums of 10), wavefront 1 passes B and C (3, 9, 7, 6) -- about
+// the same number of instructions -- and each requests half of the next chunk.  Four workgroups per CU = two wavefronts per
+// SIMD (a lone wavefront per SIMD exposes its own fp64 and LDS latencies: one wavefront doing all three passes took 3.05 us
+// per chunk with nothing else running), one workgroup barrier per chunk.  An LDS-DMA is ordered for a reader by the issuing
+// wavefront's vmcnt followed by a barrier the reader has passed.
+__device__ __forceinline__ void dma_request_half(const double* __restrict__ chunk, double* __restrict__ dst, int wave, int lane) {
+#pragma unroll
+    for (int q = 0; q < kDmaPieces / 2; ++q) {
+        const int piece = wave * (kDmaPieces / 2) + q;
+        __builtin_amdgcn_global_load_lds((global_void_ptr)(chunk + piece * 128 + 2 * lane), (lds_void_ptr)(dst + piece * 128), 16, 0, 2 /* nt */);
+    }
+}
+
+// a chunk the DMA cannot take, half per wavefront: unshifted, `shift` beyond the end (RAW passes subtract it again)
+__device__ __forceinline__ void stage_ragged_half(const double* __restrict__ x, double* __restrict__ w, int wave, int lane, int64_t c,
+                                                  int64_t n_in, double shift) {
+    const int64_t base = c * kChunk;
+#pragma unroll 1
+    for (int q0 = 0; q0 < kLoads / 2; q0 += 10) {
+        double v[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            const int64_t g = base + (wave * (kLoads / 2) + q0 + q) * 64 + lane;
+            v[q] = x[g < n_in ? g : n_in - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            const int i = (wave * (kLoads / 2) + q0 + q) * 64 + lane;
+            w[i] = (base + i < n_in) ? v[q] : shift;
+        }
+    }
+}
+
+__device__ __forceinline__ void block_sync_after_dma() {       // my DMA pieces have landed; then everybody's have
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ void __launch_bounds__(128, 2)
+allan_pair_kernel(const double* __restrict__ in, double* __restrict__ out, double* __restrict__ partial, const AllanLevel lv) {
+    __shared__ __attribute__((aligned(1024))) double stage[2][kDmaStage];       // 40 960 B: four workgroups per CU
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t s = blockIdx.y, part = blockIdx.x, nparts = gridDim.x;
+    const double* x = in + s * lv.in_stride;
+    double* out_series = lv.n_out > 0 ? out + s * lv.out_stride : nullptr;
+    const int64_t c_begin = part * lv.chunks_per_block;
+    int64_t c_end = c_begin + lv.chunks_per_block;
+    if (c_end > lv.nchunks) c_end = lv.nchunks;
+    const int64_t c_dma = (lv.n_in - kDmaStage) / kChunk;       // chunks 0 .. c_dma lie wholly inside the series
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (c_begin < c_end && c_begin <= c_dma) dma_request_half(x + c_begin * kChunk, stage[0], wave, lane);
+#pragma unroll 1
+    for (int64_t c = c_begin; c < c_end; ++c) {
+        double* w = stage[(c - c_begin) & 1];
+        if (c > c_dma) stage_ragged_half(x, w, wave, lane, c, lv.n_in, x[c * kChunk]);
+        block_sync_after_dma();                                 // chunk c is in its stage, for both wavefronts
+        // the other stage was last read by the passes of chunk c-1, which both wavefronts completed before that barrier
+        if (c + 1 < c_end && c + 1 <= c_dma) dma_request_half(x + (c + 1) * kChunk, stage[(c + 1 - c_begin) & 1], wave, lane);
+        const double shift = w[0];      // the chunk's origin, from the stage: a load from memory here would expose its latency
+        if (wave == 0) {
+            if (chunk_is_interior(c, lv)) pass_a<false, true>(w, lane, c, lv, shift, out_series, acc);
+            else pass_a<true, true>(w, lane, c, lv, shift, out_series, acc);
+        } else {
+            if (chunk_is_interior(c, lv)) pass_bc<false, true>(w, lane, c, lv, shift, acc);
+            else pass_bc<true, true>(w, lane, c, lv, shift, acc);
+        }
+    }
+    // wavefront 0 owns the factors of pass A (j = 1, 2, 4, 5, 8 -> records 0, 1, 3, 4, 7), wavefront 1 those of passes B and C
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const bool mine = (j == 0 || j == 1 || j == 3 || j == 4 || j == 7) == (wave == 0);
+        double a = acc[j];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+        if (lane == 0 && mine) partial[(s * nparts + part) * 9 + j] = a;
     }
 }
 
@@ -261,6 +392,18 @@ int allan_parts(const AllanLevel& lv) {
 hipError_t launch_allan_level(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries, hipStream_t st) {
     hipLaunchKernelGGL(allan_level_kernel, dim3((unsigned)(allan_parts(lv) / kWavesPerBlock), (unsigned)nseries),
                        dim3(64 * kWavesPerBlock), 0, st, in, out, partial, lv);
+    return hipGetLastError();
+}
+
+bool allan_dma_applies(const double* in, const AllanLevel& lv) {
+    static const int forced = [] { const char* e = getenv("GINSIM_ALLAN_DMA"); return e ? atoi(e) : 1; }();
+    return forced != 0 && ((uintptr_t)in % 16) == 0 && (lv.in_stride % 2) == 0 && lv.n_in >= kDmaStage;
+}
+// partial records per series: one per workgroup
+int allan_pair_parts(const AllanLevel& lv) { return (lv.nchunks + lv.chunks_per_block - 1) / lv.chunks_per_block; }
+
+hipError_t launch_allan_pair(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries, hipStream_t st) {
+    hipLaunchKernelGGL(allan_pair_kernel, dim3((unsigned)allan_pair_parts(lv), (unsigned)nseries), dim3(128), 0, st, in, out, partial, lv);
     return hipGetLastError();
 }
 

@@ -35,6 +35,9 @@ int allan_chunks(int64_t n_in);
 int allan_chunks_per_block(int64_t total_chunks);
 int allan_parts(const AllanLevel& lv);
 hipError_t launch_allan_level(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries, hipStream_t st);
+bool allan_dma_applies(const double* in, const AllanLevel& lv);
+int allan_pair_parts(const AllanLevel& lv);
+hipError_t launch_allan_pair(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries, hipStream_t st);
 hipError_t launch_allan_fold(const double* partial, double* sums, const AllanFold& f, int64_t nseries, hipStream_t st);
 hipError_t launch_allan_tail(const double* in, double* sums, const AllanTail& t, hipStream_t st);
 

@@ -518,12 +518,15 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
     HIP_TRY(hipSetDevice(c->device));
     const int levels = decades;
     const int64_t n1 = n / 10;
-    // levels of more than one chunk: one launch each, per-wavefront partial sums, ONE fold launch at the end;
-    // levels of at most one chunk (the last three or four): one launch for all of them
+    // levels of more than one chunk: per-wavefront / per-workgroup partial sums, ONE fold launch at the end; levels of at
+    // most one chunk (the last three or four): one launch for all of them.  Where the level's rows are 16-byte aligned the
+    // LDS-DMA wave-pair kernel takes the level, otherwise the register-staged one.
     std::vector<AllanLevel> lvs(levels);
     AllanFold fold;
     fold.nlevels = 0;
     int64_t records = 0;
+    struct Step { int k; int mode; };      // mode 0: allan_level_kernel, 1: wave-pair LDS-DMA kernel
+    std::vector<Step> steps;
     {
         int64_t n_in = n, stride_in = series_stride, pow10 = 1;
         for (int k = 0; k < levels; ++k) {
@@ -535,17 +538,31 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
             for (int j = 1; j <= 9; ++j) lv.nb[j - 1] = (j * pow10 <= mmax) ? n / (j * pow10) : 0;
             lv.nchunks = allan_chunks(n_in);
             lv.chunks_per_block = allan_chunks_per_block((int64_t)lv.nchunks * nseries);
-            if (n_in > allan_chunk_entries()) {
-                REQUIRE(k < 8, "allan: series too long");
-                fold.nparts[k] = allan_parts(lv);
-                fold.offset[k] = records;
-                records += (int64_t)fold.nparts[k] * nseries;
-                fold.nlevels = k + 1;
-            }
             stride_in = lv.n_out;
             n_in = lv.n_out;
             pow10 *= 10;
         }
+        int k = 0;
+        while (k < levels && lvs[k].n_in > allan_chunk_entries()) {
+            REQUIRE(k < 8, "allan: series too long");
+            AllanLevel& lv = lvs[k];
+            // intermediate levels live in this call's scratch region, whose rows start 256-byte aligned
+            const bool dma = allan_dma_applies(k == 0 ? x : reinterpret_cast<const double*>(uintptr_t(256)), lv);
+            int parts;
+            if (dma) {      // four workgroups per CU: ~1024 in flight; up to 8 chunks each so that the first, exposed load is amortised
+                const int64_t per = ((int64_t)lv.nchunks * nseries) / 4096;
+                lv.chunks_per_block = (int32_t)(per < 1 ? 1 : (per > 8 ? 8 : per));
+                parts = allan_pair_parts(lv);
+            } else {
+                parts = allan_parts(lv);
+            }
+            fold.nparts[k] = parts;
+            fold.offset[k] = records;
+            records += (int64_t)parts * nseries;
+            steps.push_back(Step{k, dma ? 1 : 0});
+            ++k;
+        }
+        fold.nlevels = k;
     }
     REQUIRE(levels - fold.nlevels <= 4, "allan: internal level plan");
     struct Region { void* p; double* d() const { return reinterpret_cast<double*>(p); } } ping, pong, partial, sums;
@@ -558,9 +575,15 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
     partial.p = reinterpret_cast<char*>(pong.p) + ((b_pong + 255) & ~(size_t)255);
     sums.p = reinterpret_cast<char*>(partial.p) + ((b_part + 255) & ~(size_t)255);
     const double* in = x;
-    for (int k = 0; k < fold.nlevels; ++k) {
-        double* out = (k % 2 == 0) ? ping.d() : pong.d();
-        HIP_TRY(launch_allan_level(in, out, partial.d() + 9 * fold.offset[k], lvs[k], nseries, c->stream));
+    int flip = 0;
+    for (const Step& st : steps) {
+        // level k+1 (<= n/10 entries per series) goes to ping, k+2 to pong, ...
+        double* out = (flip++ % 2 == 0) ? ping.d() : pong.d();
+        const int k = st.k;
+        if (st.mode == 1)
+            HIP_TRY(launch_allan_pair(in, out, partial.d() + 9 * fold.offset[k], lvs[k], nseries, c->stream));
+        else
+            HIP_TRY(launch_allan_level(in, out, partial.d() + 9 * fold.offset[k], lvs[k], nseries, c->stream));
         in = out;
     }
     HIP_TRY(launch_allan_fold(partial.d(), sums.d(), fold, nseries, c->stream));

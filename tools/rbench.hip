@@ -1,0 +1,123 @@
+// Pure-READ bandwidth of MI355X for the Allan level-0 access pattern (development aid): what does a kernel reach that only
+// streams 192 x 1 440 000 doubles through registers?  Variants: 8-byte vs 16-byte loads per lane, loads in flight per
+// wavefront, wavefronts per CU (limited with dummy LDS as the Allan kernel's stages limit them), temporal vs nt.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+
+template <int LOADS, bool NT>
+__global__ void __launch_bounds__(128) read8(const double* __restrict__ x, int64_t n_chunks, int64_t chunk, double* out) {
+    extern __shared__ double dummy[];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    double acc = 0.0;
+    for (int64_t c = wave; c < n_chunks; c += nwaves) {
+        const double* p = x + c * chunk + lane;
+        double v[LOADS];
+#pragma unroll
+        for (int q = 0; q < LOADS; ++q) v[q] = NT ? __builtin_nontemporal_load(p + q * 64) : p[q * 64];
+#pragma unroll
+        for (int q = 0; q < LOADS; ++q) acc += v[q];
+    }
+    if (acc == 1.2345e300) out[0] = acc + dummy[0];
+}
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <int LOADS, bool NT>
+__global__ void __launch_bounds__(128) read16(const v2d* __restrict__ x, int64_t n_chunks, int64_t chunk2, double* out) {
+    extern __shared__ double dummy[];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    double acc = 0.0;
+    for (int64_t c = wave; c < n_chunks; c += nwaves) {
+        const v2d* p = x + c * chunk2 + lane;
+        v2d v[LOADS];
+#pragma unroll
+        for (int q = 0; q < LOADS; ++q) v[q] = NT ? __builtin_nontemporal_load(p + q * 64) : p[q * 64];
+#pragma unroll
+        for (int q = 0; q < LOADS; ++q) acc += v[q].x + v[q].y;
+    }
+    if (acc == 1.2345e300) out[0] = acc + dummy[0];
+}
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* global_void_ptr;
+
+// LDS-DMA double buffering, one wavefront per block (4 per CU): chunk c+1 lands while the lane reads READS doubles of chunk c
+template <int READS>
+__global__ void __launch_bounds__(64) read_dma(const double* __restrict__ x, int64_t n_chunks, int cpw, double* out) {
+    __shared__ __attribute__((aligned(1024))) double st[2][2560];
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * cpw;
+    int64_t c1 = c0 + cpw; if (c1 > n_chunks) c1 = n_chunks;
+    double acc = 0.0;
+    if (c0 < c1)
+#pragma unroll
+        for (int q = 0; q < 20; ++q)
+            __builtin_amdgcn_global_load_lds((global_void_ptr)(x + c0 * 2560 + q * 128 + 2 * lane), (lds_void_ptr)(&st[0][q * 128]), 16, 0, 2);
+    for (int64_t c = c0; c < c1; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (c + 1 < c1)
+#pragma unroll
+            for (int q = 0; q < 20; ++q)
+                __builtin_amdgcn_global_load_lds((global_void_ptr)(x + (c + 1) * 2560 + q * 128 + 2 * lane), (lds_void_ptr)(&st[(c + 1 - c0) & 1][q * 128]), 16, 0, 2);
+        const double* w = st[(c - c0) & 1];
+#pragma unroll
+        for (int i = 0; i < READS; ++i) acc += w[(63 * lane + i) % 2560];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (acc == 1.2345e300) out[0] = acc;
+}
+
+template <typename F> static float timeit(F f, int reps = 7) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int i = 0; i < reps; ++i) {
+        hipEventRecord(a); f(); hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main() {
+    const int64_t total = 192ll * 1440000;              // doubles
+    double *x, *out;
+    hipMalloc(&x, total * 8 + 65536); hipMalloc(&out, 8);
+    {   // incompressible content
+        double* h = (double*)malloc(total * 8 + 65536);
+        uint64_t st = 88172645463325252ull;
+        for (int64_t i = 0; i < total + 8192; ++i) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; h[i] = (double)(st >> 11) * 1.1102230246251565e-16 - 0.5; }
+        hipMemcpy(x, h, total * 8 + 65536, hipMemcpyHostToDevice);
+        free(h);
+    }
+    const double gb = total * 8 / 1e9;
+    for (int wpc : {8, 4}) {                     // wavefronts per CU through a dummy LDS reservation per 2-wave block
+        const size_t lds = wpc >= 16 ? 0 : (size_t)(160 * 1024 / (wpc / 2)) - 512;
+        for (int blocks : {4096, 65536}) {
+            const int64_t chunk = 2560, n_chunks = total / chunk;
+            float ms = timeit([&] { hipLaunchKernelGGL((read8<40, true>), dim3(blocks), dim3(128), lds, 0, x, n_chunks, chunk, out); });
+            printf("waves/CU<=%2d blocks %6d  8B x40 nt : %.3f ms %.0f GB/s", wpc, blocks, ms, gb / ms * 1e3);
+            ms = timeit([&] { hipLaunchKernelGGL((read8<40, false>), dim3(blocks), dim3(128), lds, 0, x, n_chunks, chunk, out); });
+            printf(" | 8B x40 : %.3f ms %.0f GB/s", ms, gb / ms * 1e3);
+            ms = timeit([&] { hipLaunchKernelGGL((read16<20, true>), dim3(blocks), dim3(128), lds, 0, (const v2d*)x, n_chunks, chunk / 2, out); });
+            printf(" | 16B x20 nt : %.3f ms %.0f GB/s", ms, gb / ms * 1e3);
+            ms = timeit([&] { hipLaunchKernelGGL((read16<40, true>), dim3(blocks), dim3(128), lds, 0, (const v2d*)x, n_chunks / 2, chunk, out); });
+            printf(" | 16B x40 nt : %.3f ms %.0f GB/s\n", ms, gb / ms * 1e3);
+        }
+    }
+    for (int cpw : {4, 16, 64}) {
+        const int64_t n_chunks = total / 2560;
+        const int blocks = (int)((n_chunks + cpw - 1) / cpw);
+        float ms = timeit([&] { hipLaunchKernelGGL((read_dma<8>), dim3(blocks), dim3(64), 0, 0, x, n_chunks, cpw, out); });
+        printf("LDS-DMA 2 stages, 1 wave/block, cpw %2d:   8 LDS reads/lane: %.3f ms %.0f GB/s", cpw, ms, gb / ms * 1e3);
+        ms = timeit([&] { hipLaunchKernelGGL((read_dma<64>), dim3(blocks), dim3(64), 0, 0, x, n_chunks, cpw, out); });
+        printf(" |  64: %.3f ms %.0f GB/s", ms, gb / ms * 1e3);
+        ms = timeit([&] { hipLaunchKernelGGL((read_dma<168>), dim3(blocks), dim3(64), 0, 0, x, n_chunks, cpw, out); });
+        printf(" | 168: %.3f ms %.0f GB/s\n", ms, gb / ms * 1e3);
+    }
+    return 0;
+}
