@@ -52,19 +52,31 @@ __device__ __forceinline__ double pair_sq(const double (&S)[N], int64_t g0, int6
 // halves its 4-way conflict.  Eight wavefronts per CU keep ~160 KB of loads in flight per CU.
 // RAW: the stage holds the entries as they are in memory (an LDS-DMA put them there) and the chunk's origin `shift` is
 // subtracted as they are read; otherwise the stage was filled with shifted entries.  Same values either way.
-template <bool CHECK, bool RAW = false>
-__device__ __forceinline__ void pass_a(const double* __restrict__ w, int lane, int64_t c, const AllanLevel& lv, double shift,
-                                       double* __restrict__ out_series, double (&acc)[9]) {
-    const double sh = RAW ? shift : 0.0;
-    if (lane < 63) {                                            // ---- pass A
-        const double2* p = reinterpret_cast<const double2*>(w + 40 * lane);
-        double e[48];
+// Every pass is "read my segment of the stage into registers" followed by arithmetic on registers only; the wave-pair
+// kernel puts a workgroup barrier between the two so that the stage can be refilled while the arithmetic runs.
+__device__ __forceinline__ void read_a(const double* __restrict__ w, int lane, double (&e)[48]) {
+    const double2* p = reinterpret_cast<const double2*>(w + 40 * (lane < 63 ? lane : 62));
 #pragma unroll
-        for (int q = 0; q < 24; ++q) {
-            const double2 t = p[q];
-            e[2 * q] = RAW ? t.x - sh : t.x;
-            e[2 * q + 1] = RAW ? t.y - sh : t.y;
+    for (int q = 0; q < 24; ++q) {
+        const double2 t = p[q];
+        e[2 * q] = t.x;
+        e[2 * q + 1] = t.y;
+    }
+}
+
+// `between(q)`, q = 0..9, is called at ten points spread over the arithmetic (the wave-pair kernel issues one LDS-DMA piece
+// at each: ten in a row queue up behind the other wavefronts' pieces at the CU's address unit and the wavefront stands still)
+struct NothingBetween { __device__ __forceinline__ void operator()(int) const {} };
+
+template <bool CHECK, bool RAW, class Between = NothingBetween>
+__device__ __forceinline__ void compute_a(double (&e)[48], int lane, int64_t c, const AllanLevel& lv, double shift,
+                                          double* __restrict__ out_series, double (&acc)[9], const Between& between = Between()) {
+    {
+        if (RAW) {
+#pragma unroll
+            for (int q = 0; q < 48; ++q) e[q] -= shift;
         }
+        between(0);
         {
             double a[4] = {0.0, 0.0, 0.0, 0.0};
             const int64_t g0 = c * kChunk + 40 * lane;
@@ -73,23 +85,38 @@ __device__ __forceinline__ void pass_a(const double* __restrict__ w, int lane, i
                 double d = e[q + 1] - e[q];
                 if (CHECK) d = (g0 + q + 1 < lv.nb[0]) ? d : 0.0;
                 a[q & 3] = __builtin_fma(d, d, a[q & 3]);
+                if (q == 12) between(1);
+                if (q == 25) between(2);
             }
-            acc[0] += (a[0] + a[1]) + (a[2] + a[3]);
+            acc[0] += lane < 63 ? (a[0] + a[1]) + (a[2] + a[3]) : 0.0;
         }
+        between(3);
+        // order: the entries die after the bins of 2 and of 5, the bins of 2 after those of 4, ...
         double s2[24], s4[12], s8[6], s5[9];
+        const bool mine = lane < 63;
 #pragma unroll
         for (int k = 0; k < 24; ++k) s2[k] = e[2 * k] + e[2 * k + 1];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) s4[k] = s2[2 * k] + s2[2 * k + 1];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s8[k] = s4[2 * k] + s4[2 * k + 1];
+        between(4);
 #pragma unroll
         for (int k = 0; k < 9; ++k) s5[k] = (s2[(5 * k) / 2 + (k & 1)] + s2[(5 * k) / 2 + 1 + (k & 1)]) + e[(k & 1) ? 5 * k : 5 * k + 4];
-        acc[1] += pair_sq<20, CHECK>(s2, c * (kChunk / 2) + 20 * lane, lv.nb[1]);
-        acc[3] += pair_sq<10, CHECK>(s4, c * (kChunk / 4) + 10 * lane, lv.nb[3]);
-        acc[7] += pair_sq<5, CHECK>(s8, c * (kChunk / 8) + 5 * lane, lv.nb[7]);
-        acc[4] += pair_sq<8, CHECK>(s5, c * (kChunk / 5) + 8 * lane, lv.nb[4]);
-        if (out_series) {                                       // level k+1: sums of 10, unshifted
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s4[k] = s2[2 * k] + s2[2 * k + 1];
+        between(5);
+        const double r1 = pair_sq<20, CHECK>(s2, c * (kChunk / 2) + 20 * lane, lv.nb[1]);
+        acc[1] += mine ? r1 : 0.0;
+        between(6);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s8[k] = s4[2 * k] + s4[2 * k + 1];
+        const double r3 = pair_sq<10, CHECK>(s4, c * (kChunk / 4) + 10 * lane, lv.nb[3]);
+        acc[3] += mine ? r3 : 0.0;
+        between(7);
+        const double r7 = pair_sq<5, CHECK>(s8, c * (kChunk / 8) + 5 * lane, lv.nb[7]);
+        acc[7] += mine ? r7 : 0.0;
+        between(8);
+        const double r4 = pair_sq<8, CHECK>(s5, c * (kChunk / 5) + 8 * lane, lv.nb[4]);
+        acc[4] += mine ? r4 : 0.0;
+        between(9);
+        if (lane < 63 && out_series) {                                       // level k+1: sums of 10, unshifted
             const int64_t g = c * (kChunk / 10) + 4 * lane;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -99,29 +126,100 @@ __device__ __forceinline__ void pass_a(const double* __restrict__ w, int lane, i
 }
 
 template <bool CHECK, bool RAW = false>
+__device__ __forceinline__ void pass_a(const double* __restrict__ w, int lane, int64_t c, const AllanLevel& lv, double shift,
+                                       double* __restrict__ out_series, double (&acc)[9]) {
+    double e[48];
+    read_a(w, lane, e);
+    compute_a<CHECK, RAW>(e, lane, c, lv, shift, out_series, acc);
+}
+
+__device__ __forceinline__ void read_b(const double* __restrict__ w, int lane, double (&e)[72]) {
+    const double* p = w + 63 * (lane < 40 ? lane : 39);
+#pragma unroll
+    for (int q = 0; q < 72; ++q) e[q] = p[q];
+}
+
+// The same as 72 separate ds_read_b64: the compiler pairs 8-byte LDS reads into ds_read2_b64, which the LDS serves as two
+// accesses of 4 x 16 lanes (8 cycles), while a lone ds_read_b64 goes in 2 x 32 lanes (2 cycles) -- and a 63-entry lane
+// stride is conflict free either way.  The results are not tracked by the compiler: the caller waits (lgkmcnt) before use.
+__device__ __forceinline__ void read_b_single(const double* __restrict__ w, int lane, double (&e)[72]) {
+    const unsigned a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) double*)(w + 63 * (lane < 40 ? lane : 39));
+#pragma unroll
+    for (int q = 0; q < 72; ++q) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(e[q]) : "v"(a), "n"(8 * q));
+}
+
+// SIX: factor 6 from the same registers.  63 l is 0 or 3 modulo 6, so an even lane holds the bins of 6 that start at its
+// entries 0, 6, .., 66 (it owns the 11 pairs that begin in its 63 entries) and an odd lane those at 3, 9, .., 63 (10 pairs);
+// both are sums of two adjacent bins of 3.
+template <bool CHECK, bool RAW, bool SIX, class Between = NothingBetween>
+__device__ __forceinline__ void compute_b(double (&e)[72], int lane, int64_t c, const AllanLevel& lv, double shift, double (&acc)[9],
+                                          const Between& between = Between()) {
+    // every lane does the arithmetic (lanes >= 40 on a copy of lane 39's entries): `between` must run with all lanes on
+    if (RAW) {
+#pragma unroll
+        for (int q = 0; q < 72; ++q) e[q] -= shift;
+    }
+    between(0);
+    double s3[24], s7[10], s9[8];
+    // in blocks of 21 = lcm(3, 7) entries, so that the entries die as the bins of 3 and of 7 appear
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+#pragma unroll
+        for (int k = 7 * b; k < 7 * b + 7; ++k) s3[k] = (e[3 * k] + e[3 * k + 1]) + e[3 * k + 2];
+#pragma unroll
+        for (int k = 3 * b; k < 3 * b + 3; ++k)
+            s7[k] = ((e[7 * k] + e[7 * k + 1]) + (e[7 * k + 2] + e[7 * k + 3])) + ((e[7 * k + 4] + e[7 * k + 5]) + e[7 * k + 6]);
+        between(1 + b);
+    }
+#pragma unroll
+    for (int k = 21; k < 24; ++k) s3[k] = (e[3 * k] + e[3 * k + 1]) + e[3 * k + 2];
+    s7[9] = ((e[63] + e[64]) + (e[65] + e[66])) + ((e[67] + e[68]) + e[69]);
+    between(4);
+    const bool mine = lane < 40;
+    // order: the bins of 7 and of 9 die first; the bins of 3 also make those of 6
+    const double r6 = pair_sq<9, CHECK>(s7, c * (kChunk / 7) + 9 * lane, lv.nb[6]);
+    acc[6] += mine ? r6 : 0.0;
+    between(5);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s9[k] = (s3[3 * k] + s3[3 * k + 1]) + s3[3 * k + 2];
+    const double r8 = pair_sq<7, CHECK>(s9, c * (kChunk / 9) + 7 * lane, lv.nb[8]);
+    acc[8] += mine ? r8 : 0.0;
+    between(6);
+    const double r2 = pair_sq<21, CHECK>(s3, c * (kChunk / 3) + 21 * lane, lv.nb[2]);
+    acc[2] += mine ? r2 : 0.0;
+    between(7);
+    if (SIX) {
+        const bool odd = (lane & 1) != 0;
+        const int64_t g0 = c * (kChunk / 6) + 21 * (lane >> 1) + (odd ? 11 : 0);
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        double prev = s3[1] + (odd ? s3[2] : s3[0]);       // bin m of 6: bins 2m, 2m+1 of 3 (even lane) or 2m+1, 2m+2 (odd lane)
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const double next = s3[2 * k + 3] + ((k < 10 && odd) ? s3[k < 10 ? 2 * k + 4 : 0] : s3[2 * k + 2]);
+            double d = next - prev;
+            prev = next;
+            bool own = k < 10 || !odd;
+            if (CHECK) own = own && (g0 + k + 1 < lv.nb[5]);
+            if (CHECK || k == 10) d = own ? d : 0.0;
+            a[k & 3] = __builtin_fma(d, d, a[k & 3]);
+            if (k == 5) between(8);
+        }
+        acc[5] += mine ? (a[0] + a[1]) + (a[2] + a[3]) : 0.0;
+    } else {
+        between(8);
+    }
+    between(9);
+}
+
+template <bool CHECK, bool RAW = false>
 __device__ __forceinline__ void pass_bc(const double* __restrict__ w, int lane, int64_t c, const AllanLevel& lv, double shift,
                                         double (&acc)[9]) {
-    const double sh = RAW ? shift : 0.0;
-    if (lane < 40) {                                            // ---- pass B
-        const double* p = w + 63 * lane;
-        double s3[24], s7[10];
-        {
-            double e[72];
-#pragma unroll
-            for (int q = 0; q < 72; ++q) e[q] = RAW ? p[q] - sh : p[q];
-#pragma unroll
-            for (int k = 0; k < 24; ++k) s3[k] = (e[3 * k] + e[3 * k + 1]) + e[3 * k + 2];
-#pragma unroll
-            for (int k = 0; k < 10; ++k)
-                s7[k] = ((e[7 * k] + e[7 * k + 1]) + (e[7 * k + 2] + e[7 * k + 3])) + ((e[7 * k + 4] + e[7 * k + 5]) + e[7 * k + 6]);
-        }
-        double s9[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s9[k] = (s3[3 * k] + s3[3 * k + 1]) + s3[3 * k + 2];
-        acc[2] += pair_sq<21, CHECK>(s3, c * (kChunk / 3) + 21 * lane, lv.nb[2]);
-        acc[8] += pair_sq<7, CHECK>(s9, c * (kChunk / 9) + 7 * lane, lv.nb[8]);
-        acc[6] += pair_sq<9, CHECK>(s7, c * (kChunk / 7) + 9 * lane, lv.nb[6]);
+    {                                                           // ---- pass B
+        double e[72];
+        read_b(w, lane, e);
+        compute_b<CHECK, RAW, false>(e, lane, c, lv, shift, acc);
     }
+    const double sh = RAW ? shift : 0.0;
     if (lane < 60) {                                            // ---- pass C
         const double2* p = reinterpret_cast<const double2*>(w + 42 * lane);
         double s6[8];
@@ -231,18 +329,44 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* global_void_ptr;
 
 // A PAIR of wavefronts per workgroup shares the two stages and splits the work on a staged chunk by PASS, not by data:
-// wavefront 0 runs pass A (factors 1, 2, 4, 8, 5 and the sums of 10), wavefront 1 passes B and C (3, 9, 7, 6) -- about
-// the same number of instructions -- and each requests half of the next chunk.  Four workgroups per CU = two wavefronts per
-// SIMD (a lone wavefront per SIMD exposes its own fp64 and LDS latencies: one wavefront doing all three passes took 3.05 us
-// per chunk with nothing else running), one workgroup barrier per chunk.  An LDS-DMA is ordered for a reader by the issuing
-// wavefront's vmcnt followed by a barrier the reader has passed.
+// wavefront 0 takes the 40-entry segmentation (factors 1, 2, 4, 8, 5 and the sums of 10), wavefront 1 the 63-entry one
+// (3, 9, 7 and, from the same registers, 6) -- about the same number of instructions -- and each requests half of every
+// chunk.  Four workgroups per CU = two wavefronts per SIMD.  Per chunk c, in stage c mod 2:
+//     wait until my pieces of chunk c have landed; barrier            (chunk c is complete for both wavefronts)
+//     read my segment of the stage into registers; barrier            (nobody needs the stage any more)
+//     request chunk c+2 into this stage                               (chunk c+1 is still in flight to the other one)
+//     arithmetic on registers
+// so a request has the arithmetic of two chunks to land in, and up to 40 KB per workgroup are in flight.  (Requesting
+// chunk c+1 only once the arithmetic on c-1 is over -- one request in flight -- ran at the latency of the request:
+// 4.3 us per chunk, of which the arithmetic was 2 us.)  An LDS-DMA is ordered for a reader by the issuing wavefront's
+// vmcnt followed by a barrier the reader has passed; vector memory operations of one wavefront complete in order, so
+// "all but the youngest K" is exact when K counts what was issued after the request: the next request (10 pieces) and the
+// stores of the sums of 10.  A K that is too small only waits longer.
 __device__ __forceinline__ void dma_request_half(const double* __restrict__ chunk, double* __restrict__ dst, int wave, int lane) {
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int q = 0; q < kDmaPieces / 2; ++q) {
         const int piece = wave * (kDmaPieces / 2) + q;
         __builtin_amdgcn_global_load_lds((global_void_ptr)(chunk + piece * 128 + 2 * lane), (lds_void_ptr)(dst + piece * 128), 16, 0, 2 /* nt */);
     }
+    asm volatile("" ::: "memory");
 }
+
+// one piece of my half at a time, pinned where it is called
+struct DmaPieceIssue {
+    const double* chunk;
+    double* dst;
+    int wave, lane;
+    bool on;
+    __device__ __forceinline__ void operator()(int q) const {
+        __builtin_amdgcn_sched_barrier(0);
+        if (on) {
+            const int piece = wave * (kDmaPieces / 2) + q;
+            __builtin_amdgcn_global_load_lds((global_void_ptr)(chunk + piece * 128 + 2 * lane), (lds_void_ptr)(dst + piece * 128), 16, 0, 2 /* nt */);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
 
 // a chunk the DMA cannot take, half per wavefront: unshifted, `shift` beyond the end (RAW passes subtract it again)
 __device__ __forceinline__ void stage_ragged_half(const double* __restrict__ x, double* __restrict__ w, int wave, int lane, int64_t c,
@@ -264,11 +388,26 @@ __device__ __forceinline__ void stage_ragged_half(const double* __restrict__ x, 
     }
 }
 
-__device__ __forceinline__ void block_sync_after_dma() {       // my DMA pieces have landed; then everybody's have
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+// wait until at most `younger` of my vector memory operations are outstanding (s_waitcnt takes an immediate)
+__device__ __forceinline__ void wait_all_but(int younger) {
+    if (younger >= 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if (younger >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if (younger >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my LDS reads / writes are done
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+
+#ifdef ALLAN_TRACE
+__device__ unsigned long long g_trace[64 * 2 * 8];
+#define TRACE(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[slot] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define TRACE(slot) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(128, 2)
 allan_pair_kernel(const double* __restrict__ in, double* __restrict__ out, double* __restrict__ partial, const AllanLevel lv) {
@@ -283,24 +422,86 @@ allan_pair_kernel(const double* __restrict__ in, double* __restrict__ out, doubl
     if (c_end > lv.nchunks) c_end = lv.nchunks;
     const int64_t c_dma = (lv.n_in - kDmaStage) / kChunk;       // chunks 0 .. c_dma lie wholly inside the series
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef ALLAN_TRACE
+    unsigned long long* tr = (s == 100 && part < 64 && gridDim.x > 64) ? g_trace + (part * 2 + wave) * 8 : nullptr;
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tlast;
+#endif
     if (c_begin < c_end && c_begin <= c_dma) dma_request_half(x + c_begin * kChunk, stage[0], wave, lane);
+    if (c_begin + 1 < c_end && c_begin + 1 <= c_dma) dma_request_half(x + (c_begin + 1) * kChunk, stage[1], wave, lane);
+    int stores1 = 0, stores2 = 0;   // store instructions this wavefront is KNOWN to have issued in the last two iterations
 #pragma unroll 1
     for (int64_t c = c_begin; c < c_end; ++c) {
         double* w = stage[(c - c_begin) & 1];
-        if (c > c_dma) stage_ragged_half(x, w, wave, lane, c, lv.n_in, x[c * kChunk]);
-        block_sync_after_dma();                                 // chunk c is in its stage, for both wavefronts
-        // the other stage was last read by the passes of chunk c-1, which both wavefronts completed before that barrier
-        if (c + 1 < c_end && c + 1 <= c_dma) dma_request_half(x + (c + 1) * kChunk, stage[(c + 1 - c_begin) & 1], wave, lane);
-        const double shift = w[0];      // the chunk's origin, from the stage: a load from memory here would expose its latency
-        if (wave == 0) {
-            if (chunk_is_interior(c, lv)) pass_a<false, true>(w, lane, c, lv, shift, out_series, acc);
-            else pass_a<true, true>(w, lane, c, lv, shift, out_series, acc);
+        TRACE(0);
+        if (c > c_dma) {            // staged through registers; nothing else of mine is in flight
+            stage_ragged_half(x, w, wave, lane, c, lv.n_in, x[c * kChunk]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            if (chunk_is_interior(c, lv)) pass_bc<false, true>(w, lane, c, lv, shift, acc);
-            else pass_bc<true, true>(w, lane, c, lv, shift, acc);
+            wait_all_but(((c + 1 < c_end && c + 1 <= c_dma) ? kDmaPieces / 2 : 0) + stores1 + stores2);
         }
+        TRACE(1);
+        block_barrier();                                        // chunk c is in its stage, for both wavefronts
+        TRACE(2);
+        const bool interior = chunk_is_interior(c, lv);
+        const bool again = c + 2 < c_end && c + 2 <= c_dma;
+        const double shift = w[0];                              // the chunk's origin, from the stage
+        if (!interior) {
+            // the last chunk or two of a series: bounds-checked passes straight from the stage (they keep fewer entries
+            // in registers than the split form, which would not fit next to the 64-bit index compares)
+#ifdef EXP_NOCHECK
+            if (wave == 0) pass_a<false, true>(w, lane, c, lv, shift, out_series, acc);
+            else pass_bc<false, true>(w, lane, c, lv, shift, acc);
+#else
+            if (wave == 0) pass_a<true, true>(w, lane, c, lv, shift, out_series, acc);
+            else pass_bc<true, true>(w, lane, c, lv, shift, acc);
+#endif
+            block_barrier();
+            if (again) dma_request_half(x + (c + 2) * kChunk, w, wave, lane);
+            stores2 = stores1;
+            stores1 = 0;            // not known: the checked stores may be skipped
+        } else if (wave == 0) {
+            double e[48];
+            read_a(w, lane, e);
+            TRACE(3);
+            block_barrier();                                    // both wavefronts hold their segments: the stage is free
+            TRACE(4);
+#if defined(EXP_BURST) || defined(EXP_BURST_A)
+            if (again) dma_request_half(x + (c + 2) * kChunk, w, wave, lane);
+            TRACE(5);
+            compute_a<false, true>(e, lane, c, lv, shift, out_series, acc);
+#else
+            const DmaPieceIssue piece{x + (c + 2) * kChunk, w, wave, lane, again};
+            compute_a<false, true>(e, lane, c, lv, shift, out_series, acc, piece);
+#endif
+            asm volatile("" ::: "memory");
+            stores2 = stores1;
+            stores1 = out_series ? 4 : 0;
+        } else {
+            double e[72];
+#ifdef EXP_READ2
+            read_b(w, lane, e);
+#else
+            read_b_single(w, lane, e);
+#endif
+            TRACE(3);
+            block_barrier();
+            TRACE(4);
+#if defined(EXP_BURST) || defined(EXP_BURST_B)
+            if (again) dma_request_half(x + (c + 2) * kChunk, w, wave, lane);
+            TRACE(5);
+            compute_b<false, true, true>(e, lane, c, lv, shift, acc);
+#else
+            const DmaPieceIssue piece{x + (c + 2) * kChunk, w, wave, lane, again};
+            compute_b<false, true, true>(e, lane, c, lv, shift, acc, piece);
+#endif
+        }
+        TRACE(6);
     }
-    // wavefront 0 owns the factors of pass A (j = 1, 2, 4, 5, 8 -> records 0, 1, 3, 4, 7), wavefront 1 those of passes B and C
+#ifdef ALLAN_TRACE
+    if (tr && lane == 0) { for (int q = 0; q < 7; ++q) tr[q] = tacc[q]; tr[7] = __builtin_amdgcn_s_memtime() - tstart; }
+#endif
+    // wavefront 0 owns the factors of its segmentation (j = 1, 2, 4, 5, 8 -> records 0, 1, 3, 4, 7), wavefront 1 the others
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         const bool mine = (j == 0 || j == 1 || j == 3 || j == 4 || j == 7) == (wave == 0);
@@ -404,6 +605,21 @@ int allan_pair_parts(const AllanLevel& lv) { return (lv.nchunks + lv.chunks_per_
 
 hipError_t launch_allan_pair(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries, hipStream_t st) {
     hipLaunchKernelGGL(allan_pair_kernel, dim3((unsigned)allan_pair_parts(lv), (unsigned)nseries), dim3(128), 0, st, in, out, partial, lv);
+#ifdef ALLAN_TRACE
+    static int calls = 0;
+    if (allan_pair_parts(lv) > 64 && ++calls == 5) {
+        static unsigned long long h[64 * 2 * 8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h));
+        for (int b = 0; b < 64; b += 7)
+            for (int wv = 0; wv < 2; ++wv) {
+                fprintf(stderr, "trace block %d wave %d:", b, wv);
+                const unsigned long long* t = h + (b * 2 + wv) * 8;
+                for (int q = 0; q < 8; ++q) fprintf(stderr, " %lld", (long long)t[q]);
+                fprintf(stderr, "\n");
+            }
+    }
+#endif
     return hipGetLastError();
 }
 

@@ -550,8 +550,9 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
             const bool dma = allan_dma_applies(k == 0 ? x : reinterpret_cast<const double*>(uintptr_t(256)), lv);
             int parts;
             if (dma) {      // four workgroups per CU: ~1024 in flight; up to 8 chunks each so that the first, exposed load is amortised
+                static const int cap = [] { const char* e = getenv("GINSIM_ALLAN_CPB"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
                 const int64_t per = ((int64_t)lv.nchunks * nseries) / 4096;
-                lv.chunks_per_block = (int32_t)(per < 1 ? 1 : (per > 8 ? 8 : per));
+                lv.chunks_per_block = (int32_t)(per < 1 ? 1 : (per > cap ? cap : per));
                 parts = allan_pair_parts(lv);
             } else {
                 parts = allan_parts(lv);
