@@ -323,6 +323,11 @@ allan_level_kernel(const double* __restrict__ in, double* __restrict__ out, doub
 // alternates between waiting for its loads and computing.  The entries land unshifted; the passes subtract the chunk's
 // origin as they read (RAW).  Chunks that do not lie wholly inside the series (the last one or two) are staged through
 // registers, unshifted as well, with the origin beyond the end.
+// Measured on 192 x 1 440 000 (level 0, 2.21 GB): requests only (no arithmetic) 327 us = 6.75 TB/s; arithmetic only 327 us;
+// both 400-460 us depending on the box and the minute (the same binary moves by 12 % between runs).  What the two
+// wavefronts of a workgroup spend per chunk, from s_memtime stamps: reading the segments ~30 %, arithmetic with the
+// requests in between ~50 % (a third of that standing still on the ten requests), barriers and waiting ~20 %.
+// A third wavefront that only requests (168 registers each, the 63-entry segment read in two halves) was slower: 500 us.
 constexpr int kDmaPieces = 20;                      // 20 x 1 KiB (64 lanes x 16 B) >= kStage entries
 constexpr int kDmaStage = kDmaPieces * 128;         // 2560 doubles
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -334,8 +339,8 @@ typedef const __attribute__((address_space(1))) void* global_void_ptr;
 // chunk.  Four workgroups per CU = two wavefronts per SIMD.  Per chunk c, in stage c mod 2:
 //     wait until my pieces of chunk c have landed; barrier            (chunk c is complete for both wavefronts)
 //     read my segment of the stage into registers; barrier            (nobody needs the stage any more)
-//     request chunk c+2 into this stage                               (chunk c+1 is still in flight to the other one)
-//     arithmetic on registers
+//     arithmetic on registers, and in between, piece by piece, the request for chunk c+2 into this stage
+//                                                                     (chunk c+1 is still in flight to the other one)
 // so a request has the arithmetic of two chunks to land in, and up to 40 KB per workgroup are in flight.  (Requesting
 // chunk c+1 only once the arithmetic on c-1 is over -- one request in flight -- ran at the latency of the request:
 // 4.3 us per chunk, of which the arithmetic was 2 us.)  An LDS-DMA is ordered for a reader by the issuing wavefront's
@@ -402,12 +407,6 @@ __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
 }
 
-#ifdef ALLAN_TRACE
-__device__ unsigned long long g_trace[64 * 2 * 8];
-#define TRACE(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[slot] += now_ - tlast; tlast = now_; } while (0)
-#else
-#define TRACE(slot) do { } while (0)
-#endif
 
 __global__ void __launch_bounds__(128, 2)
 allan_pair_kernel(const double* __restrict__ in, double* __restrict__ out, double* __restrict__ partial, const AllanLevel lv) {
@@ -422,40 +421,27 @@ allan_pair_kernel(const double* __restrict__ in, double* __restrict__ out, doubl
     if (c_end > lv.nchunks) c_end = lv.nchunks;
     const int64_t c_dma = (lv.n_in - kDmaStage) / kChunk;       // chunks 0 .. c_dma lie wholly inside the series
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#ifdef ALLAN_TRACE
-    unsigned long long* tr = (s == 100 && part < 64 && gridDim.x > 64) ? g_trace + (part * 2 + wave) * 8 : nullptr;
-    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-    const unsigned long long tstart = tlast;
-#endif
     if (c_begin < c_end && c_begin <= c_dma) dma_request_half(x + c_begin * kChunk, stage[0], wave, lane);
     if (c_begin + 1 < c_end && c_begin + 1 <= c_dma) dma_request_half(x + (c_begin + 1) * kChunk, stage[1], wave, lane);
     int stores1 = 0, stores2 = 0;   // store instructions this wavefront is KNOWN to have issued in the last two iterations
 #pragma unroll 1
     for (int64_t c = c_begin; c < c_end; ++c) {
         double* w = stage[(c - c_begin) & 1];
-        TRACE(0);
         if (c > c_dma) {            // staged through registers; nothing else of mine is in flight
             stage_ragged_half(x, w, wave, lane, c, lv.n_in, x[c * kChunk]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             wait_all_but(((c + 1 < c_end && c + 1 <= c_dma) ? kDmaPieces / 2 : 0) + stores1 + stores2);
         }
-        TRACE(1);
         block_barrier();                                        // chunk c is in its stage, for both wavefronts
-        TRACE(2);
         const bool interior = chunk_is_interior(c, lv);
         const bool again = c + 2 < c_end && c + 2 <= c_dma;
         const double shift = w[0];                              // the chunk's origin, from the stage
         if (!interior) {
             // the last chunk or two of a series: bounds-checked passes straight from the stage (they keep fewer entries
             // in registers than the split form, which would not fit next to the 64-bit index compares)
-#ifdef EXP_NOCHECK
-            if (wave == 0) pass_a<false, true>(w, lane, c, lv, shift, out_series, acc);
-            else pass_bc<false, true>(w, lane, c, lv, shift, acc);
-#else
             if (wave == 0) pass_a<true, true>(w, lane, c, lv, shift, out_series, acc);
             else pass_bc<true, true>(w, lane, c, lv, shift, acc);
-#endif
             block_barrier();
             if (again) dma_request_half(x + (c + 2) * kChunk, w, wave, lane);
             stores2 = stores1;
@@ -463,44 +449,20 @@ allan_pair_kernel(const double* __restrict__ in, double* __restrict__ out, doubl
         } else if (wave == 0) {
             double e[48];
             read_a(w, lane, e);
-            TRACE(3);
             block_barrier();                                    // both wavefronts hold their segments: the stage is free
-            TRACE(4);
-#if defined(EXP_BURST) || defined(EXP_BURST_A)
-            if (again) dma_request_half(x + (c + 2) * kChunk, w, wave, lane);
-            TRACE(5);
-            compute_a<false, true>(e, lane, c, lv, shift, out_series, acc);
-#else
             const DmaPieceIssue piece{x + (c + 2) * kChunk, w, wave, lane, again};
             compute_a<false, true>(e, lane, c, lv, shift, out_series, acc, piece);
-#endif
             asm volatile("" ::: "memory");
             stores2 = stores1;
             stores1 = out_series ? 4 : 0;
         } else {
             double e[72];
-#ifdef EXP_READ2
-            read_b(w, lane, e);
-#else
             read_b_single(w, lane, e);
-#endif
-            TRACE(3);
             block_barrier();
-            TRACE(4);
-#if defined(EXP_BURST) || defined(EXP_BURST_B)
-            if (again) dma_request_half(x + (c + 2) * kChunk, w, wave, lane);
-            TRACE(5);
-            compute_b<false, true, true>(e, lane, c, lv, shift, acc);
-#else
             const DmaPieceIssue piece{x + (c + 2) * kChunk, w, wave, lane, again};
             compute_b<false, true, true>(e, lane, c, lv, shift, acc, piece);
-#endif
         }
-        TRACE(6);
     }
-#ifdef ALLAN_TRACE
-    if (tr && lane == 0) { for (int q = 0; q < 7; ++q) tr[q] = tacc[q]; tr[7] = __builtin_amdgcn_s_memtime() - tstart; }
-#endif
     // wavefront 0 owns the factors of its segmentation (j = 1, 2, 4, 5, 8 -> records 0, 1, 3, 4, 7), wavefront 1 the others
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
@@ -605,21 +567,6 @@ int allan_pair_parts(const AllanLevel& lv) { return (lv.nchunks + lv.chunks_per_
 
 hipError_t launch_allan_pair(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries, hipStream_t st) {
     hipLaunchKernelGGL(allan_pair_kernel, dim3((unsigned)allan_pair_parts(lv), (unsigned)nseries), dim3(128), 0, st, in, out, partial, lv);
-#ifdef ALLAN_TRACE
-    static int calls = 0;
-    if (allan_pair_parts(lv) > 64 && ++calls == 5) {
-        static unsigned long long h[64 * 2 * 8];
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h));
-        for (int b = 0; b < 64; b += 7)
-            for (int wv = 0; wv < 2; ++wv) {
-                fprintf(stderr, "trace block %d wave %d:", b, wv);
-                const unsigned long long* t = h + (b * 2 + wv) * 8;
-                for (int q = 0; q < 8; ++q) fprintf(stderr, " %lld", (long long)t[q]);
-                fprintf(stderr, "\n");
-            }
-    }
-#endif
     return hipGetLastError();
 }
 

@@ -550,9 +550,17 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
             const bool dma = allan_dma_applies(k == 0 ? x : reinterpret_cast<const double*>(uintptr_t(256)), lv);
             int parts;
             if (dma) {      // four workgroups per CU: ~1024 in flight; up to 8 chunks each so that the first, exposed load is amortised
+                // a level that fits ONE round of resident workgroups (1024) with at most 16 chunks each runs as one (a second,
+                // partly filled round costs a whole workgroup time: 144 000 entries x 192 series 62 -> 51 us); longer levels
+                // in runs of 8 chunks
                 static const int cap = [] { const char* e = getenv("GINSIM_ALLAN_CPB"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
-                const int64_t per = ((int64_t)lv.nchunks * nseries) / 4096;
-                lv.chunks_per_block = (int32_t)(per < 1 ? 1 : (per > cap ? cap : per));
+                const int64_t total = (int64_t)lv.nchunks * nseries;
+                const int64_t max_parts = nseries <= 1024 ? 1024 / nseries : 1;         // workgroups per series in one round
+                const int64_t fit = (lv.nchunks + max_parts - 1) / max_parts;
+                const bool single = fit <= 16;
+                const int64_t per = single ? fit : total / 4096;
+                const int64_t lim = single ? 16 : cap;
+                lv.chunks_per_block = (int32_t)(per < 1 ? 1 : (per > lim ? lim : per));
                 parts = allan_pair_parts(lv);
             } else {
                 parts = allan_parts(lv);
