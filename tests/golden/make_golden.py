@@ -319,6 +319,30 @@ def csv_case():
     print('   csv: %d files: %s' % (len(names), ' '.join(names)))
 
 
+def summary_case():
+    """The text Sim.results() prints (Sim.__summary, ins_sim.py:339-413) on the two-run, two-algorithm, rf 0 case of
+    csv_case(), for the three kinds of statistics: end point, process from t = 0 (the reference's default), end point in NED."""
+    import contextlib, io
+    csv = MOTION + 'motion_def-90deg_turn.csv'
+    odo_opt = {'scale': 0.999, 'stdv': 0.1}
+    ini = read_ini(csv)
+    texts = {}
+    for tag, start, opt in (('end', -1, ''), ('process', 0, ''), ('end_ned', -1, 'ned')):
+        imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=True, odo=True, odo_opt=odo_opt)
+        objs = [free_integration.FreeIntegration(ini.copy()), free_integration_odo.FreeIntegration(ini.copy())]
+        sim = ins_sim.Sim([100.0, 10.0, 0.0], csv, ref_frame=0, imu=imu, algorithm=objs)
+        shim = RandnShim(SEED, 1000, imu.accel_err['b_corr'], imu.gyro_err['b_corr'], gps_m=100, mag=False, odo=True)
+        with injected(shim):
+            sim.run(2)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            sim.results(err_stats_start=start, extra_opt=opt)
+        texts[tag] = buf.getvalue()
+    save('summary_text_rf0', seed=SEED, ini=ini, odo_scale=odo_opt['scale'], odo_stdv=odo_opt['stdv'],
+         **{'text_' + k: np.array(v) for k, v in texts.items()})
+    print(texts['end'])
+
+
 # ------------------------------------------------------------------ T4: the UNPATCHED reference, statistics only
 def t4_reference_statistics():
     """SURVEY 8(c) T4.  The reference as shipped -- its own global MT19937 stream, np.random.seed(s) for repeatability --
@@ -394,6 +418,10 @@ def allan_case():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1:           # only the named cases, e.g. `make_golden.py summary_case`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     prof = os.path.join(REPO, 'gnss-ins-sim_amd', 'motion_profiles')
     emit_profile(MOTION + 'motion_def-90deg_turn.csv', prof + '/turn_90deg.csv', '90-degree turn, 10 s')
     emit_profile(MOTION + 'motion_def-long_drive.csv', prof + '/long_drive.csv', 'long drive, <=1410 s')
@@ -417,6 +445,7 @@ if __name__ == '__main__':
     for rf in (0, 1):
         t3_case('t3_mag9_gps_rf%d' % rf, rf, dict(mag9), True, None, ['fi'], 2, fs_gps=10.0, axis=9)
     csv_case()
+    summary_case()
     allan_case()
     t2_long_drive()
     truth_mixed_types()

@@ -176,3 +176,37 @@ def test_logged_data_round_trip(tmp_path, rf):
     # end-point statistics of the re-ingested run == those of the generating run (host computation vs device reduction)
     for name in ('att_euler', 'vel'):
         np.testing.assert_allclose(sim.err_stats[name]['std'], gen.err_stats[name]['std'], rtol=1e-6, atol=1e-10)
+
+
+def test_integration_md_binding_runs_as_written():
+    """INTEGRATION.md section B1 -- the ctypes binding a maintainer of the reference would add -- executed as written
+    (only the library path is made absolute; `demo_algorithms.free_integration` resolves to the drop-in class, whose
+    constructor leaves the same attributes as the reference's, free_integration.py:19-61), on the reference's own
+    bosch fixture: external gravity + a two-column table of initial states, and the hosting contract of run()."""
+    import re
+    import types
+    from conftest import load_golden, assert_traj_close, REPO
+    text = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    block = re.search(r'### B1\..*?```python\n(.*?)```', text, re.S).group(1)
+    lib = os.path.join(PKG, 'lib', 'libginsim.so')
+    assert "'libginsim.so'" in block
+    mod = types.ModuleType('free_integration_hip')
+    exec(compile(block.replace("'libginsim.so'", repr(lib)), 'INTEGRATION.md#B1', 'exec'), mod.__dict__)
+    g = load_golden('t1_fixture_bosch')
+    k = g['rows']
+    for tag, rf, ini, erot in (('extg', 0, g['ini'], False), ('wgs', 0, g['ini'][:9], True), ('rf1', 1, g['ini'][:9], True)):
+        algo = mod.FreeIntegration(ini.copy(), earth_rot=erot)
+        assert algo.input == ['ref_frame', 'fs', 'gyro', 'accel'] and algo.output == ['att_euler', 'pos', 'vel']
+        algo.run([rf, float(g['fs']), g['gyro'].copy(), g['accel'].copy()])
+        att, pos, vel = algo.get_results()
+        assert_traj_close(att[k], pos[k], vel[k], g['att_' + tag], g['pos_' + tag], g['vel_' + tag], rtol=1e-10, what='B1 ' + tag)
+    # two sets of initial states: the second run() uses the second column (free_integration.py:76-88)
+    two = np.stack([g['ini'][:9], g['ini'][:9]], axis=1)
+    two[2, 1] += 100.0
+    algo = mod.FreeIntegration(two)
+    algo.run([1, float(g['fs']), g['gyro'], g['accel']])
+    first = [a.copy() for a in algo.get_results()]
+    algo.run([1, float(g['fs']), g['gyro'], g['accel']])
+    assert abs(algo.get_results()[1][0, 2] - first[1][0, 2]) > 1.0 or abs(np.linalg.norm(algo.get_results()[1][0] - first[1][0])) > 1.0
+    with pytest.raises(ValueError, match='bad sizes'):       # error convention: status code + ginsim_last_error -> ValueError
+        algo.run([1, float(g['fs']), np.empty((0, 3)), np.empty((0, 3))])

@@ -144,3 +144,43 @@ def test_saved_csv_files_match_the_reference(tmp_path):
             assert np.max(np.abs(d)) < 1e-7, f
         else:
             np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-9, err_msg=f)
+
+
+def _tokens(line):
+    import re
+    return [t for t in re.split(r'([\[\]\s,])', line) if t.strip()]
+
+
+@pytest.mark.parametrize('tag,start,opt', [('end', -1, ''), ('process', 0, ''), ('end_ned', -1, 'ned')])
+def test_printed_summary_is_the_reference_text(tag, start, opt):
+    """Sim.results() prints what the unmodified reference printed for the same injected noise (Sim.__summary,
+    ins_sim.py:339-413): the same lines in the same order, every word equal, every number within 2e-6 relative
+    (the text carries 8-9 digits) -- for the end-point statistics, the process statistics of the reference's default
+    err_stats_start = 0 and the end-point statistics in NED."""
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration, free_integration_odo
+    g = load_golden('summary_text_rf0')
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=True, odo=True,
+                        odo_opt={'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])})
+    ini = g['ini']
+    algos = [free_integration.FreeIntegration(ini.copy()), free_integration_odo.FreeIntegration(ini.copy())]
+    sim = ins_sim.Sim([100.0, 10.0, 0.0], csv, ref_frame=0, imu=imu, mode=None, env=None, algorithm=algos, seed=int(g['seed']))
+    sim.run(2)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        sim.results(err_stats_start=start, extra_opt=opt)
+    ours = [l for l in buf.getvalue().split('\n')]
+    want = [l for l in str(g['text_' + tag]).split('\n')]
+    assert len(ours) == len(want), '\n'.join(ours)
+    for lo, lw in zip(ours, want):
+        to, tw = _tokens(lo), _tokens(lw)
+        assert len(to) == len(tw), (lo, lw)
+        for a, b in zip(to, tw):
+            try:
+                fb = float(b)
+            except ValueError:
+                assert a == b, (lo, lw)
+                continue
+            fa = float(a)
+            assert abs(fa - fb) <= 2e-6 * abs(fb) + 1e-12, (lo, lw)
