@@ -1,14 +1,13 @@
-// Lean fp64 elementary functions for the MC kernel, specialised to the argument ranges the kernel needs.
+// Elementary functions of the MC kernel, specialised to the argument ranges the kernel needs.
 //
-// ROCm's OCML double-precision log / sincos / sincospi are <1 ulp and pay for it with double-double
-// arithmetic and a Payne-Hanek large-argument path (~1000 v_add_f64 in the first build of mc_kernel).
-// The kernel only needs:
-//   * log(u) for a uniform u in (0,1]               -> Box-Muller radius
-//   * sin/cos(pi*x) for x = 2u in (0,2)             -> Box-Muller angle
-//   * sin/cos(a + d) from sin/cos(a) for small |d|  -> Euler-angle attitude propagation
-// Errors are a few ulp (validated against NumPy through the ginsim_rng_normals / ginsim_box_muller hooks:
-// tests/test_gpu_parity.py::test_rng_words_bit_exact_and_normals, ::test_box_muller_corner_cases);
-// the engine's parity tolerances are 1e-12..1e-9.
+//   * the Box-Muller transform of the normal generator, DEFINED operation by operation in IEEE single precision (every
+//     product, sum and square root rounded separately -- no fused multiply-adds --, two committed lookup tables,
+//     normal_tables.inc), so that the NumPy and the C oracle (oracle/) reproduce the device's normals to the
+//     bit (tests/test_gpu_parity.py::test_rng_words_bit_exact_and_normals, ::test_box_muller_corner_cases).  Single
+//     precision because the SIMD issues an fp32 instruction in half the time of an fp64 one and the twelve normals of a
+//     step were 40 % of the fused kernel's fp64 work (round 2, third definition of the stream: 1.60 -> 1.46 ms per launch).
+//   * sin/cos(a + d) from sin/cos(a) for small |d| in fp64 -> Euler-angle attitude propagation (a few ulp; the engine's
+//     parity tolerances are 1e-12..1e-9).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,67 +28,103 @@ GINSIM_FM double vconst(double k) {
 }
 
 struct MathConsts {
-    double l[5];            // -2 log1p(-r'/2) = r' + r'^2 (1/4 + r'/12 + r'^2/32 + r'^3/80 + r'^4/192)
-    double ln2_hi, ln2_lo;  // -2 ln 2, split
-    double sc[5];           // sin: -1/3!, 1/5!, -1/7!, 1/9!, -1/11!   (Box-Muller uses 2, rotate_sincos 5)
-    double cc[6];           // cos: -1/2!, 1/4!, ... 1/12!             (Box-Muller uses 2, rotate_sincos 6)
-    double ang_bias, ang_scale;     // (0.5 - 2^14) 2 pi 2^-24 and 2 pi 2^-24: centred remainder of the 24-bit angle -> radians
-    double u_hi, u_lo, u_half;      // 2^-32, 2^-40, 2^-41: uniform40 as two FMAs
-    // OPAQUE = true pins the 23 constants in VGPRs (46 registers); false leaves them to the compiler (SGPR literals),
+    double sc[5];           // sin: -1/3!, 1/5!, -1/7!, 1/9!, -1/11!
+    double cc[6];           // cos: -1/2!, 1/4!, ... 1/12!
+    // OPAQUE = true pins the 11 constants in VGPRs (22 registers); false leaves them to the compiler (SGPR literals),
     // which is what the two-algorithm kernels need to stay under 256 VGPRs without scratch spills.
     template <bool OPAQUE>
     GINSIM_FM void init() {
         auto vconst = [](double x) { return OPAQUE ? ginsim::vconst(x) : x; };
-        const double lc[5] = {0.25, 1.0 / 12.0, 1.0 / 32.0, 1.0 / 80.0, 1.0 / 192.0};
-#pragma unroll
-        for (int k = 0; k < 5; ++k) l[k] = vconst(lc[k]);
-        ln2_hi = vconst(-2.0 * 6.93147180369123816490e-01);
-        ln2_lo = vconst(-2.0 * 1.90821492927058770002e-10);
         const double s[5] = {-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0, -1.0 / 39916800.0};
         const double c[6] = {-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0, 1.0 / 479001600.0};
 #pragma unroll
         for (int k = 0; k < 5; ++k) sc[k] = vconst(s[k]);
 #pragma unroll
         for (int k = 0; k < 6; ++k) cc[k] = vconst(c[k]);
-        ang_bias = vconst((0.5 - 16384.0) * (6.283185307179586476925 * 0x1.0p-24));
-        ang_scale = vconst(6.283185307179586476925 * 0x1.0p-24);
-        u_hi = vconst(0x1.0p-32);
-        u_lo = vconst(0x1.0p-40);
-        u_half = vconst(0x1.0p-41);
     }
 };
 
-// Box-Muller lookup tables, built by every workgroup in LDS (12 KB):
-//   lg[k] = {-2/c_k, -2 ln c_k}, c_k the (rounded) centre of the k-th of 256 mantissa bins of m in [sqrt(1/2), sqrt(2))
-//           (c = 1 exactly for the bin that contains 1, so that ln u -> 0 without cancellation as u -> 1); the factor
-//           -2 of the Box-Muller radius sqrt(-2 ln u) is folded into the table and the series;
+// Box-Muller lookup tables (fp32, 8 KB), copied into LDS by every workgroup from the committed constants:
+//   lg[k] = {c_k, -2/c_k, -2 ln c_k, 0}, c_k the centre of the k-th of 256 bins of the mantissa m in [sqrt(1/2), sqrt(2))
+//           (bins of 2^15 consecutive bit patterns from 0x3f3504f3; c = 1 and ln c = 0 for the bin that contains 1, so that
+//           ln u -> 0 without cancellation as u -> 1); the factor -2 of the radius sqrt(-2 ln u) is folded in;
 //   sc[i] = {sin a_i, cos a_i}, a_i = 2 pi (i + 1/2) / 512: the centre of the i-th of 512 sectors of the turn.
-// With them log needs a degree-6 series in |r| <= 2^-9 instead of a reciprocal, a quotient correction and a degree-21
-// series, and sin/cos need two two-term series in |b| <= pi/512 and four FMAs instead of a quadrant reduction, two
-// degree-15/16 series and the swap / sign selects.
 constexpr int kLogBins = 256, kAngBins = 512;
+constexpr int kNormalTableWords = 4 * kLogBins + 2 * kAngBins;
+static __device__ const uint32_t kNormalTableBits[kNormalTableWords] = {
+#include "normal_tables.inc"
+};
 struct NormalTables {
-    const double2* lg;
-    const double2* sc;
+    const float4* lg;
+    const float2* sc;
 };
 
-GINSIM_FM void fill_normal_tables(double2* tab, int tid, int nthreads) {
-    for (int k = tid; k < kLogBins; k += nthreads) {
-        const int h0 = (k << 12) + 0x3fe6a09e;
-        const double m_lo = __hiloint2double(h0, 0), m_hi = __hiloint2double(h0 + 0x1000, 0);
-        // ln c is taken for the ROUNDED reciprocal that is stored: m * (1/c) - 1 is then one exactly rounded fma of the
-        // true ratio (a reciprocal rounded independently of ln c would put an ABSOLUTE 1e-16 on ln u and spoil the
-        // relative accuracy of small |ln u|); the error of ln c scales with |ln c| ~ |ln u|.
-        const bool unit = m_lo <= 1.0 && 1.0 < m_hi;
-        const double inv = unit ? 1.0 : 1.0 / (0.5 * (m_lo + m_hi));
-        // the unit bin adds 2^-200 instead of 0: absorbed by every other value, and u = 1 gives radius 2^-100, not 0/0
-        tab[k] = double2{-2.0 * inv, unit ? 0x1.0p-200 : 2.0 * log(inv)};
-    }
-    for (int i = tid; i < kAngBins; i += nthreads) {
-        double sn, cs;
-        sincospi((double)(2 * i + 1) * (1.0 / kAngBins), &sn, &cs);
-        tab[kLogBins + i] = double2{sn, cs};
-    }
+GINSIM_FM NormalTables fill_normal_tables(uint32_t* lds, int tid, int nthreads) {
+    for (int k = tid; k < kNormalTableWords; k += nthreads) lds[k] = kNormalTableBits[k];
+    return NormalTables{reinterpret_cast<const float4*>(lds), reinterpret_cast<const float2*>(lds + 4 * kLogBins)};
+}
+
+// x = -2 ln u for u = (f32(a) + 1/2) 2^-32 in (0, 1], a = a 32-bit word: the squared Box-Muller radius (|z| <= 6.8).
+//   u = m 2^e, m in [sqrt(1/2), sqrt(2));  x = e (-2 ln 2) + (-2 ln c_k) + (r + r^2 (1/4 + r/12)),  r = (m - c_k)(-2/c_k)
+// m - c_k is exact (|m - c_k| <= 2^-8), |r| <= 2^-7, the series is cut below 2^-26 r.  The exponent/mantissa split and the
+// bin index are integer arithmetic on the bit pattern: adding (0x3f800000 - 0x3f3504f3) moves the sqrt(1/2) boundary
+// onto an exponent boundary.  EVERY operation below is one IEEE single-precision operation, in this order: the oracles
+// repeat them (oracle/philox.py radius2_f32).
+GINSIM_FM float radius2_f32(uint32_t a, const NormalTables& tab) {
+#pragma clang fp contract(off)
+    const float t = (float)a;
+    const float u = (t + 0.5f) * 0x1.0p-32f;
+    const uint32_t hx = __float_as_uint(u) + (0x3f800000u - 0x3f3504f3u);
+    const float ef = (float)((int)(hx >> 23) - 127);
+    const float4 k = tab.lg[(hx >> 15) & (kLogBins - 1)];
+    const float m = __uint_as_float((hx & 0x007fffffu) + 0x3f3504f3u);
+    const float d = m - k.x;
+    const float r = d * k.y;
+    float q = r * (1.0f / 12.0f);
+    q = q + 0.25f;
+    const float r2 = r * r;
+    q = q * r2;
+    const float small = r + q;
+    float x = ef * -1.3862943611198906f;
+    x = x + k.z;
+    x = x + small;
+    return x;
+}
+
+// Correctly rounded sqrt(x) for 0 <= x < 2^7 (never denormal here: x = 0 or x >= 2^-24): v_sqrt_f32 is good to 1 ulp;
+// of its result and the two neighbours the one whose square brackets x is the rounded root (the residuals are exact in
+// one fma each).  The oracles call sqrtf / np.sqrt, which are correctly rounded.
+GINSIM_FM float sqrt_rn_f32(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float vdn = __builtin_fmaf(-dn, s, x), vup = __builtin_fmaf(-up, s, x);
+    s = vdn <= 0.0f ? dn : s;
+    s = vup > 0.0f ? up : s;
+    return s;
+}
+
+// sin and cos of the Box-Muller angle 2 pi (w24 + 1/2) 2^-24, w24 = the low 24 bits of a Philox word: sector i = top 9
+// bits, b = centred remainder in radians (|b| <= pi/512), angle = a_i + b;  sin b = b - b^3/6 (next term 7e-14),
+// cos b - 1 = -b^2/2 (next term 6e-11).  One IEEE single-precision operation per line (oracle/philox.py sincos_f32).
+GINSIM_FM void sincos_f32(uint32_t w, float& sn, float& cs, const NormalTables& tab) {
+#pragma clang fp contract(off)
+    const float2 t = tab.sc[(w >> 15) & (kAngBins - 1)];
+    float b = (float)(int)(w & 0x7fffu);
+    b = b + (0.5f - 16384.0f);
+    b = b * 3.7450703562e-07f;                  // f32(2 pi 2^-24)
+    const float tt = b * b;
+    float u1 = tt * (-1.0f / 6.0f);
+    u1 = u1 * b;
+    const float sb = b + u1;
+    const float cm = tt * -0.5f;
+    float p1 = t.y * sb;
+    const float p2 = t.x * cm;
+    p1 = p1 + p2;
+    sn = t.x + p1;
+    float q1 = t.y * cm;
+    const float q2 = t.x * sb;
+    q1 = q1 - q2;
+    cs = t.y + q1;
 }
 
 // 1/x to ~1 ulp: hardware v_rcp_f64 estimate + two Newton steps.
@@ -113,52 +148,6 @@ GINSIM_FM double rsqrt_nr(double x) {
     double y = __builtin_amdgcn_rsq(x);
     y = __builtin_fma(y, __builtin_fma(-0.5 * y, x * y, 0.5), y);
     return __builtin_fma(y, __builtin_fma(-0.5 * y, x * y, 0.5), y);
-}
-
-// sqrt(x) for finite x > 0 well inside the normal range (here x = -2 ln u in [2^-200, 75.5]: the log table returns
-// 2^-200 instead of 0 for u = 1).  v_rsq_f64 estimate, one Goldschmidt step, one residual correction: <= 1 ulp,
-// 6 VALU + v_rsq.  The compiler's sqrt() adds range scaling, a second correction and an inf/0 select (17 VALU).
-GINSIM_FM double sqrt_pos(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    const double h = 0.5 * y;
-    const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);                                // ~2^-46
-    return __builtin_fma(__builtin_fma(-g, g, x), h, g);       // the 2^-23 error of h only scales the correction
-}
-
-// -2 ln u for 0 < u <= 1 (normal, not denormal: u >= 2^-41 by construction of uniform40): the squared Box-Muller radius.
-//   u = m 2^e, m in [sqrt(1/2), sqrt(2));  -2 ln u = e (-2 ln2) + (-2 ln c_k) + (-2 log1p(r)),  r = m / c_k - 1,
-//   |r| <= 2^-9;  with r' = -2 r = fma(m, -2/c_k, 2):  -2 log1p(r) = r' + r'^2/4 + r'^3/12 + r'^4/32 + r'^5/80 + r'^6/192
-// The exponent/mantissa split and the bin index are integer arithmetic on the high word (no compare/select):
-// adding (0x3ff00000 - 0x3fe6a09e) moves the sqrt(1/2) boundary onto an exponent boundary.
-GINSIM_FM double neg2_log_u01(double u, const MathConsts& k, const NormalTables& tab) {
-    uint32_t hx = (uint32_t)__double2hiint(u) + (0x3ff00000u - 0x3fe6a09eu);
-    const int e = (int)(hx >> 20) - 0x3ff;
-    const double2 t = tab.lg[(hx >> 12) & (kLogBins - 1)];
-    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
-    const double m = __hiloint2double((int)hx, __double2loint(u));
-    const double r = __builtin_fma(m, t.x, 2.0);
-    double p = k.l[4];
-#pragma unroll
-    for (int i = 3; i >= 0; --i) p = __builtin_fma(p, r, k.l[i]);
-    const double ed = (double)e;
-    // (e (-2 ln2)_hi + (-2 ln c)) + (r' + e (-2 ln2)_lo + r'^2 p): the first sum is exact to 1 ulp
-    const double small = __builtin_fma(r * r, p, __builtin_fma(ed, k.ln2_lo, r));
-    return __builtin_fma(ed, k.ln2_hi, t.y) + small;
-}
-
-// sin and cos of the Box-Muller angle 2 pi (a + 1/2) 2^-24, a = the low 24 bits of a Philox word: sector i = top 9
-// bits of a, b = centred remainder in radians (|b| <= pi/512), angle = a_i + b.  sin b = b + b^3 (-1/6 + b^2/120) (next
-// term 6e-20), cos b - 1 = b^2 (-1/2 + b^2/24) (next term 7e-17).
-GINSIM_FM void sincos_turn24(uint32_t w, double& s, double& c, const MathConsts& k, const NormalTables& tab) {
-    const double2 t = tab.sc[(w >> 15) & (kAngBins - 1)];
-    const double b = __builtin_fma((double)(w & 0x7fffu), k.ang_scale, k.ang_bias);        // centred remainder, radians
-    const double tt = b * b;
-    const double sb = __builtin_fma(b * tt, __builtin_fma(tt, k.sc[1], k.sc[0]), b);       // sin b
-    const double cm = tt * __builtin_fma(tt, k.cc[1], k.cc[0]);                            // cos b - 1
-    s = t.x + __builtin_fma(t.y, sb, t.x * cm);
-    c = t.y + __builtin_fma(-t.x, sb, t.y * cm);
 }
 
 // Rotate (s,c) = (sin a, cos a) by a small angle d: returns sin/cos(a+d).  Valid for |d| <= 0.25 rad

@@ -291,12 +291,12 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
         trace[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
         trace[2] = __builtin_amdgcn_s_memtime();
     }
-    __shared__ double2 ntab[GIVEN ? 1 : kLogBins + kAngBins];
+    __shared__ uint32_t ntab[GIVEN ? 4 : kNormalTableWords];
+    NormalTables tab{nullptr, nullptr};
     if (!GIVEN) {
-        fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+        tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
         __syncthreads();
     }
-    const NormalTables tab{ntab, ntab + (GIVEN ? 0 : kLogBins)};
     if (r >= a.runs) return;
     constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
     constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
@@ -353,24 +353,24 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
             const bool need_odo = ODO || a.out_odo;
             if (need_acc && need_gyr) {             // the common case: six streams in one phased batch
                 double z0[6], z1[6];
-                normal_pairs<S_ACC_D_XY, 6>(key, jj, z0, z1, mk, tab);
+                normal_pairs<S_ACC_D_XY, 6>(key, jj, z0, z1, tab);
                 const params_ptr kp = kernarg_params();
                 acc = sense3<WD>(cur_a, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
                 gyr = sense3<WD>(cur_g, &kp->gyro, dg, Vec3{z0[3], z1[3], z0[4]}, Vec3{z1[4], z0[5], z1[5]});
             } else if (need_acc) {
                 double z0[3], z1[3];
-                normal_pairs<S_ACC_D_XY, 3>(key, jj, z0, z1, mk, tab);
+                normal_pairs<S_ACC_D_XY, 3>(key, jj, z0, z1, tab);
                 acc = sense3<WD>(cur_a, &kernarg_params()->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             } else if (need_gyr) {
                 double z0[3], z1[3];
-                normal_pairs<S_GYR_D_XY, 3>(key, jj, z0, z1, mk, tab);
+                normal_pairs<S_GYR_D_XY, 3>(key, jj, z0, z1, tab);
                 gyr = sense3<WD>(cur_g, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             }
             if (need_acc && a.out_accel) store3(a.out_accel, plane, off, acc);
             if (need_gyr && a.out_gyro) store3(a.out_gyro, plane, off, gyr);
             if (need_odo) {
                 double z0, z1;
-                normal_pair(key, S_ODO, jj, z0, z1, mk, tab);
+                normal_pair(key, S_ODO, jj, z0, z1, tab);
                 const params_ptr kq = kernarg_params();
                 odo = kq->odo_scale * as_uniform(a.ref_odo)[j] + kq->odo_stdv * z0;     // pathgen.py:639-640
                 if (a.out_odo) a.out_odo[off] = odo;
@@ -410,28 +410,32 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
 // and there are no more runs to give the SIMD a second wavefront.  So the work of one step is split across TWO
 // wavefronts per 64 runs, at the point where the normal generator changes character:
 //
-//   waves 4-7 of a 512-thread workgroup (producers): the three Philox blocks of a step and the RADIUS half of the six
-//                                                    Box-Muller transforms (uniform, log, sqrt) -> LDS ring, per step
-//                                                    and run 6 doubles r and 6 angle words  (72 B)
-//   waves 0-3 (consumers)                          : read tile i-1 from LDS, the DIRECTION half (sin/cos of the angle
-//                                                    words), sensor sums, mechanisation, all stores
+//   waves 4-7 of a 512-thread workgroup (producers): the three Philox blocks of a step and the six single-precision
+//                                                    Box-Muller transforms -> LDS ring, per step and run the twelve
+//                                                    normals as floats (48 B)
+//   waves 0-3 (consumers)                          : read tile i-1 from LDS, widen, sensor sums, mechanisation, all stores
 //
-// ~400 VALU instructions per step on either side; one __syncthreads() per tile of T = 4 steps; the instruction total
-// is unchanged, the SIMD just always has a second wavefront to issue from.  Results are bit-identical to mc_kernel
-// (same functions in the same order on the same values).
+// One __syncthreads() per tile of T = 4 steps; the instruction total is unchanged, the SIMD just always has a second
+// wavefront to issue from.  Results are bit-identical to mc_kernel (same functions in the same order on the same values).
 constexpr int kSplitRuns = 256;
 constexpr int kSplitTile = 4;
-constexpr int kSplitStep = 6 * 8 + 6 * 4;               // bytes per step and run in the ring
-constexpr size_t kSplitLds = (size_t)2 * kSplitTile * kSplitStep * kSplitRuns;         // 144 KiB -> one workgroup per CU
+constexpr int kSplitStep = 12 * 4;                      // bytes per step and run in the ring
+// 96 KiB of ring + the tables, padded to more than half of the LDS so that a CU takes ONE workgroup (eight wavefronts, two
+// per SIMD: a producer and a consumer)
+constexpr size_t kSplitRing = (size_t)2 * kSplitTile * kSplitStep * kSplitRuns;
+constexpr size_t kSplitLds = kSplitRing > 100 * 1024 ? kSplitRing : 100 * 1024;
 
-template <int RF, int ALGOS, bool WD>
-__global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a) {
-    extern __shared__ double zring[];                   // [2 stages][T steps]{ r[6][256] doubles, ang[6][256] words }
+// PROD producer wavefronts per consumer wavefront: with two (768 threads, three wavefronts per SIMD, <= 168 registers) the
+// steps of a tile alternate between the two producer groups.
+template <int RF, int ALGOS, bool WD, int PROD = 1>
+__global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim_mc_params a) {
+    extern __shared__ float zring[];                    // [2 stages][T steps][12 normals][256 runs]
     constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
     constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
-    constexpr int kStepDoubles = kSplitStep * kSplitRuns / 8;          // 2304 doubles per step
+    constexpr int kStepFloats = kSplitStep * kSplitRuns / 4;           // 3072 floats per step
     const int lane = threadIdx.x & (kSplitRuns - 1);
     const bool producer = threadIdx.x >= kSplitRuns;
+    const int pgroup = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) - 1;     // which producer group (wave-uniform)
     const int64_t r = (int64_t)blockIdx.x * kSplitRuns + lane;
     const bool active = r < a.runs;
     const int64_t n = a.n, runs = a.runs, plane = n * runs;
@@ -442,32 +446,26 @@ __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a)
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     MathConsts mk;
     mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO))>();     // the two-algorithm consumer would spill
-    __shared__ double2 ntab[kLogBins + kAngBins];
-    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __shared__ uint32_t ntab[kNormalTableWords];
+    const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const NormalTables tab{ntab, ntab + kLogBins};
+
 
     if (producer) {
         for (int64_t i = 0; i <= ntiles; ++i) {
             if (i < ntiles && active) {
-                double* stage = zring + (i & 1) * (kSplitTile * kStepDoubles);
+                float* stage = zring + (i & 1) * (kSplitTile * kStepFloats);
 #pragma unroll
                 for (int t = 0; t < kSplitTile; ++t) {
                     const int64_t j = i * kSplitTile + t;
-                    if (j < n_noise) {
-                        double u[6];
-                        uint32_t ang[6];
-                        draw_streams<S_ACC_D_XY, 6>(key, (uint32_t)j, u, ang, mk);
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) u[k] = neg2_log_u01(u[k], mk, tab);
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) u[k] = sqrt_pos(u[k]);
-                        double* rb = stage + t * kStepDoubles + lane;
-                        uint32_t* ab = reinterpret_cast<uint32_t*>(stage + t * kStepDoubles + 6 * kSplitRuns) + lane;
+                    if (j < n_noise && (PROD == 1 || (t % PROD) == pgroup)) {
+                        float z0[6], z1[6];
+                        normal_pairs_f32<S_ACC_D_XY, 6>(key, (uint32_t)j, z0, z1, tab);
+                        float* zb = stage + t * kStepFloats + lane;
 #pragma unroll
                         for (int k = 0; k < 6; ++k) {
-                            rb[k * kSplitRuns] = u[k];
-                            ab[k * kSplitRuns] = ang[k];
+                            zb[(2 * k) * kSplitRuns] = z0[k];
+                            zb[(2 * k + 1) * kSplitRuns] = z1[k];
                         }
                     }
                 }
@@ -490,7 +488,7 @@ __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a)
     }
     for (int64_t i = 0; i <= ntiles; ++i) {
         if (i >= 1 && active) {
-            const double* stage = zring + ((i - 1) & 1) * (kSplitTile * kStepDoubles);
+            const float* stage = zring + ((i - 1) & 1) * (kSplitTile * kStepFloats);
 #pragma unroll 1
             for (int t = 0; t < kSplitTile; ++t) {
                 const int64_t j = (i - 1) * kSplitTile + t;
@@ -498,16 +496,12 @@ __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a)
                 const int64_t off = j * runs + r;
                 const bool last = (j == n - 1);
                 const Vec3 cur_a = load3(as_uniform(a.ref_accel), j), cur_g = load3(as_uniform(a.ref_gyro), j);
-                const double* rb = stage + t * kStepDoubles + lane;
-                const uint32_t* ab = reinterpret_cast<const uint32_t*>(stage + t * kStepDoubles + 6 * kSplitRuns) + lane;
+                const float* zb = stage + t * kStepFloats + lane;
                 double p0[6], p1[6];                  // z0 / z1 of streams 0..5
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    const double rad = rb[k * kSplitRuns];
-                    double sn, cs;
-                    sincos_turn24(ab[k * kSplitRuns], sn, cs, mk, tab);
-                    p0[k] = rad * cs;
-                    p1[k] = rad * sn;
+                    p0[k] = (double)zb[(2 * k) * kSplitRuns];
+                    p1[k] = (double)zb[(2 * k + 1) * kSplitRuns];
                 }
                 const params_ptr kp = kernarg_params();
                 const Vec3 acc = sense3<WD>(cur_a, &kp->accel, da, Vec3{p0[0], p1[0], p0[1]}, Vec3{p1[1], p0[2], p1[2]});
@@ -517,7 +511,7 @@ __global__ void __launch_bounds__(512) mc_kernel_split(const ginsim_mc_params a)
                 double odo = 0.0;
                 if (ODO || a.out_odo) {
                     double z0, z1;
-                    normal_pair(key, S_ODO, (uint32_t)j, z0, z1, mk, tab);
+                    normal_pair(key, S_ODO, (uint32_t)j, z0, z1, tab);
                     const params_ptr kq = kernarg_params();
                     odo = kq->odo_scale * as_uniform(a.ref_odo)[j] + kq->odo_stdv * z0;
                     if (a.out_odo) a.out_odo[off] = odo;
@@ -584,14 +578,23 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream) {
     const int64_t waves = (p.runs + kWave - 1) / kWave;
     if constexpr ((ALGOS & GINSIM_ALGO_FREE) != 0) {
         if (mc_variant(p) == 1) {
+            // one algorithm in the ECEF-free frame fits 168 registers: two producer wavefronts per consumer, three wavefronts
+            // per SIMD (C2: 1.48 -> 1.41 ms); ref_frame 0 would spill 76-140 B per lane
+            constexpr int PROD = (ALGOS == GINSIM_ALGO_FREE && RF == 1) ? 2 : 1;
+            static const int prod = [] { const char* e = getenv("GINSIM_SPLIT_PROD"); return e ? atoi(e) : PROD; }();
             static bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, PROD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
                 return true;
             }();
             (void)once;
             const dim3 sgrid((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns));
-            hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD>), sgrid, dim3(512), kSplitLds, stream, p);
+            if (prod == PROD && PROD > 1)
+                hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD, PROD>), sgrid, dim3(256 * (1 + PROD)), kSplitLds, stream, p);
+            else
+                hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD, 1>), sgrid, dim3(512), kSplitLds, stream, p);
             return hipGetLastError();
         }
     }
@@ -664,10 +667,10 @@ struct SeriesPlan {
 
 template <int PASS>
 __global__ void __launch_bounds__(256) series_kernel(const ginsim_mc_params a, const SeriesPlan pl) {
-    __shared__ double2 ntab[kLogBins + kAngBins];
-    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __shared__ uint32_t ntab[kNormalTableWords];
+    const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const NormalTables tab{ntab, ntab + kLogBins};
+
     MathConsts mk;
     mk.init<true>();
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -682,7 +685,7 @@ __global__ void __launch_bounds__(256) series_kernel(const ginsim_mc_params a, c
         Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
         for (int64_t j = j0; j < j1; ++j) {
             double z0[6], z1[6];
-            normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)j, z0, z1, mk, tab);
+            normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)j, z0, z1, tab);
             da.x = __builtin_fma(kp->accel.gm_a[0], da.x, kp->accel.gm_b[0] * z0[0]);
             da.y = __builtin_fma(kp->accel.gm_a[1], da.y, kp->accel.gm_b[1] * z1[0]);
             da.z = __builtin_fma(kp->accel.gm_a[2], da.z, kp->accel.gm_b[2] * z0[1]);
@@ -697,7 +700,7 @@ __global__ void __launch_bounds__(256) series_kernel(const ginsim_mc_params a, c
         for (int64_t j = j0; j < j1; ++j) {
             const int64_t off = j * a.runs + r;
             double z0[6], z1[6];
-            normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)j, z0, z1, mk, tab);
+            normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)j, z0, z1, tab);
             const Vec3 ta{a.ref_accel[3 * j], a.ref_accel[3 * j + 1], a.ref_accel[3 * j + 2]};
             const Vec3 tg{a.ref_gyro[3 * j], a.ref_gyro[3 * j + 1], a.ref_gyro[3 * j + 2]};
             const Vec3 acc = sense3(ta, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
@@ -706,7 +709,7 @@ __global__ void __launch_bounds__(256) series_kernel(const ginsim_mc_params a, c
             if (a.out_gyro) store3(a.out_gyro, plane, off, gyr);
             if (a.out_odo) {
                 double y0, y1;
-                normal_pair(key, S_ODO, (uint32_t)j, y0, y1, mk, tab);
+                normal_pair(key, S_ODO, (uint32_t)j, y0, y1, tab);
                 a.out_odo[off] = kp->odo_scale * a.ref_odo[j] + kp->odo_stdv * y0;
             }
         }
@@ -765,10 +768,10 @@ hipError_t launch_series(const ginsim_mc_params& p, double* carry, hipStream_t s
 // ---------------------------------------------------------------------------------------------------
 // Auxiliary sensors: one thread per (sample, run), run fastest.  gps_gen: pathgen.py:621-624; mag_gen: :658-661.
 __global__ void __launch_bounds__(256) aux_gps_kernel(const ginsim_aux_params a) {
-    __shared__ double2 ntab[kLogBins + kAngBins];
-    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __shared__ uint32_t ntab[kNormalTableWords];
+    const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const NormalTables tab{ntab, ntab + kLogBins};
+
     MathConsts mk;
     mk.init<false>();
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -777,7 +780,7 @@ __global__ void __launch_bounds__(256) aux_gps_kernel(const ginsim_aux_params a)
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     double z0[3], z1[3];
-    normal_pairs<S_GPS_P_XY, 3>(key, (uint32_t)k, z0, z1, mk, tab);
+    normal_pairs<S_GPS_P_XY, 3>(key, (uint32_t)k, z0, z1, tab);
     const double z[6] = {z0[0], z1[0], z0[1], z1[1], z0[2], z1[2]};     // pos x,y,z  vel x,y,z
     const int64_t plane = a.m * a.runs;
 #pragma unroll
@@ -785,10 +788,10 @@ __global__ void __launch_bounds__(256) aux_gps_kernel(const ginsim_aux_params a)
 }
 
 __global__ void __launch_bounds__(256) aux_mag_kernel(const ginsim_aux_params a) {
-    __shared__ double2 ntab[kLogBins + kAngBins];
-    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __shared__ uint32_t ntab[kNormalTableWords];
+    const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const NormalTables tab{ntab, ntab + kLogBins};
+
     MathConsts mk;
     mk.init<false>();
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -797,7 +800,7 @@ __global__ void __launch_bounds__(256) aux_mag_kernel(const ginsim_aux_params a)
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     double z0[2], z1[2];
-    normal_pairs<S_MAG_XY, 2>(key, (uint32_t)j, z0, z1, mk, tab);
+    normal_pairs<S_MAG_XY, 2>(key, (uint32_t)j, z0, z1, tab);
     const double z[3] = {z0[0], z1[0], z0[1]};
     const double v[3] = {a.ref_mag[3 * j] + a.mag_hi[0], a.ref_mag[3 * j + 1] + a.mag_hi[1], a.ref_mag[3 * j + 2] + a.mag_hi[2]};
     const int64_t plane = a.n * a.runs;
@@ -818,17 +821,15 @@ hipError_t launch_aux(const ginsim_aux_params& p, hipStream_t s) {
 // RNG self-test: normals (and raw Philox words) of one (seed, run, stream), sample index = global lane.
 __global__ void rng_probe_kernel(uint64_t seed, uint64_t run, uint32_t stream, int64_t count,
                                  double* __restrict__ z0, double* __restrict__ z1, uint32_t* __restrict__ words) {
-    __shared__ double2 ntab[kLogBins + kAngBins];
-    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __shared__ uint32_t ntab[kNormalTableWords];
+    const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const NormalTables tab{ntab, ntab + kLogBins};
-    MathConsts mk;
-    mk.init<true>();                // the hot kernels' configuration
+
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)run, (uint32_t)(run >> 32)};
     double a, b;
-    normal_pair(key, stream, (uint32_t)j, a, b, mk, tab);
+    normal_pair(key, stream, (uint32_t)j, a, b, tab);
     z0[j] = a;
     z1[j] = b;
     if (words) {
@@ -866,22 +867,20 @@ __global__ void gather_runs_kernel(const double* __restrict__ series, int C, int
     out[idx] = series[((int64_t)c * n + j) * runs + ids[k]];
 }
 
-// Box-Muller on given words (test hook): words 0-1 are taken as one half block -- 40-bit radius uniform from word 0 and the
-// top byte of word 1, angle from the low 24 bits of word 1 (words 2-3 unused).
+// Box-Muller on given words (test hook): words 0-1 are taken as one half block -- radius uniform from word 0, angle from
+// the low 24 bits of word 1 (words 2-3 unused).
 __global__ void box_muller_kernel(const uint32_t* __restrict__ words, int64_t count, double* __restrict__ z0, double* __restrict__ z1) {
-    __shared__ double2 ntab[kLogBins + kAngBins];
-    fill_normal_tables(ntab, threadIdx.x, blockDim.x);
+    __shared__ uint32_t ntab[kNormalTableWords];
+    const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const NormalTables tab{ntab, ntab + kLogBins};
-    MathConsts mk;
-    mk.init<true>();
+
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    double r[1] = {uniform40(words[4 * i], words[4 * i + 1], mk)}, a[1], b[1];
-    const uint32_t ang[1] = {words[4 * i + 1]};
-    box_muller<1>(r, ang, a, b, mk, tab);
-    z0[i] = a[0];
-    z1[i] = b[0];
+    const uint32_t ra[1] = {words[4 * i]}, ang[1] = {words[4 * i + 1]};
+    float a[1], b[1];
+    box_muller<1>(ra, ang, a, b, tab);
+    z0[i] = (double)a[0];
+    z1[i] = (double)b[0];
 }
 
 hipError_t launch_box_muller(const uint32_t* words, int64_t count, double* z0, double* z1, hipStream_t s) {

@@ -2,9 +2,9 @@
 //
 // Philox4x32-7 (Salmon, Moraes, Dror, Shaw, SC'11: seven rounds is the paper's Crush-resistant Philox4x32, ten its
 // conservative default; Random123 constants and known-answer vectors for both round counts are in the tests) +
-// Box-Muller in fp64.  A pair of normals takes 64 bits -- a 40-bit radius uniform (|z| up to 7.5 sigma) and a 24-bit
-// angle uniform -- so one 128-bit block yields TWO pairs, and the six pairs (twelve normals) of an IMU step cost
-// exactly three blocks:
+// a Box-Muller transform defined bit-exactly in single precision (fastmath.hpp).  A pair of normals takes the two words
+// of a half block -- a 32-bit radius uniform (|z| up to 6.8 sigma) and a 24-bit angle uniform -- so one 128-bit block
+// yields TWO pairs, and the six pairs (twelve normals) of an IMU step cost exactly three blocks:
 //     stream s at sample j  =  half (s & 1) of block  philox4x32_7(counter = (j, s >> 1, run_lo, run_hi), key = seed)
 // It replaces the reference's serial global np.random.randn stream
 // (gnss_ins_sim/pathgen/pathgen.py:495,557,588,593,621-622,639,660): every (run, stream, sample)
@@ -51,75 +51,81 @@ __device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c
     return u32x4{c0, c1, c2, c3};
 }
 
-// (0,1) uniform with 40 significant bits from the two words (a, b) of a half block: u = ((a << 8 | b >> 24) + 0.5) 2^-40,
-// exact in fp64: a 2^-32 + ((b >> 24) 2^-40 + 2^-41) as two FMAs on three register constants.
-__device__ __forceinline__ double uniform40(uint32_t a, uint32_t b, const MathConsts& k) {
-    return __builtin_fma((double)a, k.u_hi, __builtin_fma((double)(b >> 24), k.u_lo, k.u_half));
-}
-
 struct RngKey {
     uint32_t k0, k1;    // seed
     uint32_t r0, r1;    // global run id
 };
 
-// Box-Muller on N (radius uniform, angle word) draws, phase by phase -- all logarithms, then all square roots, then
+// Box-Muller on N (radius word, angle word) draws, phase by phase -- all logarithms, then all square roots, then
 // all sin/cos -- instead of N complete transforms in a row: each phase is N independent dependency chains (ILP for
-// a lone wavefront on its SIMD) and only ONE polynomial's constants are live at a time.
+// a lone wavefront on its SIMD).  The normals are single-precision numbers.
 template <int N>
-__device__ __forceinline__ void box_muller(double (&r)[N], const uint32_t (&ang)[N], double (&z0)[N], double (&z1)[N],
-                                           const MathConsts& mk, const NormalTables& tab) {
+__device__ __forceinline__ void box_muller(const uint32_t (&a)[N], const uint32_t (&b)[N], float (&z0)[N], float (&z1)[N],
+                                           const NormalTables& tab) {
+#pragma clang fp contract(off)
+    float r[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = neg2_log_u01(r[k], mk, tab);
+    for (int k = 0; k < N; ++k) r[k] = radius2_f32(a[k], tab);
 #pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = sqrt_pos(r[k]);
+    for (int k = 0; k < N; ++k) r[k] = sqrt_rn_f32(r[k]);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        double s, c;
-        sincos_turn24(ang[k], s, c, mk, tab);
+        float s, c;
+        sincos_f32(b[k], s, c, tab);
         z0[k] = r[k] * c;
         z1[k] = r[k] * s;
     }
 }
 
-// Radius uniforms u[N] and angle words ang[N] (the low 24 bits count) of the N consecutive streams FIRST .. FIRST+N-1
+// The two words (a: radius, b: angle, of which the low 24 bits count) of the N consecutive streams FIRST .. FIRST+N-1
 // at sample j: blocks FIRST >> 1 .. (FIRST+N-1) >> 1, each computed once.
 template <uint32_t FIRST, int N>
-__device__ __forceinline__ void draw_streams(const RngKey& key, uint32_t j, double* u, uint32_t* ang, const MathConsts& mk) {
+__device__ __forceinline__ void draw_streams(const RngKey& key, uint32_t j, uint32_t* a, uint32_t* b) {
     constexpr uint32_t B0 = FIRST >> 1, B1 = (FIRST + N - 1) >> 1;
 #pragma unroll
-    for (uint32_t b = B0; b <= B1; ++b) {
-        const u32x4 w = philox4x32(j, b, key.r0, key.r1, key.k0, key.k1);
-        if (2 * b >= FIRST) {
-            u[2 * b - FIRST] = uniform40(w.x, w.y, mk);
-            ang[2 * b - FIRST] = w.y;
+    for (uint32_t blk = B0; blk <= B1; ++blk) {
+        const u32x4 w = philox4x32(j, blk, key.r0, key.r1, key.k0, key.k1);
+        if (2 * blk >= FIRST) {
+            a[2 * blk - FIRST] = w.x;
+            b[2 * blk - FIRST] = w.y;
         }
-        if (2 * b + 1 < FIRST + N) {
-            u[2 * b + 1 - FIRST] = uniform40(w.z, w.w, mk);
-            ang[2 * b + 1 - FIRST] = w.w;
+        if (2 * blk + 1 < FIRST + N) {
+            a[2 * blk + 1 - FIRST] = w.z;
+            b[2 * blk + 1 - FIRST] = w.w;
         }
     }
 }
 
-// N consecutive streams FIRST .. FIRST+N-1 of one sample -> N normal pairs
+// N consecutive streams FIRST .. FIRST+N-1 of one sample -> N normal pairs, as single-precision numbers ...
 template <uint32_t FIRST, int N>
-__device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t j, double (&z0)[N], double (&z1)[N],
-                                             const MathConsts& mk, const NormalTables& tab) {
-    double r[N];
-    uint32_t ang[N];
-    draw_streams<FIRST, N>(key, j, r, ang, mk);
-    box_muller<N>(r, ang, z0, z1, mk, tab);
+__device__ __forceinline__ void normal_pairs_f32(const RngKey& key, uint32_t j, float (&z0)[N], float (&z1)[N], const NormalTables& tab) {
+    uint32_t a[N], b[N];
+    draw_streams<FIRST, N>(key, j, a, b);
+    box_muller<N>(a, b, z0, z1, tab);
+}
+
+// ... and widened to fp64 (exact) for the fp64 sensor models
+template <uint32_t FIRST, int N>
+__device__ __forceinline__ void normal_pairs(const RngKey& key, uint32_t j, double (&z0)[N], double (&z1)[N], const NormalTables& tab) {
+    float f0[N], f1[N];
+    normal_pairs_f32<FIRST, N>(key, j, f0, f1, tab);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        z0[k] = (double)f0[k];
+        z1[k] = (double)f1[k];
+    }
 }
 
 // Two standard normals of one stream (run-time stream id).
 __device__ __forceinline__ void normal_pair(const RngKey& key, uint32_t stream, uint32_t j, double& z0, double& z1,
-                                            const MathConsts& mk, const NormalTables& tab) {
+                                            const NormalTables& tab) {
     const u32x4 w = philox4x32(j, stream >> 1, key.r0, key.r1, key.k0, key.k1);
     const bool hi = (stream & 1u) != 0;
-    double r[1] = {uniform40(hi ? w.z : w.x, hi ? w.w : w.y, mk)}, a[1], b[1];
-    const uint32_t ang[1] = {hi ? w.w : w.y};
-    box_muller<1>(r, ang, a, b, mk, tab);
-    z0 = a[0];
-    z1 = b[0];
+    const uint32_t a[1] = {hi ? w.z : w.x}, b[1] = {hi ? w.w : w.y};
+    float f0[1], f1[1];
+    box_muller<1>(a, b, f0, f1, tab);
+    z0 = (double)f0[0];
+    z1 = (double)f1[0];
 }
 
 }  // namespace ginsim

@@ -5,6 +5,7 @@ Nothing here computes on the CPU: every number a job returns was produced by lib
 (pathgen excepted, which is native host code inside the same library and runs once per Sim.run).
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -424,8 +425,9 @@ class MonteCarloJob(object):
         ps = 0 if self.proc_first is None else (2 if (self.proc_ned and p.ref_frame == 0) else 1)
         wd = (not p.given_sensors) and (ps != 0 or (p.ref_frame == 0 and p.algo_mask == 3) or any(
             p.accel.white_drift[k] or p.gyro.white_drift[k] or p.accel.bias[k] != 0.0 or p.gyro.bias[k] != 0.0 for k in range(3)))
-        if v.value:
-            return 'ginsim::mc_kernel_split<%d, %d, %s>' % (p.ref_frame, p.algo_mask, 'true' if wd else 'false')
+        if v.value:     # one algorithm: two producer wavefronts per consumer (csrc/mc_kernel.hip, launch3)
+            prod = 2 if p.algo_mask == 1 and p.ref_frame == 1 and os.environ.get('GINSIM_SPLIT_PROD', '2') == '2' else 1
+            return 'ginsim::mc_kernel_split<%d, %d, %s, %d>' % (p.ref_frame, p.algo_mask, 'true' if wd else 'false', prod)
         return 'ginsim::mc_kernel<%d, %d, %s, %s, %d>' % (p.ref_frame, p.algo_mask, 'true' if p.given_sensors else 'false',
                                                           'true' if wd else 'false', ps)
 

@@ -16,8 +16,8 @@
  *   geo_param / lla2ecef              gnss_ins_sim/geoparams/geoparams.py:25-53 / 70-87
  *   array_error (end point)           gnss_ins_sim/sim/ins_data_manager.py:537-541, 737
  *
- * The noise source is the engine's Philox4x32-7 + Box-Muller stream (see oracle/philox.py for the
- * definition and why the reference's own np.random stream is "parity unpinned").
+ * The noise source is the engine's Philox4x32-7 + single-precision Box-Muller stream (see oracle/philox.py for the
+ * definition, which is exact to the bit, and why the reference's own np.random stream is "parity unpinned").
  * Pinned against the NumPy oracle (itself pinned against the executed reference) in
  * tests/test_oracle_c.py.  Compile with -ffp-contract=off.
  */
@@ -49,16 +49,59 @@ static void philox4x32_7(uint32_t c[4], uint32_t k0, uint32_t k1) {
     }
 }
 
-/* stream s at sample j = half (s & 1) of block (j, s >> 1): 40-bit radius uniform + 24-bit angle -- oracle/philox.py */
+/* The two fp32 tables of the generator: the committed numbers the device uses (csrc/normal_tables.inc, made by
+ * tools/gen_normal_tables.py; oracle/philox.py builds them independently and the tests compare the bits). */
+static const uint32_t normal_table_bits[256 * 4 + 512 * 2] = {
+#include "normal_tables.inc"
+};
+static float bits_f32(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
+static uint32_t f32_bits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
+
+/* stream s at sample j = half (s & 1) of block (j, s >> 1); the transform is defined operation by operation in IEEE
+ * single precision (no fused multiply-adds: this file is compiled with -ffp-contract=off) -- oracle/philox.py */
 static void normal_pair(uint64_t seed, uint64_t run, uint32_t stream, uint32_t j, double* z0, double* z1) {
     uint32_t W[4] = {j, stream >> 1, (uint32_t)run, (uint32_t)(run >> 32)};
     philox4x32_7(W, (uint32_t)seed, (uint32_t)(seed >> 32));
     const uint32_t a = (stream & 1u) ? W[2] : W[0], b = (stream & 1u) ? W[3] : W[1];
-    const double u1 = ((double)(((uint64_t)a << 8) | (b >> 24)) + 0.5) * 0x1.0p-40;
-    const double u2 = ((double)(b & 0xffffffu) + 0.5) * 0x1.0p-24;
-    double r = sqrt(-2.0 * log(u1)), ang = (2.0 * PI) * u2;
-    *z0 = r * cos(ang);
-    *z1 = r * sin(ang);
+    /* radius: x = -2 ln u, u = (f32(a) + 1/2) 2^-32 */
+    const float t = (float)a;
+    const float u = (t + 0.5f) * 0x1.0p-32f;
+    const uint32_t hx = f32_bits(u) + (0x3f800000u - 0x3f3504f3u);
+    const float ef = (float)((int32_t)(hx >> 23) - 127);
+    const uint32_t* lg = normal_table_bits + 4 * ((hx >> 15) & 255u);
+    const float m = bits_f32((hx & 0x007fffffu) + 0x3f3504f3u);
+    const float d = m - bits_f32(lg[0]);
+    const float r = d * bits_f32(lg[1]);
+    float q = r * (1.0f / 12.0f);
+    q = q + 0.25f;
+    const float r2 = r * r;
+    q = q * r2;
+    const float small = r + q;
+    float x = ef * -1.3862943611198906f;
+    x = x + bits_f32(lg[2]);
+    x = x + small;
+    const float rad = sqrtf(x);
+    /* direction: sin, cos of 2 pi ((b & 0xffffff) + 1/2) 2^-24 */
+    const uint32_t* sc = normal_table_bits + 256 * 4 + 2 * ((b >> 15) & 511u);
+    const float sn_i = bits_f32(sc[0]), cs_i = bits_f32(sc[1]);
+    float bb = (float)(int32_t)(b & 0x7fffu) + (0.5f - 16384.0f);
+    bb = bb * 3.7450703562e-07f;               /* f32(2 pi 2^-24) */
+    const float tt = bb * bb;
+    float u1 = tt * (-1.0f / 6.0f);
+    u1 = u1 * bb;
+    const float sb = bb + u1;
+    const float cm = tt * -0.5f;
+    float p1 = cs_i * sb;
+    const float p2 = sn_i * cm;
+    p1 = p1 + p2;
+    const float sn = sn_i + p1;
+    float q1 = cs_i * cm;
+    const float q2 = sn_i * sb;
+    q1 = q1 - q2;
+    const float cs = cs_i + q1;
+    const float a0 = rad * cs, a1 = rad * sn;
+    *z0 = (double)a0;
+    *z1 = (double)a1;
 }
 
 void oracle_normals(uint64_t seed, uint64_t run, uint32_t stream, int64_t count, double* z0, double* z1) {

@@ -12,10 +12,14 @@ LIB = os.path.join(HERE, '_build', 'libginsim_oracle.so')
 _PD = C.POINTER(C.c_double)
 
 
+TABLES = os.path.join(os.path.dirname(HERE), 'gnss-ins-sim_amd', 'csrc')      # normal_tables.inc: committed constants of the stream
+
+
 def build(force=False):
-    if force or not os.path.exists(LIB) or os.path.getmtime(SRC) > os.path.getmtime(LIB):
+    newest = max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(TABLES, 'normal_tables.inc')))
+    if force or not os.path.exists(LIB) or newest > os.path.getmtime(LIB):
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.check_call(['gcc', '-O2', '-fPIC', '-shared', '-fopenmp', '-ffp-contract=off', '-std=c11',
+        subprocess.check_call(['gcc', '-O2', '-fPIC', '-shared', '-fopenmp', '-ffp-contract=off', '-std=c11', '-I' + TABLES,
                                '-o', LIB, SRC, '-lm'])
     return LIB
 

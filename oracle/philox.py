@@ -7,20 +7,24 @@ engine therefore defines its own stream -- Philox4x32-7 (Salmon et al., SC'11,
 "Parallel random numbers: as easy as 1, 2, 3": seven rounds is the Crush-resistant
 Philox4x32 of the paper, ten its conservative default; Random123 v1.14 constants and
 known-answer vectors for both round counts are checked in the tests) followed by
-Box-Muller in fp64 -- and parity is "identical injected normals": the
-unmodified reference is fed THESE normals through a ``np.random.randn`` shim
-(``oracle/ref_shim.py``).
+a Box-Muller transform that is DEFINED operation by operation in IEEE single precision
+(every multiplication, addition and square root rounded separately, no fused multiply-adds,
+two committed lookup tables) -- so the device, this file and the C oracle produce the SAME BITS,
+and parity is "identical injected normals": the unmodified reference is fed THESE normals
+through a ``np.random.randn`` shim (``oracle/ref_shim.py``).
 
 Stream definition (shared by this file, ``oracle/c/ginsim_oracle.c`` and
-``gnss-ins-sim_amd/csrc/philox.hpp``).  A normal pair takes 64 bits: a 40-bit uniform for the radius
-(|z| up to 7.5 sigma) and a 24-bit uniform for the angle, so one 128-bit block gives TWO pairs and the six pairs
-of an IMU step are exactly three blocks:
+``gnss-ins-sim_amd/csrc/philox.hpp`` / ``fastmath.hpp``).  A normal pair takes the two words of a half block, so one
+128-bit block gives TWO pairs and the six pairs of an IMU step are exactly three blocks:
 
     key     = (seed & 0xffffffff, seed >> 32)
     W       = philox4x32_7((j, s >> 1, run & 0xffffffff, run >> 32), key)      j = sample index, s = stream id
     (a, b)  = (W0, W1) if s is even else (W2, W3)
-    u1 = ((a << 8 | b >> 24) + 0.5) * 2**-40 ;  u2 = ((b & 0xffffff) + 0.5) * 2**-24
-    r  = sqrt(-2 ln u1) ;  z0 = r cos(2 pi u2) ;  z1 = r sin(2 pi u2)
+    u   = (f32(a) + 0.5) * 2**-32                                   radius uniform in (0, 1]: |z| up to 6.7 sigma
+    x   = -2 ln u        by exponent / 256-bin mantissa table / cubic   (radius2_f32 below)
+    r   = sqrt(x)        correctly rounded
+    s,c = sin, cos of 2 pi ((b & 0xffffff) + 1/2) 2**-24     by 512-sector table / two-term series (sincos_f32 below)
+    z0 = f64(r * c) ;  z1 = f64(r * s)
 
 Stream ids (one stream -> two normals (z0, z1)):
 
@@ -73,10 +77,69 @@ def philox4x32(c0, c1, c2, c3, k0, k1, rounds=ROUNDS):
     return c0, c1, c2, c3
 
 
-def uniform40(a, b):
-    """Open-interval (0,1) uniform with 40 significant bits from the two words of a half block (exact in fp64)."""
-    v = (a << np.uint64(8)) | (b >> np.uint64(24))
-    return (v.astype(np.float64) + 0.5) * (2.0 ** -40)
+F32 = np.float32
+SQRT_HALF_BITS = np.uint32(0x3f3504f3)          # bits of f32(sqrt(1/2))
+NEG_2LN2 = F32(-1.3862943611198906)
+ANG_SCALE = F32(2.0 * np.pi * 2.0 ** -24)
+
+
+def normal_tables():
+    """The two fp32 tables of the generator -- the same construction as tools/gen_normal_tables.py, whose output
+    (csrc/normal_tables.inc) the device and the C oracle use; tests/test_oracle_golden.py compares the bits."""
+    k = np.arange(256, dtype=np.uint32)
+    lo = (SQRT_HALF_BITS + (k << np.uint32(15))).view(F32).astype(np.float64)
+    hi = (SQRT_HALF_BITS + (k << np.uint32(15)) + np.uint32(0x8000)).view(F32).astype(np.float64)
+    unit = (lo <= 1.0) & (1.0 < hi)
+    c = np.where(unit, 1.0, 0.5 * (lo + hi)).astype(F32)
+    c64 = c.astype(np.float64)
+    lg = np.zeros((256, 3), dtype=F32)
+    lg[:, 0] = c
+    lg[:, 1] = (-2.0 / c64).astype(F32)
+    lg[:, 2] = np.where(unit, 0.0, -2.0 * np.log(c64)).astype(F32)
+    ang = 2.0 * np.pi * (np.arange(512) + 0.5) / 512.0
+    return lg, np.stack([np.sin(ang), np.cos(ang)], axis=1).astype(F32)
+
+
+_LG, _SC = normal_tables()
+
+
+def radius2_f32(a):
+    """x = -2 ln u, u = (f32(a) + 1/2) 2^-32, in single precision: u = m 2^e with m in [sqrt(1/2), sqrt(2)),
+    x = e (-2 ln 2) + (-2 ln c_k) + (r + r^2 (1/4 + r/12)),  r = (m - c_k)(-2 / c_k).  Every operation is one IEEE op."""
+    t = np.asarray(a, dtype=np.uint64).astype(F32)                  # uint32 -> f32, round to nearest even
+    u = (t + F32(0.5)) * F32(2.0 ** -32)
+    hx = u.view(np.uint32) + (np.uint32(0x3f800000) - SQRT_HALF_BITS)
+    ef = ((hx >> np.uint32(23)).astype(np.int32) - 127).astype(F32)
+    tab = _LG[(hx >> np.uint32(15)) & np.uint32(255)]
+    m = ((hx & np.uint32(0x007fffff)) + SQRT_HALF_BITS).view(F32)
+    d = m - tab[..., 0]
+    r = d * tab[..., 1]
+    q = r * F32(1.0 / 12.0)
+    q = q + F32(0.25)
+    q = q * (r * r)
+    small = r + q
+    x = ef * NEG_2LN2
+    x = x + tab[..., 2]
+    return x + small
+
+
+def sincos_f32(b):
+    """sin, cos of 2 pi ((b & 0xffffff) + 1/2) 2^-24: sector = top 9 of the 24 bits, remainder centred, in radians."""
+    w = np.asarray(b, dtype=np.uint64).astype(np.uint32)
+    tab = _SC[(w >> np.uint32(15)) & np.uint32(511)]
+    sn_i, cs_i = tab[..., 0], tab[..., 1]
+    bb = (w & np.uint32(0x7fff)).astype(F32) + F32(0.5 - 16384.0)
+    bb = bb * ANG_SCALE
+    tt = bb * bb
+    u1 = tt * F32(-1.0 / 6.0)
+    u1 = u1 * bb
+    sb = bb + u1                                                     # sin b
+    cm = tt * F32(-0.5)                                              # cos b - 1
+    p1 = cs_i * sb
+    p1 = p1 + sn_i * cm
+    q1 = cs_i * cm
+    q1 = q1 - sn_i * sb
+    return sn_i + p1, cs_i + q1
 
 
 def stream_words(seed, run, stream, j):
@@ -90,12 +153,12 @@ def stream_words(seed, run, stream, j):
 
 
 def box_muller(a, b):
-    """(z0, z1) from the two words of a half block."""
-    u1 = uniform40(a, b)
-    u2 = ((b & np.uint64(0xFFFFFF)).astype(np.float64) + 0.5) * (2.0 ** -24)
-    r = np.sqrt(-2.0 * np.log(u1))
-    ang = (2.0 * np.pi) * u2
-    return r * np.cos(ang), r * np.sin(ang)
+    """(z0, z1) from the two words of a half block; the values are exact single-precision numbers held in float64."""
+    with np.errstate(all='ignore'):
+        r = np.sqrt(radius2_f32(a))                                   # float32 sqrt: correctly rounded
+        sn, cs = sincos_f32(b)
+        assert r.dtype == F32 and sn.dtype == F32
+        return (r * cs).astype(np.float64), (r * sn).astype(np.float64)
 
 
 def normal_pair(seed, run, stream, j):

@@ -39,46 +39,53 @@ def test_rng_words_bit_exact_and_normals(ctx):
         for k in range(4):
             assert np.array_equal(w[:, k].astype(np.uint64), ref[k]), 'Philox word %d differs' % k
         r0, r1 = philox.normal_pair(seed, run, stream, j)
-        np.testing.assert_allclose(z0, r0, rtol=0, atol=2e-14)
-        np.testing.assert_allclose(z1, r1, rtol=0, atol=2e-14)
+        assert np.array_equal(z0.view(np.uint64), r0.view(np.uint64))      # the transform is defined to the bit
+        assert np.array_equal(z1.view(np.uint64), r1.view(np.uint64))
 
 
 def test_box_muller_corner_cases(ctx):
-    """Words no seed will produce in a test: the largest u (1 - 2^-41), the smallest u (2^-41), mantissas on the
-    edges of the log table's bins (around 1 and around sqrt(1/2) / sqrt(2)), angles on sector edges of the sin/cos
-    table, plus a dense random sample -- all against NumPy's log / sqrt / cos / sin on the same uniforms.
-    A row is (a, b, -, -): the two words of a half block (40-bit radius = a and the top byte of b, angle = low 24 bits of b)."""
+    """Words no seed will produce in a test: the largest and the smallest radius uniform, mantissas on the edges of the
+    log table's bins (around 1 and around sqrt(1/2) / sqrt(2)), exponent changes, angles on sector edges of the sin/cos
+    table, plus two million random words -- the device's normals must be the oracle's, bit for bit (both are defined as the
+    same sequence of IEEE single-precision operations), and close to the textbook transform in double precision.
+    A row is (a, b, -, -): the two words of a half block (radius uniform from a, angle = low 24 bits of b)."""
     import ginsim
     from oracle import philox
     rng = np.random.default_rng(7)
     rows = []
     full, zero = 0xFFFFFFFF, 0
     rows += [(full, full, zero, zero), (zero, zero, full, full), (zero, 0x00FFFFFF, zero, zero), (full, 0xFF000000, full, full)]
-    # radius uniforms around u = 1/2, 1/4 (exponent change), around m = sqrt(2) and around every bin edge of the log table
-    for a in (0x7FFFFFFF, 0x80000000, 0x3FFFFFFF, 0x40000000, 0xB504F333, 0xB504F334, 0x5A827999, 0x5A82799A):
+    # radius uniforms around u = 1/2, 1/4 (exponent change), around m = sqrt(2), just below 1, and the smallest ones
+    for a in (0x7FFFFFFF, 0x80000000, 0x3FFFFFFF, 0x40000000, 0xB504F333, 0xB504F334, 0x5A827999, 0x5A82799A,
+              0xFFFFFF00, 0xFFFFFE80, 0xFFFFFF7F, 0xFFFFFF80, 1, 2, 3, 0xFF, 0x100, 0xFFFFFF, 0x1000000, 0x1000001):
         for b in (zero, full, 0x12345678, 0xFF000000, 0x00FFFFFF):
             rows.append((a, b, 0x9E3779B9, 0x3C6EF372))
     for k in range(0, 2048, 7):                       # mantissa bins: top 11 bits of a sweep, the rest at both ends
         rows.append(((k << 21) | 0x100000, zero, 1, 2))
         rows.append(((k << 21) | 0x0FFFFF, full, 3, 4))
+    for k in range(256):                              # both edges of every bin of the log table, for u in [1/2, 1)
+        for e in (0x3f3504f3 + (k << 15), 0x3f3504f3 + (k << 15) - 1):
+            u = np.array([e], dtype=np.uint32).view(np.float32)[0]
+            a = int(np.clip(np.float64(u) * 2.0 ** 32 - 0.5, 0, full))
+            rows += [(a, 0x555555, 0, 0), (max(a - 1, 0), 0xAAAAAA, 0, 0), (min(a + 1, full), 0x333333, 0, 0)]
     for i in range(512):                              # sector edges of the 24-bit angle: i 2^15 - 1 and i 2^15
         rows.append((0xDEADBEEF, 0x67000000 | (i << 15), zero, zero))
         rows.append((0xDEADBEEF, 0x67000000 | (((i << 15) - 1) & 0xFFFFFF), full, full))
     w = np.array(rows, dtype=np.uint64)
-    w = np.vstack([w, rng.integers(0, 2 ** 32, size=(200000, 4), dtype=np.uint64)])
+    w = np.vstack([w, rng.integers(0, 2 ** 32, size=(2000000, 4), dtype=np.uint64)])
     z0, z1 = ginsim.box_muller(ctx, w.astype(np.uint32))
-    u1 = philox.uniform40(w[:, 0], w[:, 1])
+    r0, r1 = philox.box_muller(w[:, 0], w[:, 1])
+    assert np.isfinite(z0).all() and np.isfinite(z1).all()
+    bad = np.flatnonzero((z0.view(np.uint64) != r0.view(np.uint64)) | (z1.view(np.uint64) != r1.view(np.uint64)))
+    assert bad.size == 0, (bad[:5], w[bad[:5]], z0[bad[:5]], r0[bad[:5]])
+    # and the textbook transform on the same uniforms
+    u1 = (w[:, 0].astype(np.float64) + 0.5) * 2.0 ** -32
     u2 = ((w[:, 1] & np.uint64(0xFFFFFF)).astype(np.float64) + 0.5) * 2.0 ** -24
-    assert u1.max() == 1.0 - 2.0 ** -41 and u1.min() == 2.0 ** -41
     r = np.sqrt(-2.0 * np.log(u1))
     a = (2.0 * np.pi) * u2
-    assert np.isfinite(z0).all() and np.isfinite(z1).all()
-    # the oracle's own angle 2 pi u2 carries up to 4.4e-16 rad of rounding -> allow r * 1e-15 on top of 2e-14
-    np.testing.assert_array_less(np.abs(z0 - r * np.cos(a)), 2e-14 + 1e-15 * r)
-    np.testing.assert_array_less(np.abs(z1 - r * np.sin(a)), 2e-14 + 1e-15 * r)
-    # radius to a few ulp RELATIVE, also for small radii (u -> 1), and no distortion of the direction
-    keep = r > 1e-6
-    np.testing.assert_allclose(np.hypot(z0[keep], z1[keep]) / r[keep], 1.0, rtol=0, atol=2e-15)
+    np.testing.assert_array_less(np.abs(z0 - r * np.cos(a)), 1e-6 + 1e-6 * r + 2e-7 / np.maximum(r, 1e-4))
+    np.testing.assert_array_less(np.abs(z1 - r * np.sin(a)), 1e-6 + 1e-6 * r + 2e-7 / np.maximum(r, 1e-4))
+    assert np.abs(z0).max() < 6.8 and np.abs(z0).max() > 6.5
 
 
 @pytest.mark.parametrize('name', ['bosch', 'nxp', 'tumble'])

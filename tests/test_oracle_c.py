@@ -8,10 +8,10 @@ from conftest import load_golden, assert_traj_close, ang_close
 
 def test_c_normals_match_numpy():
     for seed, run, stream in ((0, 0, 0), (20260923, 3, 5), (2 ** 63 + 5, 2 ** 40 + 7, 17), (5, 6, 7)):
-        z0, z1 = c_oracle.normals(seed, run, stream, 2000)
-        r0, r1 = philox.normal_pair(seed, run, stream, np.arange(2000, dtype=np.uint64))
-        np.testing.assert_allclose(z0, r0, rtol=0, atol=1e-15)
-        np.testing.assert_allclose(z1, r1, rtol=0, atol=1e-15)
+        z0, z1 = c_oracle.normals(seed, run, stream, 200000)
+        r0, r1 = philox.normal_pair(seed, run, stream, np.arange(200000, dtype=np.uint64))
+        assert np.array_equal(z0.view(np.uint64), r0.view(np.uint64))          # the transform is defined to the bit
+        assert np.array_equal(z1.view(np.uint64), r1.view(np.uint64))
 
 
 @pytest.mark.parametrize('name', ['bosch', 'nxp', 'tumble'])

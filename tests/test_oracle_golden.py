@@ -24,6 +24,29 @@ def test_philox_known_answers():
             assert tuple(int(x) for x in got) == want
 
 
+def test_normal_tables_are_the_committed_ones():
+    """The two fp32 tables are part of the definition of the stream: the NumPy oracle's own construction must give the
+    bits of csrc/normal_tables.inc (what the device and the C oracle read), and the constants of the transform must be the
+    single-precision numbers the device code spells."""
+    import os
+    import re
+    from conftest import PKG
+    txt = open(os.path.join(PKG, 'csrc', 'normal_tables.inc')).read()
+    w = np.array([int(x, 16) for x in re.findall(r'0x([0-9a-f]{8})u', txt)], dtype=np.uint32)
+    lg, sc = philox.normal_tables()
+    assert w.size == 256 * 4 + 512 * 2
+    assert np.array_equal(w[:1024].reshape(256, 4)[:, :3], lg.view(np.uint32)) and not w[:1024].reshape(256, 4)[:, 3].any()
+    assert np.array_equal(w[1024:].reshape(512, 2), sc.view(np.uint32))
+    assert (lg[:, 0] == 1.0).sum() == 1 and lg[lg[:, 0] == 1.0, 2] == 0.0            # the bin that contains 1
+    assert philox.ANG_SCALE == np.float32(3.7450703562e-07) and philox.NEG_2LN2 == np.float32(-1.3862943611198906)
+    # known answers of the transform itself (words -> normals), exact single-precision numbers
+    z0, z1 = philox.box_muller(np.array([0, 1, 2 ** 32 - 1, 2 ** 31], dtype=np.uint64),
+                               np.array([0, 0xffffff, 0x800000, 12345], dtype=np.uint64))
+    assert np.array_equal(z0.astype(np.float32).astype(np.float64), z0)
+    np.testing.assert_allclose(z0, [6.76370573, 6.5992794, -0.0, 1.17739749], rtol=2e-8)
+    np.testing.assert_allclose(z1, [1.26613759e-06, -1.23535767e-06, -0.0, 5.44370804e-03], rtol=2e-8)
+
+
 def test_normals_moments():
     z0, z1 = philox.normal_pair(99, np.arange(8)[None, :], 3, np.arange(50000)[:, None])
     for z in (z0, z1):
@@ -57,13 +80,18 @@ def test_stream_cut_statistics():
         assert abs(np.corrcoef(z[a][:-1], z[a][1:])[0, 1]) < lim            # consecutive samples
     other = philox.normal_pair(12345, 78, 5, j)[0]                             # the neighbouring run
     assert abs(np.corrcoef(z[4], other)[0, 1]) < lim
-    # radius and angle uniforms of one stream share the word b (top byte / low 24 bits): independent all the same
+    # radius and angle uniforms of one stream come from the two words of a half block: independent
     w = philox.stream_words(12345, 77, 4, j)
-    u1 = philox.uniform40(w[0], w[1])
+    u1 = (w[0].astype(np.float64) + 0.5) * 2.0 ** -32
     u2 = ((w[1] & np.uint64(0xFFFFFF)).astype(np.float64) + 0.5) * 2.0 ** -24
     assert abs(np.corrcoef(u1, u2)[0, 1]) < lim
     assert stats.kstest(u1, 'uniform').pvalue > 1e-3 and stats.kstest(u2, 'uniform').pvalue > 1e-3
-    assert u1.min() > 0.0 and u1.max() < 1.0
+    # the single-precision transform against the textbook one in double precision on the same uniforms: the radius
+    # uniform has a 24-bit mantissa, so the squared radius is off by up to ~1e-7 absolute (visible only where it is tiny)
+    x = philox.radius2_f32(w[0]).astype(np.float64)
+    assert np.abs(x - (-2.0 * np.log(u1))).max() < 4e-6 and (x >= 0).all()
+    sn, cs = philox.sincos_f32(w[1])
+    assert np.abs(sn - np.sin(2 * np.pi * u2)).max() < 1.5e-7 and np.abs(cs - np.cos(2 * np.pi * u2)).max() < 1.5e-7
 
 
 @pytest.mark.parametrize('name', ['bosch', 'nxp', 'tumble'])
