@@ -91,6 +91,54 @@ GINSIM_FM float radius2_f32(uint32_t a, const NormalTables& tab) {
     return x;
 }
 
+// The same on TWO words at once: the arithmetic as packed single-precision operations (v_pk_mul_f32 / v_pk_add_f32 do two
+// IEEE operations per lane in the issue time of one), the bit manipulation and the table reads per element.  Bit for bit
+// the scalar function on each element.
+typedef float v2f __attribute__((ext_vector_type(2)));
+GINSIM_FM v2f radius2_f32x2(uint32_t a0, uint32_t a1, const NormalTables& tab) {
+#pragma clang fp contract(off)
+    const v2f t = {(float)a0, (float)a1};
+    const v2f u = (t + 0.5f) * 0x1.0p-32f;
+    const uint32_t h0 = __float_as_uint(u.x) + (0x3f800000u - 0x3f3504f3u), h1 = __float_as_uint(u.y) + (0x3f800000u - 0x3f3504f3u);
+    const v2f ef = {(float)((int)(h0 >> 23) - 127), (float)((int)(h1 >> 23) - 127)};
+    const float4 k0 = tab.lg[(h0 >> 15) & (kLogBins - 1)], k1 = tab.lg[(h1 >> 15) & (kLogBins - 1)];
+    const v2f m = {__uint_as_float((h0 & 0x007fffffu) + 0x3f3504f3u), __uint_as_float((h1 & 0x007fffffu) + 0x3f3504f3u)};
+    const v2f kc = {k0.x, k1.x}, ki = {k0.y, k1.y}, kl = {k0.z, k1.z};
+    const v2f d = m - kc;
+    const v2f r = d * ki;
+    v2f q = r * (1.0f / 12.0f);
+    q = q + 0.25f;
+    const v2f r2 = r * r;
+    q = q * r2;
+    const v2f small = r + q;
+    v2f x = ef * -1.3862943611198906f;
+    x = x + kl;
+    x = x + small;
+    return x;
+}
+
+GINSIM_FM void sincos_f32x2(uint32_t w0, uint32_t w1, v2f& sn, v2f& cs, const NormalTables& tab) {
+#pragma clang fp contract(off)
+    const float2 t0 = tab.sc[(w0 >> 15) & (kAngBins - 1)], t1 = tab.sc[(w1 >> 15) & (kAngBins - 1)];
+    const v2f ts = {t0.x, t1.x}, tc = {t0.y, t1.y};
+    v2f b = {(float)(int)(w0 & 0x7fffu), (float)(int)(w1 & 0x7fffu)};
+    b = b + (0.5f - 16384.0f);
+    b = b * 3.7450703562e-07f;
+    const v2f tt = b * b;
+    v2f u1 = tt * (-1.0f / 6.0f);
+    u1 = u1 * b;
+    const v2f sb = b + u1;
+    const v2f cm = tt * -0.5f;
+    v2f p1 = tc * sb;
+    const v2f p2 = ts * cm;
+    p1 = p1 + p2;
+    sn = ts + p1;
+    v2f q1 = tc * cm;
+    const v2f q2 = ts * sb;
+    q1 = q1 - q2;
+    cs = tc + q1;
+}
+
 // Correctly rounded sqrt(x) for 0 <= x < 2^7 (never denormal here: x = 0 or x >= 2^-24): v_sqrt_f32 is good to 1 ulp;
 // of its result and the two neighbours the one whose square brackets x is the rounded root (the residuals are exact in
 // one fma each).  The oracles call sqrtf / np.sqrt, which are correctly rounded.

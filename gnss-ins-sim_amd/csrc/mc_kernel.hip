@@ -418,7 +418,10 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
 // One __syncthreads() per tile of T = 4 steps; the instruction total is unchanged, the SIMD just always has a second
 // wavefront to issue from.  Results are bit-identical to mc_kernel (same functions in the same order on the same values).
 constexpr int kSplitRuns = 256;
-constexpr int kSplitTile = 4;
+#ifndef GINSIM_SPLIT_TILE
+#define GINSIM_SPLIT_TILE 6
+#endif
+constexpr int kSplitTile = GINSIM_SPLIT_TILE;
 constexpr int kSplitStep = 12 * 4;                      // bytes per step and run in the ring
 // 96 KiB of ring + the tables, padded to more than half of the LDS so that a CU takes ONE workgroup (eight wavefronts, two
 // per SIMD: a producer and a consumer)

@@ -64,10 +64,21 @@ __device__ __forceinline__ void box_muller(const uint32_t (&a)[N], const uint32_
                                            const NormalTables& tab) {
 #pragma clang fp contract(off)
     float r[N];
+#ifdef GINSIM_BM_SCALAR
 #pragma unroll
     for (int k = 0; k < N; ++k) r[k] = radius2_f32(a[k], tab);
+#else
+#pragma unroll
+    for (int k = 0; k + 1 < N; k += 2) {
+        const v2f x = radius2_f32x2(a[k], a[k + 1], tab);
+        r[k] = x.x;
+        r[k + 1] = x.y;
+    }
+    if (N & 1) r[N - 1] = radius2_f32(a[N - 1], tab);
+#endif
 #pragma unroll
     for (int k = 0; k < N; ++k) r[k] = sqrt_rn_f32(r[k]);
+#ifdef GINSIM_BM_SCALAR
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         float s, c;
@@ -75,6 +86,23 @@ __device__ __forceinline__ void box_muller(const uint32_t (&a)[N], const uint32_
         z0[k] = r[k] * c;
         z1[k] = r[k] * s;
     }
+#else
+#pragma unroll
+    for (int k = 0; k + 1 < N; k += 2) {
+        v2f s, c;
+        sincos_f32x2(b[k], b[k + 1], s, c, tab);
+        const v2f rr = {r[k], r[k + 1]};
+        const v2f c0 = rr * c, c1 = rr * s;
+        z0[k] = c0.x; z0[k + 1] = c0.y;
+        z1[k] = c1.x; z1[k + 1] = c1.y;
+    }
+    if (N & 1) {
+        float s, c;
+        sincos_f32(b[N - 1], s, c, tab);
+        z0[N - 1] = r[N - 1] * c;
+        z1[N - 1] = r[N - 1] * s;
+    }
+#endif
 }
 
 // The two words (a: radius, b: angle, of which the low 24 bits count) of the N consecutive streams FIRST .. FIRST+N-1
