@@ -405,8 +405,8 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Wave-specialised variant for SMALL batches (<= 1024 wavefronts of runs, i.e. one wavefront per SIMD with the kernel
-// above -- BASELINE config 2).  A lone wavefront cannot hide its own dependent-instruction and s_waitcnt latencies
+// Wave-specialised variant, written for SMALL batches (<= 1024 wavefronts of runs, i.e. one wavefront per SIMD with the
+// kernel above -- BASELINE config 2) and, with two producer groups, the faster one at every size (mc_variant).  A lone wavefront cannot hide its own dependent-instruction and s_waitcnt latencies
 // and there are no more runs to give the SIMD a second wavefront.  So the work of one step is split across TWO
 // wavefronts per 64 runs, at the point where the normal generator changes character:
 //
@@ -564,6 +564,10 @@ int mc_variant(const ginsim_mc_params& p) {
     if (p.out_proc[0] || p.out_proc[1]) return 0;      // online process statistics live in the plain kernel
     const int pol = split_policy();
     if (pol >= 0) return pol != 0;
+    // one algorithm: three wavefronts per SIMD (a consumer and two producers) beat the plain kernel's two at every size
+    // (131 072 runs: 2.71 against 3.06 ms, 262 144: 5.76 against 6.13); two algorithms: only while the plain kernel
+    // cannot fill the SIMDs with a second wavefront
+    if (p.algo_mask == GINSIM_ALGO_FREE && p.ref_frame == 1) return 1;      // the variants with two producer groups (launch3)
     return (p.runs + kWave - 1) / kWave <= 1024 ? 1 : 0;
 }
 

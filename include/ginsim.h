@@ -143,7 +143,8 @@ int ginsim_mc_run(ginsim_ctx* ctx, const ginsim_mc_params* p);
 
 /* Which kernel ginsim_mc_run would launch for these parameters (telemetry for profiles; results are bit-identical):
  * 0 = one wavefront per 64 runs does noise + mechanisation (mc_kernel / mc_kernel_f32), 1 = wave-specialised
- * producer/consumer workgroups (mc_kernel_split / mc_kernel_f32_split), chosen for batches of <= 1024 wavefronts. */
+ * producer/consumer workgroups (mc_kernel_split / mc_kernel_f32_split), chosen for batches of <= 1024 wavefronts and,
+ * for one algorithm in ref_frame 1 (two producer groups: three wavefronts per SIMD), at every size. */
 int ginsim_mc_variant(const ginsim_mc_params* p, int32_t* variant);
 
 /* ---- auxiliary sensors of a Monte-Carlo batch: pathgen.gps_gen (pathgen.py:596-625) and pathgen.mag_gen (:643-661).

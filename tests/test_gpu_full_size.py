@@ -48,8 +48,11 @@ def _blocks(R, width=88):
     return [(0, width), (R // 2 - width // 2 - 5, width), (R - width, width)]
 
 
-@pytest.mark.parametrize('R', [65536, 131072, 262144])
-def test_c2_real_launch_sampled_runs_vs_c_oracle(ctx, R):
+@pytest.mark.parametrize('R,plain', [(65536, False), (131072, False), (262144, False), (131072, True)])
+def test_c2_real_launch_sampled_runs_vs_c_oracle(ctx, R, plain):
+    """The real launches of configs 2 and 4 (per-GPU share) and a 262 144-run one: the wave-specialised kernel the library
+    picks for them, and the one-wavefront-per-64-runs kernel (what two algorithms, ref_frame 0 at this size, given sensors
+    and the online statistics run on) forced through `block_threads`."""
     import ginsim
     from ginsim import workloads
     from oracle import c_oracle
@@ -57,8 +60,11 @@ def test_c2_real_launch_sampled_runs_vs_c_oracle(ctx, R):
     ini, truth, _ = workloads.truth_from_profile('turn_90deg', fs, rf)
     acc, gyr = workloads.imu_grade('mid-accuracy')
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, seed=seed, run_offset=off,
-                               keep_sensors=True, keep_traj=True).run()
-    assert ('split' in job.kernel_name()) == (R == 65536), job.kernel_name()
+                               keep_sensors=True, keep_traj=True)
+    if plain:
+        job.params.block_threads = 256
+    job.run()
+    assert ('split' in job.kernel_name()) == (not plain), job.kernel_name()
     dev_end = job.end_errors('free')
     worst = dict(att=0.0, pos=0.0, vel=0.0, accel=0.0, gyro=0.0)
     for first, count in _blocks(R):
@@ -79,7 +85,7 @@ def test_c2_real_launch_sampled_runs_vs_c_oracle(ctx, R):
         assert ang_close(dev_end[ids, :3], end[:, :3], 1e-9)
         np.testing.assert_allclose(dev_end[ids, 3:6], end[:, 3:6], rtol=0, atol=2e-8)
         np.testing.assert_allclose(dev_end[ids, 6:9], end[:, 6:9], rtol=0, atol=1e-9)
-    _record('c2_real_launch_R%d' % R, **worst)
+    _record('c2_real_launch_R%d%s' % (R, '_plain' if plain else ''), **worst)
     # the device reduction over the whole launch == NumPy over the downloaded end errors
     st = job.stats('free')
     assert st.count == R
