@@ -448,7 +448,7 @@ def main():
                        'parallelism': 'mc-shard x%d, one all-reduce (%s) of the 28-double stats record per step' % (
                            world, 'RCCL' if args.backend == 'nccl' else args.backend),
                        'device': ctx.name(), 'libginsim_sha256': build,
-                       'rng': 'Philox4x32-7, 64 bits per Box-Muller pair (3 blocks per IMU step)'},
+                       'rng': 'Philox4x32-7, 3 blocks per IMU step, Box-Muller defined bit-exactly in single precision'},
             'roofline': roofline(alg_bytes, kern_avg_ms, kname, (traffic or {}).get(kname, {}).get('hbm_bytes_per_launch'),
                                  traffic_source=traffic_source,
                                  note='writes exactly its algorithmic bytes; limited by fp64/integer VALU issue at the power-capped clock, '
