@@ -477,9 +477,31 @@ allan_pair_kernel(const double* __restrict__ in, double* __restrict__ out, doubl
 // Levels that fit one chunk (n_in <= 2520; for 3600 s @ 400 Hz the levels of 1440, 144 and 14 entries) are finished by
 // ONE wavefront per series in a single launch: the sums of 10 go to a second LDS stage instead of HBM and become
 // the next level in place.  Sums are final (one wavefront saw the whole level): written straight to sums[].
-__global__ void __launch_bounds__(64) allan_tail_kernel(const double* __restrict__ in, double* __restrict__ sums, const AllanTail t) {
+// Workgroups beyond the first t.nseries * (t.nlevels > 0) fold the per-workgroup partial records of the levels before: one
+// 64-lane workgroup per (series, level), lanes stride over the records of each factor, then a fixed butterfly.
+__device__ __forceinline__ void fold_partials(const double* __restrict__ partial, double* __restrict__ sums, const AllanFold& f,
+                                              int64_t s, int k, int64_t nseries) {
+    const int nparts = f.nparts[k];
+    const double* p = partial + (f.offset[k] + s * nparts) * 9;
+    for (int j = 0; j < 9; ++j) {
+        double a = 0.0;
+        for (int c = threadIdx.x; c < nparts; c += 64) a += p[c * 9 + j];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+        if (threadIdx.x == 0) sums[((int64_t)k * nseries + s) * 9 + j] = a;
+    }
+}
+
+__global__ void __launch_bounds__(64) allan_tail_kernel(const double* __restrict__ in, const double* __restrict__ partial,
+                                                        double* __restrict__ sums, const AllanTail t, const AllanFold f) {
     __shared__ __attribute__((aligned(16))) double stage[2][kStage];
     const int lane = threadIdx.x;
+    const int64_t ntail = t.nlevels > 0 ? t.nseries : 0;
+    if ((int64_t)blockIdx.x >= ntail) {
+        const int64_t b = (int64_t)blockIdx.x - ntail;
+        fold_partials(partial, sums, f, b % t.nseries, (int)(b / t.nseries), t.nseries);
+        return;
+    }
     const int64_t s = blockIdx.x;
     const double* x = in + s * t.in_stride;
     int cur = 0;
@@ -532,20 +554,6 @@ __global__ void __launch_bounds__(64) allan_tail_kernel(const double* __restrict
     }
 }
 
-// one 64-lane block per (series, level): lanes stride over the wavefront partials of each factor, then a fixed butterfly
-__global__ void allan_fold_kernel(const double* __restrict__ partial, double* __restrict__ sums, const AllanFold f) {
-    const int64_t s = blockIdx.x, nseries = gridDim.x;
-    const int k = blockIdx.y, nparts = f.nparts[k];
-    const double* p = partial + (f.offset[k] + s * nparts) * 9;
-    for (int j = 0; j < 9; ++j) {
-        double a = 0.0;
-        for (int c = threadIdx.x; c < nparts; c += 64) a += p[c * 9 + j];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
-        if (threadIdx.x == 0) sums[((int64_t)k * nseries + s) * 9 + j] = a;
-    }
-}
-
 int allan_parts(const AllanLevel& lv) {
     const int per_block = lv.chunks_per_block * kWavesPerBlock;
     return (lv.nchunks + per_block - 1) / per_block * kWavesPerBlock;
@@ -570,14 +578,10 @@ hipError_t launch_allan_pair(const double* in, double* out, double* partial, con
     return hipGetLastError();
 }
 
-hipError_t launch_allan_fold(const double* partial, double* sums, const AllanFold& f, int64_t nseries, hipStream_t st) {
-    if (f.nlevels > 0)
-        hipLaunchKernelGGL(allan_fold_kernel, dim3((unsigned)nseries, (unsigned)f.nlevels), dim3(64), 0, st, partial, sums, f);
-    return hipGetLastError();
-}
-
-hipError_t launch_allan_tail(const double* in, double* sums, const AllanTail& t, hipStream_t st) {
-    hipLaunchKernelGGL(allan_tail_kernel, dim3((unsigned)t.nseries), dim3(64), 0, st, in, sums, t);
+hipError_t launch_allan_finish(const double* in, const double* partial, double* sums, const AllanTail& t, const AllanFold& f,
+                               int64_t nseries, hipStream_t st) {
+    const int64_t blocks = (t.nlevels > 0 ? nseries : 0) + nseries * f.nlevels;
+    if (blocks > 0) hipLaunchKernelGGL(allan_tail_kernel, dim3((unsigned)blocks), dim3(64), 0, st, in, partial, sums, t, f);
     return hipGetLastError();
 }
 

@@ -38,7 +38,9 @@ hipError_t launch_allan_level(const double* in, double* out, double* partial, co
 bool allan_dma_applies(const double* in, const AllanLevel& lv);
 int allan_pair_parts(const AllanLevel& lv);
 hipError_t launch_allan_pair(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries, hipStream_t st);
-hipError_t launch_allan_fold(const double* partial, double* sums, const AllanFold& f, int64_t nseries, hipStream_t st);
-hipError_t launch_allan_tail(const double* in, double* sums, const AllanTail& t, hipStream_t st);
+// ONE launch finishes the call: workgroups 0 .. nseries-1 run the levels that fit a chunk, the others fold the partial records
+// of the levels before (either part may be empty)
+hipError_t launch_allan_finish(const double* in, const double* partial, double* sums, const AllanTail& t, const AllanFold& f,
+                               int64_t nseries, hipStream_t st);
 
 }  // namespace ginsim

@@ -61,6 +61,8 @@ struct ginsim_ctx {
     std::vector<hipEvent_t> pool;   // lazily created, indexed by slot
     void* ws[4] = {nullptr, nullptr, nullptr, nullptr};   // grow-only scratch regions (stats / allan)
     size_t ws_bytes[4] = {0, 0, 0, 0};
+    double* allan_host = nullptr;                         // pinned host memory the Allan kernels write their sums into
+    size_t allan_host_doubles = 0;
     ginsim_stats* stat_slots = nullptr;                   // pinned host records of ginsim_end_stats_begin/_finish
     hipEvent_t stat_ev[8] = {};
     bool stat_pending[8] = {};
@@ -162,6 +164,7 @@ int ginsim_destroy(ginsim_ctx* c) {
     for (hipEvent_t e : c->stat_ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stat_slots) (void)hipHostFree(c->stat_slots);
+    if (c->allan_host) (void)hipHostFree(c->allan_host);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return GINSIM_OK;
@@ -518,8 +521,8 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
     HIP_TRY(hipSetDevice(c->device));
     const int levels = decades;
     const int64_t n1 = n / 10;
-    // levels of more than one chunk: per-wavefront / per-workgroup partial sums, ONE fold launch at the end; levels of at
-    // most one chunk (the last three or four): one launch for all of them.  Where the level's rows are 16-byte aligned the
+    // levels of more than one chunk: per-wavefront / per-workgroup partial sums; ONE launch at the end folds them and runs
+    // the levels of at most one chunk (the last three or four).  Where the level's rows are 16-byte aligned the
     // LDS-DMA wave-pair kernel takes the level, otherwise the register-staged one.
     std::vector<AllanLevel> lvs(levels);
     AllanFold fold;
@@ -574,15 +577,14 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
         fold.nlevels = k;
     }
     REQUIRE(levels - fold.nlevels <= 4, "allan: internal level plan");
-    struct Region { void* p; double* d() const { return reinterpret_cast<double*>(p); } } ping, pong, partial, sums;
+    struct Region { void* p; double* d() const { return reinterpret_cast<double*>(p); } } ping, pong, partial;
     const size_t b_ping = sizeof(double) * (size_t)nseries * (n1 + 1), b_pong = sizeof(double) * (size_t)nseries * (n1 / 10 + 1);
-    const size_t b_part = sizeof(double) * 9 * (size_t)(records + 1), b_sums = sizeof(double) * 9 * (size_t)nseries * levels;
+    const size_t b_part = sizeof(double) * 9 * (size_t)(records + 1), b_sums = 0;
     void* region = nullptr;
     HIP_TRY(scratch(c, 1, b_ping + b_pong + b_part + b_sums + 1024, &region));
     ping.p = region;
     pong.p = reinterpret_cast<char*>(region) + ((b_ping + 255) & ~(size_t)255);
     partial.p = reinterpret_cast<char*>(pong.p) + ((b_pong + 255) & ~(size_t)255);
-    sums.p = reinterpret_cast<char*>(partial.p) + ((b_part + 255) & ~(size_t)255);
     const double* in = x;
     int flip = 0;
     for (const Step& st : steps) {
@@ -595,22 +597,25 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
             HIP_TRY(launch_allan_level(in, out, partial.d() + 9 * fold.offset[k], lvs[k], nseries, c->stream));
         in = out;
     }
-    HIP_TRY(launch_allan_fold(partial.d(), sums.d(), fold, nseries, c->stream));
-    if (fold.nlevels < levels) {
-        AllanTail t;
-        t.first = fold.nlevels;
-        t.nlevels = levels - fold.nlevels;
-        t.in_stride = lvs[t.first].in_stride;
-        t.nseries = nseries;
-        for (int l = 0; l < t.nlevels; ++l) {
-            t.n_in[l] = lvs[t.first + l].n_in;
-            for (int j = 0; j < 9; ++j) t.nb[l][j] = lvs[t.first + l].nb[j];
-        }
-        HIP_TRY(launch_allan_tail(in, sums.d(), t, c->stream));
+    AllanTail t;
+    t.first = fold.nlevels;
+    t.nlevels = levels - fold.nlevels;
+    t.in_stride = t.nlevels > 0 ? lvs[t.first].in_stride : 0;
+    t.nseries = nseries;
+    for (int l = 0; l < t.nlevels; ++l) {
+        t.n_in[l] = lvs[t.first + l].n_in;
+        for (int j = 0; j < 9; ++j) t.nb[l][j] = lvs[t.first + l].nb[j];
     }
-    std::vector<double> h((size_t)9 * nseries * levels);
-    HIP_TRY(hipMemcpyAsync(h.data(), sums.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    // the sums go straight into pinned host memory (83 KB for 192 series x 6 levels): no copy, one synchronisation
+    const size_t nsums = (size_t)9 * nseries * levels;
+    if (c->allan_host_doubles < nsums) {
+        if (c->allan_host) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipHostFree(c->allan_host)); c->allan_host = nullptr; c->allan_host_doubles = 0; }
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->allan_host), sizeof(double) * (nsums + nsums / 4 + 64), hipHostMallocDefault));
+        c->allan_host_doubles = nsums + nsums / 4 + 64;
+    }
+    HIP_TRY(launch_allan_finish(in, partial.d(), c->allan_host, t, fold, nseries, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const double* h = c->allan_host;
     for (int i = 0; i < nt; ++i) {
         const int64_t m = mult[i];
         int k = 0;
