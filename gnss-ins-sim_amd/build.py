@@ -68,8 +68,11 @@ def build(force=False, verbose=False, tag=None, defines=()):
             if verbose:
                 print(' '.join(cmd))
             p = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)
+            if p.returncode != 0:       # show the compiler's own message, not a parse error of its remarks
+                sys.stderr.write('\n'.join(l for l in p.stderr.splitlines() if 'remark:' not in l) + '\n')
+                raise subprocess.CalledProcessError(p.returncode, cmd)
             if src.endswith('.hip'):
-                remarks = [l for l in p.stderr.splitlines() if 'kernel-resource-usage' in l]
+                remarks = [l for l in p.stderr.splitlines() if 'kernel-resource-usage' in l and 'remark:' in l]
                 with open(o[:-2] + '.resources.txt', 'w') as f:
                     f.write('\n'.join(l.split('remark:', 1)[1].replace('[-Rpass-analysis=kernel-resource-usage]', '').strip()
                                       for l in remarks) + '\n')

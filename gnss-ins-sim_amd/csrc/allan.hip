@@ -492,64 +492,64 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ partial
     }
 }
 
-__global__ void __launch_bounds__(64) allan_tail_kernel(const double* __restrict__ in, const double* __restrict__ partial,
-                                                        double* __restrict__ sums, const AllanTail t, const AllanFold f) {
-    __shared__ __attribute__((aligned(16))) double stage[2][kStage];
-    const int lane = threadIdx.x;
+// The levels that fit a chunk, for one series per workgroup of three wavefronts: wavefront 0 first builds the entries of the
+// levels after the first (sums of 10 of the level before: 252, 25, 2 entries at most) in LDS, then every wavefront runs the
+// passes of its own level(s) at the same time -- wavefront w level w, wavefront 2 also the tiny fourth one.  (One wavefront
+// doing the levels one after the other, each producing the next, took 30 us for 1440 / 144 / 14 entries.)
+constexpr int kTailWaves = 3;
+__global__ void __launch_bounds__(64 * kTailWaves) allan_tail_kernel(const double* __restrict__ in, const double* __restrict__ partial,
+                                                                     double* __restrict__ sums, const AllanTail t, const AllanFold f) {
+    __shared__ __attribute__((aligned(16))) double stage[kTailWaves][kStage];
+    __shared__ double lev_store[256 + 32 + 8];          // entries of the second, third and fourth tail level (<= 252, 25, 2)
+    auto lev = [&](int l) -> double* { return lev_store + (l == 0 ? 0 : (l == 1 ? 256 : 288)); };
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t ntail = t.nlevels > 0 ? t.nseries : 0;
     if ((int64_t)blockIdx.x >= ntail) {
+        if (wave != 0) return;
         const int64_t b = (int64_t)blockIdx.x - ntail;
         fold_partials(partial, sums, f, b % t.nseries, (int)(b / t.nseries), t.nseries);
         return;
     }
     const int64_t s = blockIdx.x;
     const double* x = in + s * t.in_stride;
-    int cur = 0;
-    {
-        const int64_t n0 = t.n_in[0];
-        const double shift = x[0];
-        for (int i = lane; i < kStage; i += 64) stage[0][i] = i < n0 ? x[i] - shift : 0.0;
+    if (wave == 0) {
+        // level l+1 entry i = 10 sh + sum_t (E_l[10 i + t] - sh), sh = E_l[0]: the same value the level passes hand on
+        const double* src = x;
+        for (int l = 0; l + 1 < t.nlevels; ++l) {
+            const int64_t n_next = t.n_in[l + 1];
+            const double sh = src[0];
+            for (int i = lane; i < n_next; i += 64) {
+                double acc10 = 0.0;
+#pragma unroll
+                for (int q = 0; q < 10; ++q) acc10 += src[10 * i + q] - sh;
+                lev(l)[i] = __builtin_fma(10.0, sh, acc10);
+            }
+            wave_sync();
+            src = lev(l);
+        }
     }
-    double shift = x[0];
-    for (int l = 0; l < t.nlevels; ++l) {
+    __syncthreads();
+    for (int l = wave; l < t.nlevels; l += kTailWaves) {
+        const double* src = l == 0 ? x : lev(l - 1);
         AllanLevel lv;
         lv.n_in = t.n_in[l];
-        lv.n_out = (l + 1 < t.nlevels) ? t.n_in[l + 1] : 0;
+        lv.n_out = 0;
 #pragma unroll
         for (int j = 0; j < 9; ++j) lv.nb[j] = t.nb[l][j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double shift = src[0];
+        double* w = stage[wave];
+        wave_sync();                                    // my previous level's passes are done with the stage
+        for (int i = lane; i < kStage; i += 64) w[i] = i < lv.n_in ? src[i] - shift : 0.0;
+        wave_sync();
         double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        double* nxt = stage[cur ^ 1];
-        chunk_passes<true>(stage[cur], lane, 0, lv, shift, lv.n_out > 0 ? nxt : nullptr, acc);
+        chunk_passes<true>(w, lane, 0, lv, shift, nullptr, acc);
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             double a = acc[j];
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
             if (lane == 0) sums[((int64_t)(t.first + l) * t.nseries + s) * 9 + j] = a;
-        }
-        if (lv.n_out > 0) {      // the sums of 10 (unshifted) become the next level: shift by its first entry, zero the rest
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            shift = nxt[0];
-            double v[kLoads];
-#pragma unroll
-            for (int q = 0; q < kLoads; ++q) {
-                const int i = q * 64 + lane;
-                v[q] = (i < lv.n_out) ? nxt[i < kStage ? i : 0] - shift : 0.0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int q = 0; q < kLoads; ++q) {
-                const int i = q * 64 + lane;
-                if (i < kStage) nxt[i] = v[q];
-            }
-            cur ^= 1;
         }
     }
 }
@@ -581,7 +581,7 @@ hipError_t launch_allan_pair(const double* in, double* out, double* partial, con
 hipError_t launch_allan_finish(const double* in, const double* partial, double* sums, const AllanTail& t, const AllanFold& f,
                                int64_t nseries, hipStream_t st) {
     const int64_t blocks = (t.nlevels > 0 ? nseries : 0) + nseries * f.nlevels;
-    if (blocks > 0) hipLaunchKernelGGL(allan_tail_kernel, dim3((unsigned)blocks), dim3(64), 0, st, in, partial, sums, t, f);
+    if (blocks > 0) hipLaunchKernelGGL(allan_tail_kernel, dim3((unsigned)blocks), dim3(64 * kTailWaves), 0, st, in, partial, sums, t, f);
     return hipGetLastError();
 }
 
