@@ -409,6 +409,48 @@ def truth_mixed_types():
         print('   mixed rf%d: n = %d, m = %d' % (rf, n, m))
 
 
+def truth_random_profiles():
+    """path_gen on 24 RANDOM motion definitions (seeded): 2-7 segments of command types 1-5 with random rates, speeds,
+    durations (some segments of types 2-5 end early, some run out of time), random mobility limits, sample rates and GPS
+    visibility, both frames.  Sample counts and sampled rows of every output; the native generator must reproduce them."""
+    rng = np.random.RandomState(20260924)
+    cases = []
+    for i in range(24):
+        rf = i % 2
+        fs = float(rng.choice([20.0, 50.0, 100.0, 125.0]))
+        fs_gps = float(rng.choice([1.0, 5.0, 10.0]))
+        ini = np.array([rng.uniform(-60, 60) * D2R, rng.uniform(-170, 170) * D2R, rng.uniform(0, 500),
+                        rng.uniform(0, 25), 0.0, 0.0, rng.uniform(-180, 180) * D2R, rng.uniform(-5, 5) * D2R, rng.uniform(-5, 5) * D2R])
+        segs = []
+        for _ in range(rng.randint(2, 8)):
+            t = int(rng.randint(1, 6))
+            dur = float(rng.uniform(2.0, 20.0))
+            if t == 1:      # rates + accelerations
+                row = [t, rng.uniform(-12, 12), rng.uniform(-2, 2), rng.uniform(-4, 4), rng.uniform(-1.5, 1.5), 0.0, 0.0, dur, rng.randint(0, 2)]
+            elif t in (2, 4):   # absolute attitude (deg), absolute (2) or relative (4) velocity
+                row = [t, rng.uniform(-180, 180), rng.uniform(-8, 8), rng.uniform(-10, 10), rng.uniform(0, 20) if t == 2 else rng.uniform(-4, 4),
+                       0.0, 0.0, dur, rng.randint(0, 2)]
+            else:           # relative attitude change, absolute (5) or relative (3) velocity
+                row = [t, rng.uniform(-90, 90), rng.uniform(-5, 5), rng.uniform(-8, 8), rng.uniform(0, 20) if t == 5 else rng.uniform(-4, 4),
+                       0.0, 0.0, dur, rng.randint(0, 2)]
+            segs.append(row)
+        md = np.array(segs, dtype=np.float64)
+        md[:, 1:4] *= D2R
+        mob = np.array([rng.uniform(0.5, 4.0), rng.uniform(5.0, 40.0) * D2R, rng.uniform(10.0, 90.0) * D2R])
+        output_def = np.array([[1.0, fs], [1.0, fs_gps], [1.0, fs]])
+        r = pathgen.path_gen(ini.copy(), md.copy(), output_def, mob.copy(), ref_frame=rf, magnet=False)
+        n, m = r['imu'].shape[0], r['gps'].shape[0]
+        k, kg = rows(n, max(1, n // 40)), rows(m, max(1, m // 10))
+        cases.append(dict(rf=rf, fs=fs, fs_gps=fs_gps, ini=ini, md=md, mob=mob, n=n, m=m, k=k, kg=kg,
+                          imu=r['imu'][k], nav=r['nav'][k], gps=r['gps'][kg], odo=r['odo'][k]))
+        print('   random %2d: rf %d fs %5.1f segments %d types %s -> n = %d, m = %d' % (i, rf, fs, len(segs), sorted(set(int(x[0]) for x in segs)), n, m))
+    out = {'count': len(cases)}
+    for i, c in enumerate(cases):
+        for key, v in c.items():
+            out['c%02d_%s' % (i, key)] = v
+    save('truth_random_profiles', **out)
+
+
 def allan_case():
     n, fs = 360000, 100.0
     x = 0.3 * philox.normal_pair(SEED, 7, 5, np.arange(n, dtype=np.uint64))[0] \
@@ -449,4 +491,5 @@ if __name__ == '__main__':
     allan_case()
     t2_long_drive()
     truth_mixed_types()
+    truth_random_profiles()
     t4_reference_statistics()

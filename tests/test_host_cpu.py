@@ -233,3 +233,26 @@ def test_hot_kernels_keep_two_wavefronts_per_simd():
         assert agpr == 0, '%s parks %d registers in AGPRs' % (name, agpr)
         assert scratch <= (128 if two_algos else 32), '%s: %d bytes of scratch per lane' % (name, scratch)
     assert checked >= 40, checked
+
+
+def test_native_pathgen_random_profiles_vs_reference():
+    """24 random motion definitions (2-7 segments of command types 1-5, random mobility limits, 20-125 Hz, GPS at 1-10 Hz with
+    random visibility, both frames) executed by the unmodified reference (tests/golden/make_golden.py
+    truth_random_profiles): the native generator gives the same sample counts -- the segment-completion tests are threshold
+    compares, a different rounding anywhere would change n -- and the same rows."""
+    import ginsim
+    g = load_golden('truth_random_profiles')
+    worst = 0.0
+    for i in range(int(g['count'])):
+        c = {k[4:]: g[k] for k in g if k.startswith('c%02d_' % i)}
+        r = ginsim.pathgen(c['ini'], c['md'], float(c['fs']), float(c['fs_gps']), c['mob'], int(c['rf']), gps=True)
+        assert r['imu'].shape[0] == int(c['n']) and r['gps'].shape[0] == int(c['m']), (i, r['imu'].shape, int(c['n']), r['gps'].shape, int(c['m']))
+        k, kg = c['k'], c['kg']
+        # measured: nav / gps / odo identical to the last bit, imu within 3.6e-15 (one ulp of its terms)
+        np.testing.assert_allclose(r['imu'][k], c['imu'], rtol=0, atol=2e-14, err_msg='profile %d imu' % i)
+        assert np.array_equal(r['nav'][k], c['nav']), 'profile %d nav' % i
+        if int(c['m']):
+            assert np.array_equal(r['gps'][kg], c['gps']), 'profile %d gps' % i
+        assert np.array_equal(r['odo'][k], c['odo']), 'profile %d odo' % i
+        worst = max(worst, float(np.abs(r['imu'][k] - c['imu']).max()))
+    assert worst < 2e-14
