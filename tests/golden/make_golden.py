@@ -114,6 +114,37 @@ def t1_fixture(name):
     t1_run(name, ini, gyro, accel, 10)
 
 
+def t1_rates():
+    """Both plugins as the host calls them (FreeIntegration.run(set_of_input), free_integration.py:63-174 and
+    free_integration_odo.py:63-160) on band-limited random sensor records at 50, 200 and 400 Hz (the other given-data
+    fixtures are all 100 Hz), both frames, with and without Earth rotation / external gravity."""
+    rng = np.random.RandomState(77)
+    out = {}
+    for ci, fs in enumerate((50.0, 200.0, 400.0)):
+        n = 1600
+        t = np.arange(n) / fs
+        def band(scale, m=4):
+            f = rng.uniform(0.05, 2.0, size=(m, 3))
+            ph = rng.uniform(0, 2 * np.pi, size=(m, 3))
+            amp = rng.uniform(0.2, 1.0, size=(m, 3)) * scale
+            return sum(amp[k] * np.sin(2 * np.pi * f[k] * t[:, None] + ph[k]) for k in range(m))
+        gyro = band(8.0 * D2R)
+        accel = band(0.4) + np.array([0.0, 0.0, -9.79])
+        odo = 6.0 + band(1.5)[:, 0]
+        ini = np.array([rng.uniform(-50, 50) * D2R, rng.uniform(-170, 170) * D2R, rng.uniform(0, 300), rng.uniform(2, 12), 0.0, 0.0,
+                        rng.uniform(-180, 180) * D2R, rng.uniform(-4, 4) * D2R, rng.uniform(-4, 4) * D2R, 9.79 + rng.uniform(-0.01, 0.01)])
+        k = rows(n, 16)
+        key = 'c%d_' % ci
+        out.update({key + 'fs': fs, key + 'ini': ini, key + 'gyro': gyro, key + 'accel': accel, key + 'odo': odo, key + 'rows': k})
+        for tag, rf, use_g, erot in (('extg', 0, True, False), ('wgs', 0, False, True), ('rf1', 1, False, True)):
+            for plug, mod, series in (('free', free_integration, accel), ('odo', free_integration_odo, odo)):
+                algo = mod.FreeIntegration(ini.copy() if use_g else ini[0:9].copy(), earth_rot=erot)
+                algo.run([rf, fs, gyro.copy(), series.copy()])
+                att, pos, vel = algo.get_results()
+                out.update({key + '%s_%s_att' % (plug, tag): att[k], key + '%s_%s_pos' % (plug, tag): pos[k], key + '%s_%s_vel' % (plug, tag): vel[k]})
+    save('t1_rates', count=3, **out)
+
+
 def t1_tumble():
     """Synthetic body rates that drive the pitch through +-90 deg (the fold of attitude.euler_update_zyx,
     attitude.py:700-712) and yaw / roll through +-180 deg (the single 2 pi wrap, :713-720) several times.
@@ -469,6 +500,7 @@ if __name__ == '__main__':
     emit_profile(MOTION + 'motion_def-long_drive.csv', prof + '/long_drive.csv', 'long drive, <=1410 s')
     emit_profile(MOTION + 'motion_def-Allan.csv', prof + '/static_1800s.csv', 'static, 1800 s')
     t1_tumble()
+    t1_rates()
     t1_fixture('bosch')
     t1_fixture('nxp')
     t2_turn(1)

@@ -101,6 +101,24 @@ def test_t1_given_data_fixture(ctx, name):
                           rtol=1e-10, what=name + tag)
 
 
+def test_t1_both_plugins_at_other_rates(ctx):
+    """The plugins' given-data boundary (ginsim_free_integration, both algorithms) at 50 / 200 / 400 Hz on random band-limited
+    records, both frames, external gravity / Earth rotation: what the unmodified reference's run(set_of_input) returned."""
+    import ginsim
+    g = load_golden('t1_rates')
+    for ci in range(int(g['count'])):
+        c = {k[3:]: g[k] for k in g if k.startswith('c%d_' % ci)}
+        k = c['rows']
+        for tag, rf, use_g, erot in (('extg', 0, True, False), ('wgs', 0, False, True), ('rf1', 1, False, True)):
+            ini = c['ini'] if use_g else c['ini'][:9]
+            for plug in ('free', 'odo'):
+                att, pos, vel = ginsim.free_integration_host(ctx, plug, rf, float(c['fs']), c['gyro'],
+                                                             accel=c['accel'] if plug == 'free' else None,
+                                                             odo=c['odo'] if plug == 'odo' else None, ini=ini, earth_rot=erot)
+                assert_traj_close(att[k], pos[k], vel[k], c['%s_%s_att' % (plug, tag)], c['%s_%s_pos' % (plug, tag)],
+                                  c['%s_%s_vel' % (plug, tag)], rtol=1e-10, what='%s %s %g Hz' % (plug, tag, float(c['fs'])))
+
+
 def _truth_from_pathgen(g, rf, fs=100.0, gps=False):
     import ginsim
     r = ginsim.pathgen(g['ini_pva'], g['motion_def'], fs, 10.0, g['mobility'], rf, gps=gps)

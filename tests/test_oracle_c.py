@@ -81,3 +81,13 @@ def test_c_allan():
     avar, tau = c_oracle.allan_var(x, fs)
     np.testing.assert_allclose(tau, g['tau'], rtol=1e-15)
     np.testing.assert_allclose(avar, g['avar'], rtol=1e-10)
+
+
+def test_c_t1_both_plugins_at_other_rates():
+    from test_oracle_golden import _t1_rates_cases
+    for c, tag, rf, ini, erot, plug in _t1_rates_cases():
+        k = c['rows']
+        att, pos, vel = c_oracle.free_integration(rf, float(c['fs']), c['gyro'], c['accel'] if plug == 'free' else None, ini,
+                                                  earth_rot=erot, odo=c['odo'] if plug == 'odo' else None)
+        assert_traj_close(att[k], pos[k], vel[k], c['%s_%s_att' % (plug, tag)], c['%s_%s_pos' % (plug, tag)],
+                          c['%s_%s_vel' % (plug, tag)], rtol=1e-11, what='%s %s %g Hz' % (plug, tag, float(c['fs'])))

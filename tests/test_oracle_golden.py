@@ -231,3 +231,22 @@ def test_t3_magnetometer_and_gps_models(rf):
     gps = ins_np.gps_errors(g['ref_gps'], {'stdp': g['gps_stdp'], 'stdv': g['gps_stdv']}, rf,
                             np.stack([a for a, _ in z]), np.stack([b for _, b in z]))
     np.testing.assert_allclose(gps, g['gps'], rtol=1e-14, atol=1e-12)
+
+
+def _t1_rates_cases():
+    g = load_golden('t1_rates')
+    for ci in range(int(g['count'])):
+        c = {k[3:]: g[k] for k in g if k.startswith('c%d_' % ci)}
+        for tag, rf, use_g, erot in (('extg', 0, True, False), ('wgs', 0, False, True), ('rf1', 1, False, True)):
+            for plug in ('free', 'odo'):
+                yield c, tag, rf, (c['ini'] if use_g else c['ini'][:9]), erot, plug
+
+
+def test_t1_both_plugins_at_other_rates():
+    """FreeIntegration.run of both plugins at 50 / 200 / 400 Hz on random band-limited records (reference-executed golden)."""
+    for c, tag, rf, ini, erot, plug in _t1_rates_cases():
+        k = c['rows']
+        att, pos, vel = ins_np.free_integration(rf, float(c['fs']), c['gyro'][None], c['accel'][None] if plug == 'free' else None, ini,
+                                                earth_rot=erot, odo=c['odo'][None] if plug == 'odo' else None)
+        assert_traj_close(att[0][k], pos[0][k], vel[0][k], c['%s_%s_att' % (plug, tag)], c['%s_%s_pos' % (plug, tag)],
+                          c['%s_%s_vel' % (plug, tag)], rtol=1e-11, what='%s %s %g Hz' % (plug, tag, float(c['fs'])))
