@@ -220,6 +220,15 @@ def t2_long_drive():
 
 
 # ------------------------------------------------------------------ T3: injected noise, end to end
+DRIVE = """ini lat (deg),ini lon (deg),ini alt (m),ini vx_body (m/s),ini vy_body (m/s),ini vz_body (m/s),ini yaw (deg),ini pitch (deg),ini roll (deg)
+-33.9,151.2,55,4,0,0,-120,0,0
+command type,yaw (deg),pitch (deg),roll (deg),vx_body (m/s),vy_body (m/s),vz_body (m/s),command duration (s),GPS visibility
+1,0,0,0,0.8,0,0,5,1
+5,45,0,0,12,0,0,8,1
+1,0,0,0,0,0,0,3,0
+3,-30,2,0,-3,0,0,6,1
+"""
+
 DEMO_IMU = {'gyro_b': np.array([0.0, 0.0, 0.0]),
             'gyro_arw': np.array([0.25, 0.25, 0.25]),
             'gyro_b_stability': np.array([3.5, 3.5, 3.5]),
@@ -234,17 +243,28 @@ def err_dict_arrays(prefix, e):
     return {prefix + k: np.array(v, dtype=np.float64) for k, v in e.items()}
 
 
-def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=6):
-    csv = MOTION + 'motion_def-90deg_turn.csv'
+def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=6, csv=None, fs=100.0):
+    """csv: a motion definition as text (default: the reference's 90-degree turn file, n = 1000 at 100 Hz)."""
+    if csv is None:
+        csv = MOTION + 'motion_def-90deg_turn.csv'
+        ini = read_ini(csv)
+        n, m = 1000, (100 if gps else 0)
+    else:
+        text = csv.strip().split('\n')
+        ini = np.array([float(v) for v in text[1].split(',')])
+        ini[0:2] *= D2R
+        ini[6:9] *= D2R
+        probe = ins_sim.Sim([fs, fs_gps, 0.0], csv, ref_frame=ref_frame, imu=None)
+        ini_pva, motion_def = probe._Sim__parse_motion()
+        r = pathgen.path_gen(ini_pva.copy(), motion_def.copy(), np.array([[1.0, fs], [1.0, fs_gps], [1.0, fs]]),
+                             probe._Sim__parse_mode(None), ref_frame=ref_frame, magnet=False)
+        n, m = r['imu'].shape[0], (r['gps'].shape[0] if gps else 0)
     imu = imu_model.IMU(accuracy=accuracy, axis=axis, gps=gps, odo=odo_opt is not None, odo_opt=odo_opt)
-    ini = read_ini(csv)
     objs = []
     for a in algos:
         mod = free_integration_odo if a == 'odo' else free_integration
         objs.append(mod.FreeIntegration(ini.copy()))
-    sim = ins_sim.Sim([100.0, fs_gps, 0.0], csv, ref_frame=ref_frame, imu=imu, algorithm=objs)
-    n = 1000
-    m = 100 if gps else 0
+    sim = ins_sim.Sim([fs, fs_gps, 0.0], csv, ref_frame=ref_frame, imu=imu, algorithm=objs)
     shim = RandnShim(SEED, n, imu.accel_err['b_corr'], imu.gyro_err['b_corr'], gps_m=m, mag=(axis == 9),
                      odo=odo_opt is not None)
     with injected(shim):
@@ -252,7 +272,7 @@ def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=
     assert shim.run == R and not shim.queue
     d = sim.dmgr
     k = rows(n, 25)
-    out = dict(seed=SEED, R=R, fs=100.0, n=n, rows=k, ref_frame=ref_frame,
+    out = dict(seed=SEED, R=R, fs=fs, n=n, rows=k, ref_frame=ref_frame,
                ref_pos=d.ref_pos.data, ref_vel=d.ref_vel.data, ref_att=d.ref_att_euler.data,
                ref_accel=d.ref_accel.data, ref_gyro=d.ref_gyro.data, ini=ini)
     out.update(err_dict_arrays('accel_', imu.accel_err))
@@ -518,6 +538,7 @@ if __name__ == '__main__':
                  'mag_hi': np.array([5.0, -8.0, 12.0]), 'mag_std': np.array([0.2, 0.1, 0.3])})
     for rf in (0, 1):
         t3_case('t3_mag9_gps_rf%d' % rf, rf, dict(mag9), True, None, ['fi'], 2, fs_gps=10.0, axis=9)
+    t3_case('t3_drive200_rf0', 0, 'low-accuracy', True, {'scale': 0.998, 'stdv': 0.05}, ['fi', 'odo'], 2, fs_gps=5.0, csv=DRIVE, fs=200.0)
     csv_case()
     summary_case()
     allan_case()

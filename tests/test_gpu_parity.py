@@ -159,7 +159,7 @@ def _errs(g):
     return acc, gyr
 
 
-@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0'])
+@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'])
 def test_t3_injected_noise_vs_reference(ctx, name):
     """Unmodified reference Sim.run(R) fed the engine's Philox normals == fused kernel, per sample."""
     import ginsim

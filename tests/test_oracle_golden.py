@@ -149,7 +149,7 @@ def _errs(g):
     return acc, gyr
 
 
-@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0'])
+@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'])
 def test_t3_injected_noise_end_to_end(name):
     g = load_golden(name)
     R, k, fs, rf = int(g['R']), g['rows'], float(g['fs']), int(g['ref_frame'])

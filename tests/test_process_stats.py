@@ -5,7 +5,7 @@ import pytest
 
 from conftest import load_golden
 
-CASES = ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0']
+CASES = ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0']
 
 
 def _errs(g):
@@ -17,7 +17,7 @@ def _errs(g):
 def _algos(g):
     # run keys are 'algo<i>_<r>' in the order the case listed its algorithms
     order = {'t3_demo_rf1': ['odo', 'free'], 't3_mid_rf0': ['free'], 't3_white_gps_rf0': ['free', 'odo'],
-             't3_low_rf1': ['free'], 't3_high_odo_rf0': ['odo', 'free']}
+             't3_low_rf1': ['free'], 't3_high_odo_rf0': ['odo', 'free'], 't3_drive200_rf0': ['free', 'odo']}
     return order
 
 
