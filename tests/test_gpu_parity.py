@@ -277,7 +277,7 @@ def test_full_size_properties(ctx):
     np.testing.assert_allclose(st.mean, np.mean(e, 0), rtol=1e-8, atol=1e-14)
 
 
-@pytest.mark.parametrize('name', ['t3_mag9_gps_rf0', 't3_mag9_gps_rf1', 't3_white_gps_rf0'])
+@pytest.mark.parametrize('name', ['t3_mag9_gps_rf0', 't3_mag9_gps_rf1', 't3_white_gps_rf0', 't3_drive200_rf0'])
 def test_gps_and_magnetometer_error_models_vs_reference(ctx, name):
     """pathgen.gps_gen / mag_gen on the device == the unmodified reference fed the same normals."""
     import ginsim
