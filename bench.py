@@ -62,11 +62,22 @@ def roofline(alg_bytes, ms, kernel, traffic=None, **extra):
     return out
 
 
+WARM_MS = 40.0      # launches of one kernel get faster for the first 20-30 ms of back-to-back execution (clock / power
+                    # management settling: 1.65 -> 1.38 ms for the fused kernel, 0.61 -> 0.56 ms for the Allan call); the
+                    # headline has its --warmup steps, the legs warm up by TIME
+
+
 def time_launches(ctx, launch, reps, warm=2):
     """(average, minimum) HIP-event time of `reps` launches issued BACK TO BACK on the context's stream, as the timed
-    region of the headline issues them: an event pair around every launch, no host synchronisation in between."""
-    for _ in range(warm):
+    region of the headline issues them: an event pair around every launch, no host synchronisation in between.
+    Untimed warm-up first: `warm` launches, and more until WARM_MS of kernel time have gone by (40 launches at most)."""
+    spent, done = 0.0, 0
+    while done < warm or (warm > 0 and spent < WARM_MS and done < 40):
+        ctx.event_record(0)
         launch()
+        ctx.event_record(1)
+        spent += ctx.event_elapsed(0, 1)
+        done += 1
     for i in range(reps):
         ctx.event_record(2 * i)
         launch()
@@ -257,9 +268,10 @@ def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0):
     tmp = ctx.malloc(8 * S * n)
     for i, nm in enumerate(('accel', 'gyro')):
         check(ginsim.lib.ginsim_runs_to_series(ctx.handle, job.buffer(nm).ptr, 3, n, runs, tmp.at(i * 24 * n * runs)))
-    ginsim.allan_var(ctx, tmp, n, S, n, fs)
+    for _ in range(40):         # warm-up: the call settles after ~30 of them (WARM_MS)
+        ginsim.allan_var(ctx, tmp, n, S, n, fs)
     ms = []
-    for _ in range(8):          # every call ends with the copy of the sums to the host: the calls cannot overlap
+    for _ in range(30):         # every call ends with a synchronisation (the sums are on the host): the calls cannot overlap
         ctx.timer_begin()
         ginsim.allan_var(ctx, tmp, n, S, n, fs)
         ms.append(ctx.timer_end())
@@ -273,7 +285,7 @@ def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0):
                        'of %d series, %d averaging factors' % (seconds, fs, n, runs, S, tau.size),
            'sensor_generation_ms': gen_ms, 'relayout_plus_allan_wall_ms': e2e_wall_ms, 'allan_call_ms_min': min(ms),
            'samples_per_s_allan_call': S * n / avg * 1e3,
-           'roofline': roofline(8.0 * S * n, avg, 'ginsim_allan (allan_level_kernel + tail, whole call incl. the copy of the sums)', None),
+           'roofline': roofline(8.0 * S * n, avg, 'ginsim_allan (allan_pair_kernel x3 + allan_tail_kernel: the whole call, up to the synchronisation that returns the sums)', None),
            'result': {'ad_gyro_x_at_1s_over_arw': float(ad['gyro'][:, k1, 0].mean() / arw * np.sqrt(tau[k1]))}}
     job.release()
     return out
@@ -284,7 +296,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--runs-per-gpu', type=int, default=0, help='default: 65 536 at N = 1 (C2), 131 072 at N > 1 (C4)')
     ap.add_argument('--profile', default='turn_90deg')
     ap.add_argument('--fs', type=float, default=100.0)

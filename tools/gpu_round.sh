@@ -25,7 +25,7 @@ for l in d.get("configs", []):
 PY
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py --pmc-child"
-# the default command (200 + 10 steps, all legs) under the kernel trace: per-kernel averages that must agree with the HIP events
+# the default command (200 timed + 30 warm-up steps, all legs) under the kernel trace: per-kernel averages that must agree with the HIP events
 rocprofv3 --kernel-trace --stats -d $OUT/prof_trace -o bench -- python $ROOT/bench.py --cpu-baseline-seconds 0 --pmc off > $OUT/prof_trace.json 2> $OUT/prof_trace.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/prof_pmc_write -o bench -- $B > $OUT/prof_pmc_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_pmc_fetch -o bench -- $B > $OUT/prof_pmc_fetch.log 2>&1

@@ -50,7 +50,7 @@ total = sum(r[2] for r in rows)
 with open(os.path.join(DST, tag + '_kernel_trace_stats.csv'), 'w', newline='') as f:
     w = csv.writer(f)
     w.writerow([stamp])
-    w.writerow(['# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-baseline-seconds 0 --pmc off   (200 timed + 10 warm-up steps, all legs)'])
+    w.writerow(['# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-baseline-seconds 0 --pmc off   (200 timed + 30 warm-up steps, all legs)'])
     w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'min_ns', 'max_ns', 'percent', 'vgpr', 'sgpr', 'lds_bytes', 'grid_x', 'workgroup_x'])
     for r in rows:
         w.writerow([r[0], r[1], int(r[2]), int(r[3]), int(r[4]), int(r[5]), '%.2f' % (100.0 * r[2] / total)] + list(r[6:]))
