@@ -430,8 +430,15 @@ constexpr size_t kSplitLds = kSplitRing > 100 * 1024 ? kSplitRing : 100 * 1024;
 
 // PROD producer wavefronts per consumer wavefront: with two (768 threads, three wavefronts per SIMD, <= 168 registers) the
 // steps of a tile alternate between the two producer groups.
-template <int RF, int ALGOS, bool WD, int PROD = 1>
-__global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim_mc_params a) {
+// KEEP = false: a statistics-only launch (no series pointer set): the store code and its address registers are compiled out,
+// which is what lets the ref_frame 0 consumer fit the 168 registers of three wavefronts per SIMD.
+template <int RF, int ALGOS, bool WD, int PROD = 1, bool KEEP = true>
+__global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim_mc_params a_in) {
+    ginsim_mc_params a = a_in;
+    if (!KEEP) {
+        a.out_accel = a.out_gyro = a.out_odo = nullptr;
+        a.out_traj[0] = a.out_traj[1] = nullptr;
+    }
     extern __shared__ float zring[];                    // [2 stages][T steps][12 normals][256 runs]
     constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
     constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
@@ -598,6 +605,19 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream) {
             }();
             (void)once;
             const dim3 sgrid((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns));
+            if constexpr (ALGOS == GINSIM_ALGO_FREE && RF == 0) {     // nothing kept: two producer groups fit here too
+                const bool keep = p.out_accel || p.out_gyro || p.out_odo || p.out_traj[0] || p.out_traj[1];
+                if (!keep && prod != 1) {
+                    static bool once2 = [] {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 2, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
+                        return true;
+                    }();
+                    (void)once2;
+                    hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD, 2, false>), sgrid, dim3(768), kSplitLds, stream, p);
+                    return hipGetLastError();
+                }
+            }
             if (prod == PROD && PROD > 1)
                 hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD, PROD>), sgrid, dim3(256 * (1 + PROD)), kSplitLds, stream, p);
             else

@@ -426,8 +426,12 @@ class MonteCarloJob(object):
         wd = (not p.given_sensors) and (ps != 0 or (p.ref_frame == 0 and p.algo_mask == 3) or any(
             p.accel.white_drift[k] or p.gyro.white_drift[k] or p.accel.bias[k] != 0.0 or p.gyro.bias[k] != 0.0 for k in range(3)))
         if v.value:     # one algorithm: two producer wavefronts per consumer (csrc/mc_kernel.hip, launch3)
-            prod = 2 if p.algo_mask == 1 and p.ref_frame == 1 and os.environ.get('GINSIM_SPLIT_PROD', '2') == '2' else 1
-            return 'ginsim::mc_kernel_split<%d, %d, %s, %d>' % (p.ref_frame, p.algo_mask, 'true' if wd else 'false', prod)
+            two = p.algo_mask == 1 and os.environ.get('GINSIM_SPLIT_PROD', '2') != '1'
+            kept = bool(p.out_accel or p.out_gyro or p.out_odo or p.out_traj[0] or p.out_traj[1])
+            if two and p.ref_frame == 0 and not kept:       # the statistics-only variant of ref_frame 0
+                return 'ginsim::mc_kernel_split<0, 1, %s, 2, false>' % ('true' if wd else 'false')
+            prod = 2 if two and p.ref_frame == 1 else 1
+            return 'ginsim::mc_kernel_split<%d, %d, %s, %d, true>' % (p.ref_frame, p.algo_mask, 'true' if wd else 'false', prod)
         return 'ginsim::mc_kernel<%d, %d, %s, %s, %d>' % (p.ref_frame, p.algo_mask, 'true' if p.given_sensors else 'false',
                                                           'true' if wd else 'false', ps)
 

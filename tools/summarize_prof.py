@@ -111,5 +111,5 @@ print(json.dumps(summary, indent=1))
 for kn, c in pmc.items():
     if 'mc_kernel_split' in kn and 'SQ_INSTS_VALU' in c and 'SQ_WAVES' in c:
         steps = 1000.0
-        groups = c['SQ_WAVES'][1] / (3.0 if kn.rstrip().endswith('2>(ginsim_mc_params)') else 2.0)
+        groups = c['SQ_WAVES'][1] / (3.0 if (', 2, true>' in kn or ', 2, false>' in kn) else 2.0)     # PROD = 2: three wavefronts per 64 runs
         print('%s: VALU per step and 64 runs = %.1f' % (kn[:60], c['SQ_INSTS_VALU'][1] / groups / steps))
