@@ -185,6 +185,22 @@ int ginsim_malloc(ginsim_ctx* c, size_t bytes, void** dptr) {
     return GINSIM_OK;
 }
 
+int ginsim_host_alloc(ginsim_ctx* c, size_t bytes, void** hptr) {
+    REQUIRE(c && hptr, "host_alloc: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostMalloc(hptr, bytes ? bytes : 8, hipHostMallocDefault));
+    return GINSIM_OK;
+}
+
+int ginsim_host_free(ginsim_ctx* c, void* hptr) {
+    REQUIRE(c, "host_free: NULL context");
+    if (!hptr) return GINSIM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipHostFree(hptr));
+    return GINSIM_OK;
+}
+
 int ginsim_free(ginsim_ctx* c, void* dptr) {
     REQUIRE(c, "free: NULL context");
     if (!dptr) return GINSIM_OK;

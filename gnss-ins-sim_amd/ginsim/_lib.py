@@ -76,6 +76,8 @@ _SIGS = {
     'ginsim_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     'ginsim_memcpy_d2h': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     'ginsim_memset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    'ginsim_host_alloc': (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    'ginsim_host_free': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ginsim_sync': (C.c_int, [C.c_void_p]),
     'ginsim_timer_begin': (C.c_int, [C.c_void_p]),
     'ginsim_timer_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

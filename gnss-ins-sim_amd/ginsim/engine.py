@@ -584,10 +584,28 @@ class AuxSensorJob(object):
         self._bufs = {}
 
 
+def pinned_empty(ctx, shape, dtype=np.float64):
+    """An uninitialised NumPy array in page-locked host memory (ginsim_host_alloc): host-buffer calls on such arrays copy
+    at the link rate.  The memory is released when the array (and every view of it) is gone."""
+    import weakref
+    shape = tuple(int(v) for v in np.atleast_1d(shape))
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    check(lib.ginsim_host_alloc(ctx.handle, max(nbytes, 8), C.byref(p)))
+    raw = (C.c_char * max(nbytes, 8)).from_address(p.value)
+    arr = np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    handle, addr = ctx.handle, p.value
+    weakref.finalize(raw, lambda: lib.ginsim_host_free(handle, C.c_void_p(addr)))
+    return arr
+
+
 def free_integration_host(ctx, algo, ref_frame, fs, gyro, accel=None, odo=None, ini=None, earth_rot=True,
-                          ini_first=0):
+                          ini_first=0, pinned_out=False, out=None):
     """Given-data mechanisation through ginsim_free_integration (host buffers in, host buffers out).
-    gyro/accel (R,n,3) or (n,3); odo (R,n) or (n,).  Returns att, pos, vel with gyro's leading shape."""
+    gyro/accel (R,n,3) or (n,3); odo (R,n) or (n,).  Returns att, pos, vel with gyro's leading shape.
+    pinned_out: the three results in page-locked memory (pinned_empty); inputs made with pinned_empty are used as they are.
+    out: (att, pos, vel) arrays of shape (R, n, 3) to write into (e.g. page-locked ones kept across calls: locking pages costs
+    about what it saves on ONE copy)."""
     g = np.asarray(gyro, dtype=np.float64)
     single = g.ndim == 2
     g = np.ascontiguousarray(g.reshape((-1,) + g.shape[-2:]))
@@ -595,7 +613,14 @@ def free_integration_host(ctx, algo, ref_frame, fs, gyro, accel=None, odo=None, 
     a = None if accel is None else np.ascontiguousarray(np.asarray(accel, dtype=np.float64).reshape(R, n, 3))
     o = None if odo is None else np.ascontiguousarray(np.asarray(odo, dtype=np.float64).reshape(R, n))
     table, has_g = ini_table(ini)
-    att, pos, vel = np.empty((R, n, 3)), np.empty((R, n, 3)), np.empty((R, n, 3))
+    if out is not None:
+        att, pos, vel = out
+        for v in out:
+            if v.shape != (R, n, 3) or v.dtype != np.float64 or not v.flags['C_CONTIGUOUS']:
+                raise ValueError('out: three C-contiguous float64 arrays of shape (%d, %d, 3)' % (R, n))
+    else:
+        new = (lambda: pinned_empty(ctx, (R, n, 3))) if pinned_out else (lambda: np.empty((R, n, 3)))
+        att, pos, vel = new(), new(), new()
     check(lib.ginsim_free_integration(ctx.handle, ALGO_BITS[algo], int(ref_frame), float(fs), int(bool(earth_rot)),
                                       dptr(g), dptr(a), dptr(o), R, n, dptr(table), table.shape[0], int(has_g),
                                       int(ini_first), dptr(att), dptr(pos), dptr(vel)))

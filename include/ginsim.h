@@ -43,6 +43,11 @@ int  ginsim_free(ginsim_ctx* ctx, void* dptr);
 int  ginsim_memcpy_h2d(ginsim_ctx* ctx, void* dst, const void* src, size_t bytes);
 int  ginsim_memcpy_d2h(ginsim_ctx* ctx, void* dst, const void* src, size_t bytes);
 int  ginsim_memset(ginsim_ctx* ctx, void* dptr, int value, size_t bytes);
+/* Page-locked host memory for callers of the host-buffer entry points (ginsim_free_integration, ginsim_memcpy_*): copies from
+ * and to such buffers run at the link rate instead of through the driver's staging of pageable memory.  The reference has
+ * no counterpart (its arrays are plain NumPy); the Python layer wraps it as ginsim.pinned_empty(). */
+int  ginsim_host_alloc(ginsim_ctx* ctx, size_t bytes, void** hptr);
+int  ginsim_host_free(ginsim_ctx* ctx, void* hptr);
 int  ginsim_sync(ginsim_ctx* ctx);
 /* HIP-event timer on the context's stream (the stream every kernel of this context is launched on). */
 int  ginsim_timer_begin(ginsim_ctx* ctx);

@@ -283,3 +283,25 @@ def test_time_parallel_sensor_series_match_oracle_and_lane_per_run_kernel(ctx, r
         np.testing.assert_allclose(g_dev, big.sensors('gyro', pick), rtol=0, atol=2e-16)
     big.release()
     job.release()
+
+
+def test_pinned_host_buffers(ctx):
+    """ginsim.pinned_empty (ginsim_host_alloc): page-locked NumPy arrays in and out of the host-buffer boundary give the
+    same bits as pageable ones, and are released with the array."""
+    import gc
+    import ginsim
+    g = load_golden('t1_fixture_bosch')
+    gyro, accel = ginsim.pinned_empty(ctx, (8,) + g['gyro'].shape), ginsim.pinned_empty(ctx, (8,) + g['accel'].shape)
+    assert gyro.flags['C_CONTIGUOUS'] and gyro.dtype == np.float64 and gyro.shape == (8, g['gyro'].shape[0], 3)
+    gyro[...] = g['gyro']
+    accel[...] = g['accel']
+    a0 = ginsim.free_integration_host(ctx, 'free', 1, float(g['fs']), np.array(gyro), np.array(accel), ini=g['ini'][:9])
+    a1 = ginsim.free_integration_host(ctx, 'free', 1, float(g['fs']), gyro, accel, ini=g['ini'][:9], pinned_out=True)
+    for x, y in zip(a0, a1):
+        np.testing.assert_array_equal(x, y)
+    view = a1[0][3]
+    del a1, gyro, accel
+    gc.collect()
+    assert np.isfinite(view).all()          # a view keeps the pinned block alive
+    small = ginsim.pinned_empty(ctx, 0)
+    assert small.size == 0
