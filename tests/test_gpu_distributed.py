@@ -46,6 +46,30 @@ def test_bench_two_ranks_share_the_work():
     assert two['value'] > 0 and 'roofline' in two and 'cpu_baseline' not in two
 
 
+def test_bench_line_contract():
+    """The ONE JSON line the driver reads: every field of the contract, on the C2 workload at its real size (few steps), with
+    a short CPU-baseline sample and one leg-free pass; the roofline object must be consistent with itself."""
+    d = _bench(1, ['--steps', '5', '--warmup', '3', '--cpu-baseline-seconds', '1', '--no-legs', '--pmc', 'off'])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 5 and d['warmup'] == 3 and d['higher_is_better'] is True and d['vs_baseline'] is None
+    assert d['dtype'] == 'f64' and d['data'] == 'synthetic' and d['scaling'] == 'weak' and d['unit'] == 'sample*MC/s'
+    assert 'workload' in d['config'] and 'configs[1]' in d['config']['workload'] and 'model' not in d['config']
+    assert d['config']['runs_per_gpu'] == 65536 and d['config']['samples_per_run'] == 1000
+    # value = units of all timed steps / wall time
+    np.testing.assert_allclose(d['value'], 65536 * 1000 / (d['ms_per_step'] * 1e-3), rtol=1e-6)
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and r['traffic'] is None      # --pmc off
+    assert r['algorithmic_bytes_per_launch'] == 120 * 65536 * 1000 + 72 * 65536
+    np.testing.assert_allclose(r['achieved'], r['algorithmic_bytes_per_launch'] / (r['kernel_ms_avg'] * 1e-3) / 1e9, rtol=1e-9)
+    np.testing.assert_allclose(r['frac'], r['achieved'] / r['peak'], rtol=1e-12)
+    assert 0.3 < r['frac'] < 0.95 and r['kernel_ms_avg'] < d['ms_per_step'] and 'mc_kernel' in r['kernel']
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['unit'] == 'sample*MC/s' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
+    assert c['reference_python']['kind'] in ('quoted', 'reference') and c['reference_python']['cores'] == 1
+
+
 def test_rccl_exchange_executes_on_one_gpu():
     """The box has one GPU, so the 8-rank RCCL run cannot happen here -- but its code path can: backend 'nccl' (= RCCL) with a
     one-rank communicator executes communicator set-up, the device-tensor all-reduce of the statistics table, the
