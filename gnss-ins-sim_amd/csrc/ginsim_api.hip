@@ -25,8 +25,8 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 
-hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream);
-hipError_t launch_mc_f32(const ginsim_mc_params& p, hipStream_t stream);
+hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap);      // name: report, do not launch
+hipError_t launch_mc_f32(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap);
 int mc_variant(const ginsim_mc_params& p);
 bool series_path_applies(const ginsim_mc_params& p);
 int64_t series_chunks(const ginsim_mc_params& p, int32_t* L_out);
@@ -193,10 +193,13 @@ int ginsim_host_alloc(ginsim_ctx* c, size_t bytes, void** hptr) {
 }
 
 int ginsim_host_free(ginsim_ctx* c, void* hptr) {
-    REQUIRE(c, "host_free: NULL context");
+    // c may be NULL: page-locked arrays handed to a caller can outlive the context that allocated them (hipHostFree needs
+    // no stream); with a live context its stream is drained first so that no copy still targets the pages
     if (!hptr) return GINSIM_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     HIP_TRY(hipHostFree(hptr));
     return GINSIM_OK;
 }
@@ -288,8 +291,43 @@ int ginsim_mc_variant(const ginsim_mc_params* p, int32_t* variant) {
     return GINSIM_OK;
 }
 
+static int check_mc_params(const ginsim_mc_params* p);
+
+int ginsim_mc_kernel_name(const ginsim_mc_params* p, char* buf, size_t cap) {
+    REQUIRE(p && buf && cap > 0, "mc_kernel_name: bad arguments");
+    const int rc = check_mc_params(p);
+    if (rc) return rc;
+    buf[0] = 0;
+    if (p->precision == 1) (void)launch_mc_f32(*p, nullptr, buf, cap);
+    else if (series_path_applies(*p)) snprintf(buf, cap, "ginsim::series_kernel<1>");
+    else (void)launch_mc(*p, nullptr, buf, cap);
+    REQUIRE(buf[0], "mc_kernel_name: no kernel serves these parameters");
+    return GINSIM_OK;
+}
+
 int ginsim_mc_run(ginsim_ctx* c, const ginsim_mc_params* p) {
-    REQUIRE(c && p, "mc_run: NULL argument");
+    REQUIRE(c, "mc_run: NULL argument");
+    const int rc0 = check_mc_params(p);
+    if (rc0) return rc0;
+    HIP_TRY(hipSetDevice(c->device));
+    if (p->precision == 1) {
+        HIP_TRY(launch_mc_f32(*p, c->stream, nullptr, 0));
+    } else if (series_path_applies(*p)) {       // sensors only, few runs, long series: parallel along time
+        int32_t L = 0;
+        const int64_t nchunks = series_chunks(*p, &L);
+        void* carry = nullptr;
+        HIP_TRY(scratch(c, 3, sizeof(double) * 6 * (size_t)nchunks * (size_t)p->runs, &carry));
+        HIP_TRY(launch_series(*p, reinterpret_cast<double*>(carry), c->stream));
+    } else {
+        HIP_TRY(launch_mc(*p, c->stream, nullptr, 0));
+    }
+    return GINSIM_OK;
+}
+
+}  // extern "C"
+
+static int check_mc_params(const ginsim_mc_params* p) {
+    REQUIRE(p, "mc_run: NULL argument");
     REQUIRE(p->n >= 1 && p->runs >= 1, "mc_run: n=%lld runs=%lld must be >= 1", (long long)p->n, (long long)p->runs);
     REQUIRE(p->n <= 0xFFFFFFFFll, "mc_run: n exceeds the 32-bit sample counter of the RNG");
     REQUIRE(p->runs <= (int64_t)0x7FFFFFFF * 64, "mc_run: too many runs for one launch");
@@ -326,21 +364,15 @@ int ginsim_mc_run(ginsim_ctx* c, const ginsim_mc_params* p) {
     }
     REQUIRE(!(p->out_end_ned[0] || p->out_end_ned[1]) || (p->ref_frame == 0 && p->precision == 0 && !p->given_sensors),
             "mc_run: out_end_ned needs ref_frame 0, fp64, generate mode");
-    HIP_TRY(hipSetDevice(c->device));
     if (p->precision == 1) {
-        REQUIRE(!p->given_sensors && p->algo_mask != 0, "mc_run: the fp32 kernel supports generate mode with an algorithm only");
-        HIP_TRY(launch_mc_f32(*p, c->stream));
-    } else if (series_path_applies(*p)) {       // sensors only, few runs, long series: parallel along time
-        int32_t L = 0;
-        const int64_t nchunks = series_chunks(*p, &L);
-        void* carry = nullptr;
-        HIP_TRY(scratch(c, 3, sizeof(double) * 6 * (size_t)nchunks * (size_t)p->runs, &carry));
-        HIP_TRY(launch_series(*p, reinterpret_cast<double*>(carry), c->stream));
-    } else {
-        HIP_TRY(launch_mc(*p, c->stream));
+        REQUIRE(p->algo_mask != 0, "mc_run: the fp32 kernel needs an algorithm");
+        REQUIRE(!(p->out_proc[0] || p->out_proc[1] || p->out_end_ned[0] || p->out_end_ned[1] || p->wave_trace || p->block_threads),
+                "mc_run: the fp32 kernel has no online process statistics, NED record or telemetry hooks");
     }
     return GINSIM_OK;
 }
+
+extern "C" {
 
 int ginsim_aux_sensors(ginsim_ctx* c, const ginsim_aux_params* p) {
     REQUIRE(c && p, "aux_sensors: NULL argument");

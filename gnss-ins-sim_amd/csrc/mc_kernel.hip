@@ -14,6 +14,7 @@
 //   FreeIntegration.run (odometer variant)     demo_algorithms/free_integration_odo.py:63-160
 //   array_error + end-point pick               gnss_ins_sim/sim/ins_data_manager.py:519-541, 737
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include "ginsim.h"
 #include "ins_math.hpp"
@@ -415,7 +416,7 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
 //                                                    normals as floats (48 B)
 //   waves 0-3 (consumers)                          : read tile i-1 from LDS, widen, sensor sums, mechanisation, all stores
 //
-// One __syncthreads() per tile of T = 4 steps; the instruction total is unchanged, the SIMD just always has a second
+// One __syncthreads() per tile of T = kSplitTile (6) steps; the instruction total is unchanged, the SIMD just always has a second
 // wavefront to issue from.  Results are bit-identical to mc_kernel (same functions in the same order on the same values).
 constexpr int kSplitRuns = 256;
 #ifndef GINSIM_SPLIT_TILE
@@ -586,8 +587,17 @@ static bool any_white_drift(const ginsim_mc_params& p) {
     return f;
 }
 
+// name != nullptr: write the kernel's name (as rocprofv3 reports it, without arguments) instead of launching -- what
+// ginsim_mc_kernel_name returns, so that profiles and the bench attribute to the instantiation that really runs
+#define GINSIM_NAME_OR(fmt, ...)                         \
+    if (name) {                                          \
+        snprintf(name, cap, fmt, __VA_ARGS__);           \
+        return hipSuccess;                               \
+    }
+static const char* tf(bool b) { return b ? "true" : "false"; }
+
 template <int RF, int ALGOS, bool WD>
-static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream) {
+static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
     const int tb = p.block_threads > 0 ? p.block_threads : kBlock;
     const int64_t waves = (p.runs + kWave - 1) / kWave;
     if constexpr ((ALGOS & GINSIM_ALGO_FREE) != 0) {
@@ -596,18 +606,11 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream) {
             // per SIMD (C2: 1.48 -> 1.41 ms); ref_frame 0 would spill 76-140 B per lane
             constexpr int PROD = (ALGOS == GINSIM_ALGO_FREE && RF == 1) ? 2 : 1;
             static const int prod = [] { const char* e = getenv("GINSIM_SPLIT_PROD"); return e ? atoi(e) : PROD; }();
-            static bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, PROD>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
-                return true;
-            }();
-            (void)once;
             const dim3 sgrid((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns));
             if constexpr (ALGOS == GINSIM_ALGO_FREE && RF == 0) {     // nothing kept: two producer groups fit here too
                 const bool keep = p.out_accel || p.out_gyro || p.out_odo || p.out_traj[0] || p.out_traj[1];
                 if (!keep && prod != 1) {
+                    GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, 2, false>", RF, ALGOS, tf(WD))
                     static bool once2 = [] {
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 2, false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
@@ -618,7 +621,17 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream) {
                     return hipGetLastError();
                 }
             }
-            if (prod == PROD && PROD > 1)
+            const bool two = prod == PROD && PROD > 1;
+            GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, %d, true>", RF, ALGOS, tf(WD), two ? PROD : 1)
+            static bool once = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, PROD>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
+                return true;
+            }();
+            (void)once;
+            if (two)
                 hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD, PROD>), sgrid, dim3(256 * (1 + PROD)), kSplitLds, stream, p);
             else
                 hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD, 1>), sgrid, dim3(512), kSplitLds, stream, p);
@@ -631,19 +644,23 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream) {
     const dim3 grid((unsigned)((p.runs + tb - 1) / tb)), block(tb);
     if constexpr (WD && (ALGOS == GINSIM_ALGO_FREE || ALGOS == GINSIM_ALGO_ODO)) {
         if (p.out_proc[ALGOS == GINSIM_ALGO_FREE ? 0 : 1]) {       // the general sensor model serves all PS launches
-            if (RF == 0 && p.proc_pos_ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1>), grid, block, lds, stream, p);
+            const bool ned = RF == 0 && p.proc_pos_ned;
+            GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d>", RF, ALGOS, ned ? 2 : 1)
+            if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1>), grid, block, lds, stream, p);
             else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1>), grid, block, lds, stream, p);
             return hipGetLastError();
         }
     }
+    GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, %s, 0>", RF, ALGOS, tf(WD))
     hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, WD>), grid, block, lds, stream, p);
     return hipGetLastError();
 }
 
 template <int RF, int ALGOS>
-static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
+static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
     if (p.given_sensors) {
         if constexpr (ALGOS != 0) {
+            GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, true, false, 0>", RF, ALGOS)
             const int tb = p.block_threads > 0 ? p.block_threads : kBlock;
             const int64_t waves = (p.runs + kWave - 1) / kWave;
             const int per_cu = waves <= 1024 ? 1 : 2;
@@ -655,23 +672,23 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream) {
     }
     // the simple-model variant of the two-algorithm ref_frame 0 kernels is the one instantiation that spills: use the general one
     constexpr bool kSimpleFits = !(RF == 0 && ALGOS == (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO));
-    if (any_white_drift(p) || !kSimpleFits || p.out_proc[0] || p.out_proc[1]) return launch3<RF, ALGOS, true>(p, stream);
-    if constexpr (kSimpleFits) return launch3<RF, ALGOS, false>(p, stream);
+    if (any_white_drift(p) || !kSimpleFits || p.out_proc[0] || p.out_proc[1]) return launch3<RF, ALGOS, true>(p, stream, name, cap);
+    if constexpr (kSimpleFits) return launch3<RF, ALGOS, false>(p, stream, name, cap);
     return hipErrorInvalidValue;
 }
 
 template <int RF>
-static hipError_t launch1(const ginsim_mc_params& p, hipStream_t stream) {
+static hipError_t launch1(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
     switch (p.algo_mask) {
-        case 0: return launch2<RF, 0>(p, stream);      // sensors only (Sim without an algorithm)
-        case GINSIM_ALGO_FREE: return launch2<RF, GINSIM_ALGO_FREE>(p, stream);
-        case GINSIM_ALGO_ODO: return launch2<RF, GINSIM_ALGO_ODO>(p, stream);
-        default: return launch2<RF, GINSIM_ALGO_FREE | GINSIM_ALGO_ODO>(p, stream);
+        case 0: return launch2<RF, 0>(p, stream, name, cap);      // sensors only (Sim without an algorithm)
+        case GINSIM_ALGO_FREE: return launch2<RF, GINSIM_ALGO_FREE>(p, stream, name, cap);
+        case GINSIM_ALGO_ODO: return launch2<RF, GINSIM_ALGO_ODO>(p, stream, name, cap);
+        default: return launch2<RF, GINSIM_ALGO_FREE | GINSIM_ALGO_ODO>(p, stream, name, cap);
     }
 }
 
-hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream) {
-    return p.ref_frame == 1 ? launch1<1>(p, stream) : launch1<0>(p, stream);
+hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
+    return p.ref_frame == 1 ? launch1<1>(p, stream, name, cap) : launch1<0>(p, stream, name, cap);
 }
 
 // ---------------------------------------------------------------------------------------------------

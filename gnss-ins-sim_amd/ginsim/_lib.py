@@ -89,6 +89,7 @@ _SIGS = {
     'ginsim_aux_sensors': (C.c_int, [C.c_void_p, C.POINTER(AuxParams)]),
     'ginsim_mc_run': (C.c_int, [C.c_void_p, C.POINTER(McParams)]),
     'ginsim_mc_variant': (C.c_int, [C.POINTER(McParams), C.POINTER(C.c_int32)]),
+    'ginsim_mc_kernel_name': (C.c_int, [C.POINTER(McParams), C.c_char_p, C.c_size_t]),
     'ginsim_end_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Stats)]),
     'ginsim_end_stats_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     'ginsim_end_stats_finish': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),

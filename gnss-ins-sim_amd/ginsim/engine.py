@@ -86,7 +86,7 @@ class Context(object):
 
     def download(self, buf_or_ptr, shape, dtype=np.float64):
         out = np.empty(shape, dtype=dtype)
-        ptr = buf_or_ptr.ptr if isinstance(buf_or_ptr, DeviceBuffer) else buf_or_ptr
+        ptr = getattr(buf_or_ptr, 'ptr', buf_or_ptr)          # DeviceBuffer, DeviceView or a raw device pointer
         check(lib.ginsim_memcpy_d2h(self.handle, out.ctypes.data, ptr, out.nbytes))
         return out
 
@@ -263,7 +263,7 @@ class MonteCarloJob(object):
     given: None (sensors are generated), or a dict of DeviceBuffers {'gyro', 'accel'[, 'odo']} holding sensor series
     that are already on the device in the engine's [component][sample][run] fp64 layout -- e.g. the 'gyro'/'accel'
     buffers another job materialised -- which are then integrated as they are (the plugin's run(set_of_input)
-    boundary for a whole batch; accel_err / gyro_err may be None).
+    boundary for a whole batch; accel_err / gyro_err may be None).  precision='f32' rounds them to float as it reads them.
     """
 
     def __init__(self, ctx, fs, ref_frame, truth, accel_err, gyro_err, ini, runs, algos=('free',),
@@ -280,8 +280,8 @@ class MonteCarloJob(object):
         self.keep_sensors, self.keep_traj = bool(keep_sensors), bool(keep_traj)
         self.want_odo = 'odo' in self.algos or (odo_err is not None and 'ref_odo' in truth)
         if given is not None:
-            if precision != 'f64' or keep_sensors or not self.algos:
-                raise ValueError('given sensors: fp64, at least one algorithm, nothing to keep but trajectories')
+            if keep_sensors or not self.algos:
+                raise ValueError('given sensors: at least one algorithm, nothing to keep but trajectories')
             need = ['gyro'] + (['accel'] if 'free' in self.algos else []) + (['odo'] if 'odo' in self.algos else [])
             for k in need:
                 size = (1 if k == 'odo' else 3) * self.n * self.runs * 8
@@ -416,24 +416,11 @@ class MonteCarloJob(object):
         check(lib.ginsim_mc_run(self.ctx.handle, C.byref(self.params)))
 
     def kernel_name(self):
-        """Name of the kernel launch() dispatches for these parameters (as rocprofv3 reports it, without arguments)."""
-        v = C.c_int32(0)
-        check(lib.ginsim_mc_variant(C.byref(self.params), C.byref(v)))
-        p = self.params
-        if p.precision == 1:
-            return 'ginsim::f32::mc_kernel_f32%s<%d, %d>' % ('_split' if v.value else '', p.ref_frame, p.algo_mask)
-        ps = 0 if self.proc_first is None else (2 if (self.proc_ned and p.ref_frame == 0) else 1)
-        wd = (not p.given_sensors) and (ps != 0 or (p.ref_frame == 0 and p.algo_mask == 3) or any(
-            p.accel.white_drift[k] or p.gyro.white_drift[k] or p.accel.bias[k] != 0.0 or p.gyro.bias[k] != 0.0 for k in range(3)))
-        if v.value:     # one algorithm: two producer wavefronts per consumer (csrc/mc_kernel.hip, launch3)
-            two = p.algo_mask == 1 and os.environ.get('GINSIM_SPLIT_PROD', '2') != '1'
-            kept = bool(p.out_accel or p.out_gyro or p.out_odo or p.out_traj[0] or p.out_traj[1])
-            if two and p.ref_frame == 0 and not kept:       # the statistics-only variant of ref_frame 0
-                return 'ginsim::mc_kernel_split<0, 1, %s, 2, false>' % ('true' if wd else 'false')
-            prod = 2 if two and p.ref_frame == 1 else 1
-            return 'ginsim::mc_kernel_split<%d, %d, %s, %d, true>' % (p.ref_frame, p.algo_mask, 'true' if wd else 'false', prod)
-        return 'ginsim::mc_kernel<%d, %d, %s, %s, %d>' % (p.ref_frame, p.algo_mask, 'true' if p.given_sensors else 'false',
-                                                          'true' if wd else 'false', ps)
+        """Name of the kernel launch() dispatches for these parameters (as rocprofv3 reports it, without arguments),
+        reported by the library's own dispatch code (ginsim_mc_kernel_name)."""
+        buf = C.create_string_buffer(256)
+        check(lib.ginsim_mc_kernel_name(C.byref(self.params), buf, 256))
+        return buf.value.decode()
 
     def run(self):
         self.launch()
@@ -594,8 +581,11 @@ def pinned_empty(ctx, shape, dtype=np.float64):
     check(lib.ginsim_host_alloc(ctx.handle, max(nbytes, 8), C.byref(p)))
     raw = (C.c_char * max(nbytes, 8)).from_address(p.value)
     arr = np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-    handle, addr = ctx.handle, p.value
-    weakref.finalize(raw, lambda: lib.ginsim_host_free(handle, C.c_void_p(addr)))
+    addr = p.value
+
+    def release(owner=ctx):         # the closure keeps the Context object (not its raw handle) alive as long as the pages
+        lib.ginsim_host_free(owner.handle, C.c_void_p(addr))     # handle is None once the context was closed: plain hipHostFree
+    weakref.finalize(raw, release)
     return arr
 
 
@@ -646,9 +636,9 @@ def box_muller(ctx, words):
 
 
 def allan_var(ctx, x, n, nseries, series_stride, fs, cap=128):
-    """Allan variance of `nseries` device-resident series (DeviceBuffer or raw pointer), allan.py:18-59.
+    """Allan variance of `nseries` device-resident series (DeviceBuffer, DeviceView or raw pointer), allan.py:18-59.
     Returns (avar (nseries, ntau), tau (ntau,))."""
-    ptr = x.ptr if isinstance(x, DeviceBuffer) else x
+    ptr = getattr(x, 'ptr', x)
     tau = np.zeros(cap)
     avar = np.zeros((nseries, cap))
     nt = C.c_int32(0)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define GINSIM_ABI_VERSION 2
+#define GINSIM_ABI_VERSION 3
 
 /* status codes */
 #define GINSIM_OK          0
@@ -47,7 +47,7 @@ int  ginsim_memset(ginsim_ctx* ctx, void* dptr, int value, size_t bytes);
  * and to such buffers run at the link rate instead of through the driver's staging of pageable memory.  The reference has
  * no counterpart (its arrays are plain NumPy); the Python layer wraps it as ginsim.pinned_empty(). */
 int  ginsim_host_alloc(ginsim_ctx* ctx, size_t bytes, void** hptr);
-int  ginsim_host_free(ginsim_ctx* ctx, void* hptr);
+int  ginsim_host_free(ginsim_ctx* ctx /* may be NULL: the pages may outlive the context */, void* hptr);
 int  ginsim_sync(ginsim_ctx* ctx);
 /* HIP-event timer on the context's stream (the stream every kernel of this context is launched on). */
 int  ginsim_timer_begin(ginsim_ctx* ctx);
@@ -131,7 +131,10 @@ typedef struct {
     int32_t   precision;      /* 0: fp64 (default).  1: fp32 kernel -- out_accel/out_gyro/out_odo/out_traj point to FLOAT
                                * buffers of the same [component][sample][run] shape; the position planes of out_traj hold
                                * the displacement from the run's initial position (ECEF-based for ref_frame 1, LLA for 0);
-                               * out_end stays double.  Generate mode only. */
+                               * out_end stays double; in_* (given_sensors) stay double and are rounded to float as read.
+                               * The fp32 kernel consumes the SAME normals as the fp64 one (they are single-precision numbers)
+                               * and every operation of it is one defined IEEE operation: oracle/c/ginsim_oracle.c
+                               * (oracle_mc_run_f32) reproduces its series to the bit. */
     int32_t   proc_pos_ned;   /* process statistics of the position error in local NED metres (ref_frame 0 only) */
     /* ---- statistics WITHOUT trajectories (ABI 2): what Sim.results() needs when the series are not materialised ---- */
     const double* ref_nav;    /* [n][9] truth att3, pos3, vel3 of every sample; needed when out_proc is set */
@@ -151,6 +154,9 @@ int ginsim_mc_run(ginsim_ctx* ctx, const ginsim_mc_params* p);
  * producer/consumer workgroups (mc_kernel_split / mc_kernel_f32_split), chosen for batches of <= 1024 wavefronts and,
  * for one algorithm in ref_frame 1 (two producer groups: three wavefronts per SIMD), at every size. */
 int ginsim_mc_variant(const ginsim_mc_params* p, int32_t* variant);
+/* ABI 3: the NAME of that kernel as rocprofv3 reports it, without arguments (e.g. "ginsim::mc_kernel_split<1, 1, false, 2,
+ * true>"), written by the same dispatch code that launches it -- profiles and bench.py attribute to what really runs. */
+int ginsim_mc_kernel_name(const ginsim_mc_params* p, char* buf, size_t cap);
 
 /* ---- auxiliary sensors of a Monte-Carlo batch: pathgen.gps_gen (pathgen.py:596-625) and pathgen.mag_gen (:643-661).
  *      FreeIntegration does not consume them, so they are generated only when they are to be kept. */

@@ -45,8 +45,11 @@ MOTION = REF + '/demo_motion_def_files/'
 SEED = 20260923
 
 
+OUT = os.environ.get('GINSIM_GOLDEN_OUT')        # --check: write into a scratch directory instead of the tree
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name + '.npz')
+    path = os.path.join(OUT or HERE, name + '.npz')
     np.savez_compressed(path, **arrays)
     print('%-28s %7.1f KB' % (name + '.npz', os.path.getsize(path) / 1024))
 
@@ -78,6 +81,8 @@ def emit_profile(src, dst, comment):
     if seg.ndim == 1:
         seg = seg.reshape(1, -1)
     seg[np.isnan(seg)] = 0.0
+    if OUT:
+        dst = os.path.join(OUT, 'motion_profiles', os.path.basename(dst))
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     with open(dst, 'w') as f:
         f.write('lat_deg,lon_deg,alt_m,vbx_mps,vby_mps,vbz_mps,yaw_deg,pitch_deg,roll_deg  # %s\n' % comment)
@@ -510,39 +515,101 @@ def allan_case():
     save('allan_ref', seed=SEED, n=n, fs=fs, avar=avar, tau=tau)
 
 
-if __name__ == '__main__':
-    if len(sys.argv) > 1:           # only the named cases, e.g. `make_golden.py summary_case`
-        for name in sys.argv[1:]:
-            globals()[name]()
-        sys.exit(0)
+def emit_profiles():
     prof = os.path.join(REPO, 'gnss-ins-sim_amd', 'motion_profiles')
     emit_profile(MOTION + 'motion_def-90deg_turn.csv', prof + '/turn_90deg.csv', '90-degree turn, 10 s')
     emit_profile(MOTION + 'motion_def-long_drive.csv', prof + '/long_drive.csv', 'long drive, <=1410 s')
     emit_profile(MOTION + 'motion_def-Allan.csv', prof + '/static_1800s.csv', 'static, 1800 s')
-    t1_tumble()
-    t1_rates()
-    t1_fixture('bosch')
-    t1_fixture('nxp')
-    t2_turn(1)
-    t2_turn(0)
-    t3_case('t3_demo_rf1', 1, dict(DEMO_IMU), False, {'scale': 0.999, 'stdv': 0.1}, ['odo', 'fi'], 4)
-    t3_case('t3_mid_rf0', 0, 'mid-accuracy', False, None, ['fi'], 4)
-    t3_case('t3_low_rf1', 1, 'low-accuracy', False, None, ['fi'], 3)
-    t3_case('t3_high_odo_rf0', 0, 'high-accuracy', False, {'scale': 1.002, 'stdv': 0.02}, ['odo', 'fi'], 3)
+
+
+def t3_white():
     white = {k: v for k, v in DEMO_IMU.items() if not k.endswith('_corr')}
     white['gyro_b'] = np.array([10.0, -20.0, 30.0])
     white['accel_b'] = np.array([1e-3, -2e-3, 3e-3])
     t3_case('t3_white_gps_rf0', 0, white, True, {'scale': 1.001, 'stdv': 0.05}, ['fi', 'odo'], 3, fs_gps=10.0)
+
+
+def t3_mag9(rf):
     mag9 = dict(DEMO_IMU)
     mag9.update({'mag_si': np.array([[1.02, 0.01, -0.02], [0.03, 0.97, 0.01], [-0.01, 0.02, 1.05]]),
                  'mag_hi': np.array([5.0, -8.0, 12.0]), 'mag_std': np.array([0.2, 0.1, 0.3])})
-    for rf in (0, 1):
-        t3_case('t3_mag9_gps_rf%d' % rf, rf, dict(mag9), True, None, ['fi'], 2, fs_gps=10.0, axis=9)
-    t3_case('t3_drive200_rf0', 0, 'low-accuracy', True, {'scale': 0.998, 'stdv': 0.05}, ['fi', 'odo'], 2, fs_gps=5.0, csv=DRIVE, fs=200.0)
-    csv_case()
-    summary_case()
-    allan_case()
-    t2_long_drive()
-    truth_mixed_types()
-    truth_random_profiles()
-    t4_reference_statistics()
+    t3_case('t3_mag9_gps_rf%d' % rf, rf, dict(mag9), True, None, ['fi'], 2, fs_gps=10.0, axis=9)
+
+
+# Every case runs in an interpreter of its own.  The reference's IMU(accuracy=dict) ALIASES the module-level
+# 'low-accuracy' dicts and then overwrites them with the caller's values (gnss_ins_sim/sim/imu_model.py:110-112, 138-158),
+# so in one interpreter every 'low-accuracy' case that follows a dict case silently gets the dict's IMU -- round 2's
+# t3_low_rf1 was the demo IMU under another name.  One process per case makes the recipe independent of the order.
+CASES = [
+    ('profiles', 'emit_profiles()', ['motion_profiles/turn_90deg.csv', 'motion_profiles/long_drive.csv', 'motion_profiles/static_1800s.csv']),
+    ('t1_tumble', 't1_tumble()', ['t1_fixture_tumble.npz']),
+    ('t1_rates', 't1_rates()', ['t1_rates.npz']),
+    ('t1_bosch', "t1_fixture('bosch')", ['t1_fixture_bosch.npz']),
+    ('t1_nxp', "t1_fixture('nxp')", ['t1_fixture_nxp.npz']),
+    ('t2_turn_rf1', 't2_turn(1)', ['t2_turn_rf1.npz']),
+    ('t2_turn_rf0', 't2_turn(0)', ['t2_turn_rf0.npz']),
+    ('t3_demo_rf1', "t3_case('t3_demo_rf1', 1, dict(DEMO_IMU), False, {'scale': 0.999, 'stdv': 0.1}, ['odo', 'fi'], 4)", ['t3_demo_rf1.npz']),
+    ('t3_mid_rf0', "t3_case('t3_mid_rf0', 0, 'mid-accuracy', False, None, ['fi'], 4)", ['t3_mid_rf0.npz']),
+    ('t3_low_rf1', "t3_case('t3_low_rf1', 1, 'low-accuracy', False, None, ['fi'], 3)", ['t3_low_rf1.npz']),
+    ('t3_high_odo_rf0', "t3_case('t3_high_odo_rf0', 0, 'high-accuracy', False, {'scale': 1.002, 'stdv': 0.02}, ['odo', 'fi'], 3)", ['t3_high_odo_rf0.npz']),
+    ('t3_white_gps_rf0', 't3_white()', ['t3_white_gps_rf0.npz']),
+    ('t3_mag9_gps_rf0', 't3_mag9(0)', ['t3_mag9_gps_rf0.npz']),
+    ('t3_mag9_gps_rf1', 't3_mag9(1)', ['t3_mag9_gps_rf1.npz']),
+    ('t3_drive200_rf0', "t3_case('t3_drive200_rf0', 0, 'low-accuracy', True, {'scale': 0.998, 'stdv': 0.05}, ['fi', 'odo'], 2, fs_gps=5.0, csv=DRIVE, fs=200.0)", ['t3_drive200_rf0.npz']),
+    ('csv_case', 'csv_case()', ['csv_files_rf0.npz']),
+    ('summary_case', 'summary_case()', ['summary_text_rf0.npz']),
+    ('allan_case', 'allan_case()', ['allan_ref.npz']),
+    ('t2_long_drive', 't2_long_drive()', ['t2_long_drive_rf0.npz']),
+    ('truth_mixed_types', 'truth_mixed_types()', ['truth_mixed_types_rf0.npz', 'truth_mixed_types_rf1.npz']),
+    ('truth_random_profiles', 'truth_random_profiles()', ['truth_random_profiles.npz']),
+    ('t4_reference_statistics', 't4_reference_statistics()', ['t4_c1_reference_stats.npz']),
+]
+
+
+def run_cases(names, out_dir=None):
+    """One fresh interpreter per case (see CASES).  out_dir: write there instead of tests/golden/ (and motion_profiles/)."""
+    import subprocess
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', MPLBACKEND='Agg')
+    if out_dir:
+        env['GINSIM_GOLDEN_OUT'] = out_dir
+    for name, _, _ in CASES:
+        if names and name not in names:
+            continue
+        print('== %s' % name, flush=True)
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), '--case', name], env=env)
+
+
+def check():
+    """Regenerate every golden into a scratch directory and byte-compare with the committed files."""
+    import filecmp
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix='golden_check_')
+    run_cases(sys.argv[2:], tmp)
+    prof = os.path.join(REPO, 'gnss-ins-sim_amd')
+    bad = []
+    for name, _, files in CASES:
+        if sys.argv[2:] and name not in sys.argv[2:]:
+            continue
+        for f in files:
+            committed = os.path.join(prof, f) if f.startswith('motion_profiles/') else os.path.join(HERE, f)
+            fresh = os.path.join(tmp, f)
+            same = os.path.exists(fresh) and os.path.exists(committed) and filecmp.cmp(fresh, committed, shallow=False)
+            print('%-40s %s' % (f, 'identical' if same else 'DIFFERS'))
+            if not same:
+                bad.append(f)
+    print('%d file(s) differ' % len(bad) if bad else 'all golden files reproduce bit-identically')
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    # make_golden.py                 every case, each in a fresh interpreter
+    # make_golden.py NAME [NAME..]   the named cases (names of CASES), each in a fresh interpreter
+    # make_golden.py --check [NAME..] regenerate into a scratch directory and byte-compare with the committed files
+    # make_golden.py --case NAME     (internal) run ONE case in this interpreter
+    if len(sys.argv) > 2 and sys.argv[1] == '--case':
+        code = dict((c[0], c[1]) for c in CASES)[sys.argv[2]]
+        eval(code)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == '--check':
+        sys.exit(check())
+    run_cases(sys.argv[1:])

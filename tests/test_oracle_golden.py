@@ -193,6 +193,38 @@ def test_t3_injected_noise_end_to_end(name):
         assert ok, 'end-point statistics of %s/%s match no reference group' % (name, a)
 
 
+@pytest.mark.parametrize('name,grade', [('t3_mid_rf0', 'mid-accuracy'), ('t3_low_rf1', 'low-accuracy'),
+                                        ('t3_high_odo_rf0', 'high-accuracy'), ('t3_drive200_rf0', 'low-accuracy')])
+def test_t3_goldens_hold_the_grade_their_name_claims(name, grade):
+    """The reference's IMU(accuracy=dict) overwrites the module-level 'low-accuracy' dicts
+    (gnss_ins_sim/sim/imu_model.py:110-112, 138-158): generated in ONE interpreter after a dict case, a 'low-accuracy'
+    golden silently holds the dict's IMU (round 2's t3_low_rf1 did).  make_golden.py now runs every case in a fresh
+    interpreter; this test pins the recorded parameters to the grade table (imu_model.py:18-52 values)."""
+    from gnss_ins_sim.sim import imu_model
+    g = load_golden(name)
+    imu = imu_model.IMU(accuracy=grade, axis=6, gps=False)
+    for k, v in imu.gyro_err.items():
+        np.testing.assert_array_equal(g['gyro_' + k], v, err_msg='%s gyro %s' % (name, k))
+    for k, v in imu.accel_err.items():
+        np.testing.assert_array_equal(g['accel_' + k], v, err_msg='%s accel %s' % (name, k))
+    # and the three grades really differ
+    other = imu_model.IMU(accuracy='mid-accuracy' if grade != 'mid-accuracy' else 'low-accuracy', axis=6, gps=False)
+    assert not np.array_equal(g['gyro_arw'], other.gyro_err['arw'])
+
+
+def test_golden_recipe_lists_every_committed_file():
+    """Every .npz under tests/golden/ is produced by a case of make_golden.py (so `--check` covers all of them)."""
+    import ast
+    import os
+    from conftest import GOLDEN
+    src = open(os.path.join(GOLDEN, 'make_golden.py')).read()
+    tree = ast.parse(src)
+    cases = next(n for n in tree.body if isinstance(n, ast.Assign) and getattr(n.targets[0], 'id', '') == 'CASES')
+    listed = {f for c in ast.literal_eval(cases.value) for f in c[2]}
+    have = {f for f in os.listdir(GOLDEN) if f.endswith('.npz')}
+    assert have == {f for f in listed if f.endswith('.npz')}
+
+
 def test_t2_long_drive_truth_rows():
     """Full-length pathgen restatement is slow in Python (193k steps); run it only on request."""
     import os
