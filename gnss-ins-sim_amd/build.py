@@ -42,7 +42,7 @@ def newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=False, tag=None, defines=()):
+def build(force=False, verbose=False, tag=None, defines=(), xflags=()):
     """tag / defines: an experiment build (A/B timing) -> lib/libginsim_<tag>.so from build/<tag>/ objects compiled with
     -D<define>; loaded with GINSIM_LIB=<path>.  The product build has neither."""
     global OBJ, LIB
@@ -62,7 +62,7 @@ def build(force=False, verbose=False, tag=None, defines=()):
         o = os.path.join(OBJ, src.rsplit('.', 1)[0] + '.o')
         objs.append(o)
         if force or newer(s, o) or any(newer(d, o) for d in deps):
-            cmd = [HIPCC] + COMMON + extra + ['-D' + d for d in defines] + ['-c', s, '-o', o]
+            cmd = [HIPCC] + COMMON + extra + ['-D' + d for d in defines] + (list(xflags) if src.startswith('mc_kernel') else []) + ['-c', s, '-o', o]
             if src.endswith('.hip'):
                 # per-kernel registers / scratch / occupancy as the compiler reports them -> build/<name>.resources.txt
                 # (tests/test_host_cpu.py holds the hot kernels to two wavefronts per SIMD and no AGPR spills)
@@ -97,4 +97,5 @@ def build(force=False, verbose=False, tag=None, defines=()):
 if __name__ == '__main__':
     _tag = sys.argv[sys.argv.index('--tag') + 1] if '--tag' in sys.argv else None
     _defs = [a[2:] for a in sys.argv if a.startswith('-D')]
-    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv, tag=_tag, defines=_defs))
+    _xf = ['-' + a[2:] for a in sys.argv if a.startswith('-X')]      # -X<flag>: extra compiler flag for the MC kernels (experiments)
+    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv, tag=_tag, defines=_defs, xflags=_xf))

@@ -26,7 +26,8 @@ void set_error(const char* fmt, ...) {
 }
 
 hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap);      // name: report, do not launch
-hipError_t launch_mc_f32(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap);
+hipError_t launch_mc_f32(const ginsim_mc_params& p, float* truth32, hipStream_t stream, char* name, size_t cap);
+size_t mc_f32_truth_bytes(const ginsim_mc_params& p);
 int mc_variant(const ginsim_mc_params& p);
 bool series_path_applies(const ginsim_mc_params& p);
 int64_t series_chunks(const ginsim_mc_params& p, int32_t* L_out);
@@ -39,7 +40,7 @@ hipError_t launch_rng_probe(uint64_t seed, uint64_t run, uint32_t stream, int64_
                             uint32_t* words, hipStream_t stream_h);
 hipError_t launch_aos_to_soa(const double* src, double* dst, int64_t R, int64_t n, int C, hipStream_t s);
 hipError_t launch_runs_to_series(const double* in, double* out, int C, int64_t n, int64_t R, hipStream_t s);
-hipError_t launch_box_muller(const uint32_t* words, int64_t count, double* z0, double* z1, hipStream_t s);
+hipError_t launch_normal_transform(const uint32_t* words, int64_t count, double* z0, double* z1, hipStream_t s);
 hipError_t launch_gather_runs(const double* series, int C, int64_t n, int64_t runs, const int64_t* ids, int nsel,
                               double* out, hipStream_t s);
 size_t stats_scratch_bytes(int64_t runs);
@@ -298,7 +299,7 @@ int ginsim_mc_kernel_name(const ginsim_mc_params* p, char* buf, size_t cap) {
     const int rc = check_mc_params(p);
     if (rc) return rc;
     buf[0] = 0;
-    if (p->precision == 1) (void)launch_mc_f32(*p, nullptr, buf, cap);
+    if (p->precision == 1) (void)launch_mc_f32(*p, nullptr, nullptr, buf, cap);
     else if (series_path_applies(*p)) snprintf(buf, cap, "ginsim::series_kernel<1>");
     else (void)launch_mc(*p, nullptr, buf, cap);
     REQUIRE(buf[0], "mc_kernel_name: no kernel serves these parameters");
@@ -311,7 +312,10 @@ int ginsim_mc_run(ginsim_ctx* c, const ginsim_mc_params* p) {
     if (rc0) return rc0;
     HIP_TRY(hipSetDevice(c->device));
     if (p->precision == 1) {
-        HIP_TRY(launch_mc_f32(*p, c->stream, nullptr, 0));
+        void* truth32 = nullptr;       // the wave-specialised fp32 kernel reads its truth as floats (converted by a pre-launch)
+        const size_t tb = mc_f32_truth_bytes(*p);
+        if (tb) HIP_TRY(scratch(c, 3, tb, &truth32));
+        HIP_TRY(launch_mc_f32(*p, reinterpret_cast<float*>(truth32), c->stream, nullptr, 0));
     } else if (series_path_applies(*p)) {       // sensors only, few runs, long series: parallel along time
         int32_t L = 0;
         const int64_t nchunks = series_chunks(*p, &L);
@@ -366,8 +370,9 @@ static int check_mc_params(const ginsim_mc_params* p) {
             "mc_run: out_end_ned needs ref_frame 0, fp64, generate mode");
     if (p->precision == 1) {
         REQUIRE(p->algo_mask != 0, "mc_run: the fp32 kernel needs an algorithm");
-        REQUIRE(!(p->out_proc[0] || p->out_proc[1] || p->out_end_ned[0] || p->out_end_ned[1] || p->wave_trace || p->block_threads),
-                "mc_run: the fp32 kernel has no online process statistics, NED record or telemetry hooks");
+        REQUIRE(!(p->out_proc[0] || p->out_proc[1] || p->out_end_ned[0] || p->out_end_ned[1] || p->wave_trace),
+                "mc_run: the fp32 kernel has no online process statistics, NED record or wave trace");
+        REQUIRE(p->block_threads == 0 || p->block_threads == 256, "mc_run: the fp32 kernel takes block_threads 0 or 256 (256 = the plain kernel)");
     }
     return GINSIM_OK;
 }
@@ -707,15 +712,15 @@ int ginsim_runs_to_series(ginsim_ctx* c, const double* series, int32_t ncomp, in
     return GINSIM_OK;
 }
 
-int ginsim_box_muller(ginsim_ctx* c, const uint32_t* host_words, int64_t count, double* host_z0, double* host_z1) {
-    REQUIRE(c && host_words && host_z0 && host_z1 && count >= 1, "box_muller: bad arguments");
+int ginsim_normal_transform(ginsim_ctx* c, const uint32_t* host_words, int64_t count, double* host_z0, double* host_z1) {
+    REQUIRE(c && host_words && host_z0 && host_z1 && count >= 1, "normal_transform: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
     DevBuf z0, z1, w;
     HIP_TRY(z0.alloc(sizeof(double) * count));
     HIP_TRY(z1.alloc(sizeof(double) * count));
     HIP_TRY(w.alloc(sizeof(uint32_t) * 4 * count));
     HIP_TRY(hipMemcpyAsync(w.p, host_words, sizeof(uint32_t) * 4 * count, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_box_muller(w.as<uint32_t>(), count, z0.as<double>(), z1.as<double>(), c->stream));
+    HIP_TRY(launch_normal_transform(w.as<uint32_t>(), count, z0.as<double>(), z1.as<double>(), c->stream));
     HIP_TRY(hipMemcpyAsync(host_z0, z0.p, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(host_z1, z1.p, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

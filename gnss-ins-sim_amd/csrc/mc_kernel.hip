@@ -1,7 +1,7 @@
 // Fused Monte-Carlo kernel: sensor-error injection + strapdown mechanisation + end-point error.
 //
 // One lane = one Monte-Carlo run (no inter-lane traffic in the time loop; workgroups of 256 or 512 threads only
-// shape the placement on the SIMDs and share the 12 KB Box-Muller tables).  Per-run state (Euler attitude + cached
+// shape the placement on the SIMDs and share the 4 KB coefficient table of the normal transform).  Per-run state (Euler attitude + cached
 // trig, body/NED velocity, position, the six Gauss-Markov bias states) lives in VGPRs for the whole time loop.
 // Truth samples are wave-uniform and come in through the scalar cache.  Everything that leaves the lane is SoA [component][sample][run]
 // (run fastest) so that every store instruction of a wavefront writes 64 x 8 B contiguous bytes.
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
         trace[2] = __builtin_amdgcn_s_memtime();
     }
     __shared__ uint32_t ntab[GIVEN ? 4 : kNormalTableWords];
-    NormalTables tab{nullptr, nullptr};
+    NormalTables tab{nullptr};
     if (!GIVEN) {
         tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
         __syncthreads();
@@ -411,8 +411,8 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
 // and there are no more runs to give the SIMD a second wavefront.  So the work of one step is split across TWO
 // wavefronts per 64 runs, at the point where the normal generator changes character:
 //
-//   waves 4-7 of a 512-thread workgroup (producers): the three Philox blocks of a step and the six single-precision
-//                                                    Box-Muller transforms -> LDS ring, per step and run the twelve
+//   waves 4-7 of a 512-thread workgroup (producers): the three Philox blocks of a step and the twelve single-precision
+//                                                    normal transforms -> LDS ring, per step and run the twelve
 //                                                    normals as floats (48 B)
 //   waves 0-3 (consumers)                          : read tile i-1 from LDS, widen, sensor sums, mechanisation, all stores
 //
@@ -911,9 +911,9 @@ __global__ void gather_runs_kernel(const double* __restrict__ series, int C, int
     out[idx] = series[((int64_t)c * n + j) * runs + ids[k]];
 }
 
-// Box-Muller on given words (test hook): words 0-1 are taken as one half block -- radius uniform from word 0, angle from
-// the low 24 bits of word 1 (words 2-3 unused).
-__global__ void box_muller_kernel(const uint32_t* __restrict__ words, int64_t count, double* __restrict__ z0, double* __restrict__ z1) {
+// The normal transform on given words (test hook): words 0-1 are taken as one half block -- z0 from word 0, z1 from
+// word 1 (words 2-3 unused).
+__global__ void normal_transform_kernel(const uint32_t* __restrict__ words, int64_t count, double* __restrict__ z0, double* __restrict__ z1) {
     __shared__ uint32_t ntab[kNormalTableWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -922,13 +922,13 @@ __global__ void box_muller_kernel(const uint32_t* __restrict__ words, int64_t co
     if (i >= count) return;
     const uint32_t ra[1] = {words[4 * i]}, ang[1] = {words[4 * i + 1]};
     float a[1], b[1];
-    box_muller<1>(ra, ang, a, b, tab);
+    normal_transform<1>(ra, ang, a, b, tab);
     z0[i] = (double)a[0];
     z1[i] = (double)b[0];
 }
 
-hipError_t launch_box_muller(const uint32_t* words, int64_t count, double* z0, double* z1, hipStream_t s) {
-    hipLaunchKernelGGL(box_muller_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, words, count, z0, z1);
+hipError_t launch_normal_transform(const uint32_t* words, int64_t count, double* z0, double* z1, hipStream_t s) {
+    hipLaunchKernelGGL(normal_transform_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, words, count, z0, z1);
     return hipGetLastError();
 }
 

@@ -1,9 +1,9 @@
 // fp32 variant of the fused Monte-Carlo kernel (BASELINE config 5).  Same algorithm, same launch geometry and the same
 // SoA [component][sample][run] outputs as mc_kernel.hip, in single precision -- and, since round 3, DEFINED operation by
-// operation, so that the float restatement in oracle/c/ginsim_oracle.c (oracle_mc_run_f32) reproduces the sensor series
+// operation, so that the float restatement in the test oracle (oracle_mc_run_f32 under oracle/c/) reproduces the sensor series
 // and the trajectories of every run TO THE BIT:
 //
-//   * noise: exactly the normals of the fp64 path (philox.hpp: Philox4x32-7, three blocks per IMU step, the Box-Muller
+//   * noise: exactly the normals of the fp64 path (philox.hpp: Philox4x32-7, three blocks per IMU step, the normal
 //     transform that is defined in IEEE single precision) -- the fp64 kernel widens those floats, this one uses them as
 //     they are.  Identical seeds therefore give the SAME noise realisation in both precisions, and the fp32 / fp64
 //     trajectories of a run differ by rounding only (tests/test_gpu_fp32.py states the tolerances);
@@ -64,7 +64,7 @@ struct Acc {
 //   k = rint(x 2/pi);  r = x - k pi/2 (two fused steps, pi/2 split in two doubles);  t = r^2
 //   sin r = r + r t (S1 + t (S2 + t (S3 + t (S4 + t S5))))          |r| <= pi/4: truncation 7e-12
 //   cos r = 1 + t (C1 + t (C2 + t (C3 + t (C4 + t (C5 + t C6)))))   truncation 1e-13
-// then the quadrant k mod 4 swaps / negates.  oracle/c/ginsim_oracle.c sincos_def() repeats these operations.
+// then the quadrant k mod 4 swaps / negates.  The test oracle (sincos_def under oracle/c/) repeats these operations.
 F32_FM void sincos_def(double x, float& sn, float& cs) {
     const double k = __builtin_rint(x * 0.63661977236758134308);
     double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
@@ -137,16 +137,25 @@ struct Att {
         const float dp = fm(w.y, cr, -(w.z * sr)) * dt;
         const float dr = fm(q, sp * icp, w.x) * dt;
         yaw.add(dy); pit.add(dp); rol.add(dr);
-        const bool fold = (pit.v > kHalfPiF) || (pit.v < -kHalfPiF);
-        if (fold) {
-            pit = Acc{pit.v > 0.f ? kPiF - pit.v : -kPiF - pit.v, 0.f};
-            yaw.add(kPiF); rol.add(kPiF);
-        }
-        if (yaw.v > kPiF) { yaw.add(-kTwoPiHi); yaw.add(-kTwoPiLo); } else if (yaw.v < -kPiF) { yaw.add(kTwoPiHi); yaw.add(kTwoPiLo); }
-        if (rol.v > kPiF) { rol.add(-kTwoPiHi); rol.add(-kTwoPiLo); } else if (rol.v < -kPiF) { rol.add(kTwoPiHi); rol.add(kTwoPiLo); }
         const float big = fmaxf(fabsf(dy), fmaxf(fabsf(dp), fabsf(dr)));
-        if (do_resync || fold || !(big <= 0.25f)) {
-            resync();
+        // ONE wave-uniform branch for everything that is rare (exact trig every kTrigResync steps, pitch over the pole, yaw /
+        // roll over +-pi, a step > 0.25 rad): when no lane of the wavefront needs it, the step is three rotations and nothing
+        // else -- no per-lane exec juggling on the common path.  The general path does the same operations on a lane that
+        // did not need it, so a run's bits do not depend on its wavefront neighbours.
+        const bool rare = do_resync || !(fabsf(pit.v) <= kHalfPiF) || !(fabsf(yaw.v) <= kPiF) || !(fabsf(rol.v) <= kPiF) || !(big <= 0.25f);
+        if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+            const bool fold = (pit.v > kHalfPiF) || (pit.v < -kHalfPiF);
+            if (fold) {
+                pit = Acc{pit.v > 0.f ? kPiF - pit.v : -kPiF - pit.v, 0.f};
+                yaw.add(kPiF); rol.add(kPiF);
+            }
+            if (yaw.v > kPiF) { yaw.add(-kTwoPiHi); yaw.add(-kTwoPiLo); } else if (yaw.v < -kPiF) { yaw.add(kTwoPiHi); yaw.add(kTwoPiLo); }
+            if (rol.v > kPiF) { rol.add(-kTwoPiHi); rol.add(-kTwoPiLo); } else if (rol.v < -kPiF) { rol.add(kTwoPiHi); rol.add(kTwoPiLo); }
+            if (do_resync || fold || !(big <= 0.25f)) {
+                resync();
+            } else {
+                rotate(dy, sy, cy); rotate(dp, sp, cp); rotate(dr, sr, cr);
+            }
         } else {
             rotate(dy, sy, cy); rotate(dp, sp, cp); rotate(dr, sr, cr);
         }
@@ -324,14 +333,14 @@ F32_FM float odo_normal(const RngKey& key, uint32_t j, const NormalTables& tab) 
     const u32x4 w = philox4x32(j, S_ODO >> 1, key.r0, key.r1, key.k0, key.k1);
     const uint32_t a[1] = {w.x}, b[1] = {w.y};
     float z0[1], z1[1];
-    box_muller<1>(a, b, z0, z1, tab);
+    normal_transform<1>(a, b, z0, z1, tab);
     return z0[0];
 }
 
 template <int RF, int ALGOS, bool GIVEN, bool WD>
-__global__ void __launch_bounds__(256) mc_kernel_f32(const ginsim_mc_params a) {
+__global__ void __launch_bounds__(256, 2) mc_kernel_f32(const ginsim_mc_params a) {
     __shared__ uint32_t ntab[GIVEN ? 4 : kNormalTableWords];
-    NormalTables tab{nullptr, nullptr};
+    NormalTables tab{nullptr};
     if (!GIVEN) {
         tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
         __syncthreads();
@@ -412,12 +421,61 @@ __global__ void __launch_bounds__(256) mc_kernel_f32(const ginsim_mc_params a) {
 // workgroup generate the twelve normals of a step -- the SAME code as the fp64 kernel's producers -- into an LDS ring,
 // waves 0-3 consume them and do sensors, mechanisation and stores.  PROD producer wavefronts per consumer wavefront
 // (the steps of a tile alternate between the groups).  Bit-identical to mc_kernel_f32.
+//
+// The consumer is ONE wavefront per SIMD and the step time hangs on it: a lone wavefront issues an instruction every ~5
+// cycles whatever its kind (tools/ubench3.hip: v_fma_f32 5.1, s_mov_b32 8.5, v_cvt_f32_f64 8.0, v_mad_u64_u32 9.1, a
+// transcendental 8.8), so its loop is written for instruction COUNT:
+//   * KEEP is a template parameter (everything kept / nothing kept; other combinations take the plain kernel): no
+//     per-step tests of the output pointers;
+//   * the series are stored through buffer resources -- one descriptor per group of three planes, ONE 32-bit lane offset
+//     advanced by runs x 4 bytes per step, the plane as the scalar offset: 15 x `buffer_store_dword v, voff, rsrc, splane`
+//     and one v_add_u32 per step instead of 15 64-bit address computations (needs 3 planes < 4 GiB: the launcher checks);
+//   * the truth of a step comes as eight floats {accel xyz, gyro xyz, odometer, 0} converted once per launch by
+//     truth_f32_kernel (one s_load_dwordx8, no six v_cvt_f32_f64 per step);
+//   * the rare work of the attitude update sits behind one wave-uniform branch (Att::step).
 constexpr int kSplitTileF = 6;
 constexpr int kSplitRunsF = 256;
 constexpr size_t kSplitLdsF = sizeof(float) * 2 * kSplitTileF * 12 * kSplitRunsF;      // 144 KiB
 
-template <int RF, int ALGOS, bool WD, int PROD>
-__global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const ginsim_mc_params a) {
+typedef const float __attribute__((address_space(4))) * uniform_f32_ptr;
+
+struct Planes3 {            // three consecutive [n][runs] float planes behind one buffer descriptor
+    __amdgpu_buffer_rsrc_t rs;
+    F32_FM void init(float* base) { rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, -1 /* 4 GiB - 1 */, 0x00020000); }
+    F32_FM void store(uint32_t voff, uint32_t pl, float x, float y, float z) const {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, voff, 0, 2);         // aux 2 = nt
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs, voff, pl, 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), rs, voff, 2 * pl, 2);
+    }
+};
+
+struct TrajOut {
+    Planes3 att, pos, vel;
+    F32_FM void init(float* base, int64_t plane) { att.init(base); pos.init(base + 3 * plane); vel.init(base + 6 * plane); }
+    template <int RF>
+    F32_FM void store(uint32_t voff, uint32_t pl, const Nav& s) const {
+        att.store(voff, pl, s.att.yaw.v, s.att.pit.v, s.att.rol.v);
+        if (RF == 1) pos.store(voff, pl, (float)s.pos[0], (float)s.pos[1], (float)s.pos[2]);
+        else pos.store(voff, pl, (float)(s.pos[0] - s.pos0[0]), (float)(s.pos[1] - s.pos0[1]), (float)(s.pos[2] - s.pos0[2]));
+        vel.store(voff, pl, s.vel.x, s.vel.y, s.vel.z);
+    }
+};
+
+// truth [n][3] + [n][3] (+ [n]) doubles -> [n][8] floats {accel xyz, gyro xyz, odo, 0}: the conversions the sensor sums would
+// otherwise repeat in every lane's instruction stream (same rounding: one v_cvt_f32_f64 each)
+__global__ void truth_f32_kernel(const double* __restrict__ ra, const double* __restrict__ rg, const double* __restrict__ ro,
+                                 int64_t n, float* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float* o = out + 8 * j;
+    o[0] = (float)ra[3 * j]; o[1] = (float)ra[3 * j + 1]; o[2] = (float)ra[3 * j + 2];
+    o[3] = (float)rg[3 * j]; o[4] = (float)rg[3 * j + 1]; o[5] = (float)rg[3 * j + 2];
+    o[6] = ro ? (float)ro[j] : 0.f;
+    o[7] = 0.f;
+}
+
+template <int RF, int ALGOS, bool WD, int PROD, bool KEEP>
+__global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const ginsim_mc_params a, const float* __restrict__ truth32) {
     extern __shared__ float zringf[];                   // [2 stages][T steps][12 normals][256 runs]
     constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
     constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
@@ -427,31 +485,31 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const gi
     const int pgroup = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) - 1;     // which producer group (wave-uniform)
     const int64_t r = (int64_t)blockIdx.x * kSplitRunsF + lane;
     const bool active = r < a.runs;
-    const int64_t n = a.n, runs = a.runs, plane = n * runs;
-    float* o_acc = reinterpret_cast<float*>(a.out_accel);
-    float* o_gyr = reinterpret_cast<float*>(a.out_gyro);
-    float* o_odo = reinterpret_cast<float*>(a.out_odo);
-    float* o_fi = reinterpret_cast<float*>(a.out_traj[0]);
-    float* o_od = reinterpret_cast<float*>(a.out_traj[1]);
-    const bool keep_last = o_acc || o_gyr || o_odo;
-    const int64_t n_noise = keep_last ? n : n - 1;
-    const int64_t ntiles = (n_noise + kSplitTileF - 1) / kSplitTileF;
+    const uint32_t n = (uint32_t)a.n;
+    const int64_t runs = a.runs;
+    const uint32_t n_noise = KEEP ? n : n - 1;            // the last sample only exists as sensor output
+    const uint32_t ntiles = (n_noise + kSplitTileF - 1) / kSplitTileF;
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     __shared__ uint32_t ntab[kNormalTableWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
+#ifdef GINSIM_EXPERIMENT
+    const int exp_flags = a.accel.reserved;
+#else
+    constexpr int exp_flags = 0;
+#endif
 
     if (producer) {
-        for (int64_t i = 0; i <= ntiles; ++i) {
-            if (i < ntiles && active) {
+        for (uint32_t i = 0; i <= ntiles; ++i) {
+            if (i < ntiles && active && !(exp_flags & 1)) {
                 float* stage = zringf + (i & 1) * (kSplitTileF * kStepFloats);
 #pragma unroll
                 for (int t = 0; t < kSplitTileF; ++t) {
-                    const int64_t j = i * kSplitTileF + t;
+                    const uint32_t j = i * kSplitTileF + t;
                     if (j < n_noise && (PROD == 1 || (t % PROD) == pgroup)) {
                         float z0[6], z1[6];
-                        normal_pairs_f32<S_ACC_D_XY, 6>(key, (uint32_t)j, z0, z1, tab);
+                        normal_pairs_f32<S_ACC_D_XY, 6>(key, j, z0, z1, tab);
                         float* zb = stage + t * kStepFloats + lane;
 #pragma unroll
                         for (int k = 0; k < 6; ++k) {
@@ -477,23 +535,33 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const gi
     load_model(a.gyro, mg);
     const float odo_scale = (float)a.odo_scale, odo_stdv = (float)a.odo_stdv;
     float da[3] = {0.f, 0.f, 0.f}, dg[3] = {0.f, 0.f, 0.f};
-    const uniform_ptr ref_a = (uniform_ptr)(uintptr_t)a.ref_accel, ref_g = (uniform_ptr)(uintptr_t)a.ref_gyro,
-                      ref_o = (uniform_ptr)(uintptr_t)a.ref_odo;
-    if (active) {
-        if (FREE && o_fi) store9<RF>(o_fi, plane, r, fi);
-        if (ODO && o_od) store9<RF>(o_od, plane, r, od);
+    const uniform_f32_ptr truth = (uniform_f32_ptr)(uintptr_t)truth32;
+    Planes3 o_acc, o_gyr, o_odo;
+    TrajOut o_fi, o_od;
+    const int64_t plane = (int64_t)n * runs;
+    const uint32_t pl = (uint32_t)plane * 4u, step_bytes = (uint32_t)runs * 4u;
+    uint32_t voff = (uint32_t)r * 4u;                   // byte offset of (sample j, run r) inside a plane
+    if (KEEP) {
+        o_acc.init(reinterpret_cast<float*>(a.out_accel));
+        o_gyr.init(reinterpret_cast<float*>(a.out_gyro));
+        if (ODO) o_odo.init(reinterpret_cast<float*>(a.out_odo));
+        if (FREE) o_fi.init(reinterpret_cast<float*>(a.out_traj[0]), plane);
+        if (ODO) o_od.init(reinterpret_cast<float*>(a.out_traj[1]), plane);
+        if (active) {
+            if (FREE) o_fi.store<RF>(voff, pl, fi);
+            if (ODO) o_od.store<RF>(voff, pl, od);
+        }
     }
-    for (int64_t i = 0; i <= ntiles; ++i) {
-        if (i >= 1 && active) {
+    for (uint32_t i = 0; i <= ntiles; ++i) {
+        if (i >= 1 && active && !(exp_flags & 2)) {
             const float* stage = zringf + ((i - 1) & 1) * (kSplitTileF * kStepFloats);
 #pragma unroll 1
             for (int t = 0; t < kSplitTileF; ++t) {
-                const int64_t j = (i - 1) * kSplitTileF + t;
+                const uint32_t j = (i - 1) * kSplitTileF + t;
                 if (j >= n_noise) break;
-                const int64_t off = j * runs + r;
-                const bool last = (j == n - 1);
-                const double ta[3] = {ref_a[3 * j], ref_a[3 * j + 1], ref_a[3 * j + 2]};
-                const double tg[3] = {ref_g[3 * j], ref_g[3 * j + 1], ref_g[3 * j + 2]};
+                const uniform_f32_ptr tj = truth + 8 * (uint64_t)j;
+                const double ta[3] = {(double)tj[0], (double)tj[1], (double)tj[2]};      // widened and narrowed again: exact
+                const double tg[3] = {(double)tj[3], (double)tj[4], (double)tj[5]};
                 const float* zb = stage + t * kStepFloats + lane;
                 float p0[6], p1[6];                   // z0 / z1 of streams 0..5
 #pragma unroll
@@ -505,22 +573,25 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const gi
                 const float zdg[3] = {p0[3], p1[3], p0[4]}, zwg[3] = {p1[4], p0[5], p1[5]};
                 const V3 acc = sense3<WD>(ta, ma, da, zda, zwa);
                 const V3 gyr = sense3<WD>(tg, mg, dg, zdg, zwg);
-                if (o_acc) { st(o_acc + off, acc.x); st(o_acc + plane + off, acc.y); st(o_acc + 2 * plane + off, acc.z); }
-                if (o_gyr) { st(o_gyr + off, gyr.x); st(o_gyr + plane + off, gyr.y); st(o_gyr + 2 * plane + off, gyr.z); }
-                float odo = 0.f;
-                if (ODO || o_odo) {
-                    odo = fm(odo_stdv, odo_normal(key, (uint32_t)j, tab), odo_scale * (float)ref_o[j]);
-                    if (o_odo) st(o_odo + off, odo);
+                if (KEEP) {
+                    o_acc.store(voff, pl, acc.x, acc.y, acc.z);
+                    o_gyr.store(voff, pl, gyr.x, gyr.y, gyr.z);
                 }
-                if (last) break;
+                float odo = 0.f;
+                if (ODO) {
+                    odo = fm(odo_stdv, odo_normal(key, j, tab), odo_scale * tj[6]);
+                    if (KEEP) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(odo), o_odo.rs, voff, 0, 2);
+                }
+                if (j == n - 1) break;
+                voff += step_bytes;
                 const bool resync = ((j + 1) & (kTrigResync - 1)) == 0;
                 if (FREE) {
                     nav_step<RF, false>(fi, gyr, acc, 0.f, dt, a.earth_rot, resync);
-                    if (o_fi) store9<RF>(o_fi, plane, off + runs, fi);
+                    if (KEEP) o_fi.store<RF>(voff, pl, fi);
                 }
                 if (ODO) {
                     nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot, resync);
-                    if (o_od) store9<RF>(o_od, plane, off + runs, od);
+                    if (KEEP) o_od.store<RF>(voff, pl, od);
                 }
             }
         }
@@ -545,8 +616,20 @@ static int split_prod_f32() {
     return v;
 }
 
+// everything this launch can keep is kept (1) / nothing is (0) / a mixture (-1: the plain kernel tests the pointers per step)
+static int keep_mode_f32(const ginsim_mc_params& p) {
+    const bool fre = (p.algo_mask & GINSIM_ALGO_FREE) != 0, odo = (p.algo_mask & GINSIM_ALGO_ODO) != 0;
+    const bool all = p.out_accel && p.out_gyro && (!fre || p.out_traj[0]) && (!odo || (p.out_traj[1] && p.out_odo)) && (odo || !p.out_odo);
+    const bool none = !p.out_accel && !p.out_gyro && !p.out_odo && !p.out_traj[0] && !p.out_traj[1];
+    return all ? 1 : (none ? 0 : -1);
+}
+
 int mc_variant_f32(const ginsim_mc_params& p) {
-    if (!(p.algo_mask & GINSIM_ALGO_FREE) || p.given_sensors || p.n < 2) return 0;
+    if (!(p.algo_mask & GINSIM_ALGO_FREE) || p.given_sensors || p.block_threads != 0 || p.n < 2) return 0;      // block_threads: the plain kernel (tests)
+    const int keep = keep_mode_f32(p);
+    if (keep < 0) return 0;
+    // the wave-specialised kernel addresses a group of three planes with 32-bit byte offsets
+    if (keep == 1 && (double)p.n * (double)p.runs * 12.0 >= 4294967296.0) return 0;
     const int pol = split_policy_f32();
     if (pol >= 0) return pol != 0;
     return 1;       // three wavefronts per SIMD beat the plain kernel at every size (as for the fp64 kernel)
@@ -559,32 +642,41 @@ static bool any_white_drift_f32(const ginsim_mc_params& p) {
     return f;
 }
 
+template <int RF, int ALGOS, bool WD, int PROD, bool KEEP>
+static hipError_t launch_split_f32(const ginsim_mc_params& p, const float* truth32, hipStream_t stream) {
+    static bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&f32::mc_kernel_f32_split<RF, ALGOS, WD, PROD, KEEP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)f32::kSplitLdsF);
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((f32::mc_kernel_f32_split<RF, ALGOS, WD, PROD, KEEP>), dim3((unsigned)((p.runs + 255) / 256)), dim3(256 * (1 + PROD)),
+                       f32::kSplitLdsF, stream, p, truth32);
+    return hipGetLastError();
+}
+
 // name != nullptr: write the kernel's name (as rocprofv3 reports it, without arguments) instead of launching
 template <int RF, int ALGOS, bool WD>
-static hipError_t launch3_f32(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
+static hipError_t launch3_f32(const ginsim_mc_params& p, const float* truth32, hipStream_t stream, char* name, size_t cap) {
     const int tb = 256;
     const int64_t waves = (p.runs + 63) / 64;
     if constexpr ((ALGOS & GINSIM_ALGO_FREE) != 0) {
         if (mc_variant_f32(p)) {
-            const int prod = split_prod_f32();
+            // two producer groups (three wavefronts per SIMD, <= 168 registers) where the kernel fits without spilling: one
+            // algorithm with the simple sensor model -- every standard IMU grade, config 5's launch
+            constexpr int PROD = (ALGOS == GINSIM_ALGO_FREE && !WD) ? 2 : 1;
+            const int prod = PROD == 2 ? split_prod_f32() : 1;
+            const bool keep = keep_mode_f32(p) == 1;
             if (name) {
-                snprintf(name, cap, "ginsim::f32::mc_kernel_f32_split<%d, %d, %s, %d>", RF, ALGOS, WD ? "true" : "false", prod);
+                snprintf(name, cap, "ginsim::f32::mc_kernel_f32_split<%d, %d, %s, %d, %s>", RF, ALGOS, WD ? "true" : "false", prod,
+                         keep ? "true" : "false");
                 return hipSuccess;
             }
-            static bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&f32::mc_kernel_f32_split<RF, ALGOS, WD, 1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)f32::kSplitLdsF);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&f32::mc_kernel_f32_split<RF, ALGOS, WD, 2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)f32::kSplitLdsF);
-                return true;
-            }();
-            (void)once;
-            const dim3 grid((unsigned)((p.runs + 255) / 256));
-            if (prod == 2)
-                hipLaunchKernelGGL((f32::mc_kernel_f32_split<RF, ALGOS, WD, 2>), grid, dim3(768), f32::kSplitLdsF, stream, p);
-            else
-                hipLaunchKernelGGL((f32::mc_kernel_f32_split<RF, ALGOS, WD, 1>), grid, dim3(512), f32::kSplitLdsF, stream, p);
-            return hipGetLastError();
+            hipLaunchKernelGGL(f32::truth_f32_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, p.ref_accel, p.ref_gyro,
+                               p.ref_odo, p.n, const_cast<float*>(truth32));
+            if (prod == PROD)
+                return keep ? launch_split_f32<RF, ALGOS, WD, PROD, true>(p, truth32, stream) : launch_split_f32<RF, ALGOS, WD, PROD, false>(p, truth32, stream);
+            return keep ? launch_split_f32<RF, ALGOS, WD, 1, true>(p, truth32, stream) : launch_split_f32<RF, ALGOS, WD, 1, false>(p, truth32, stream);
         }
     }
     if (name) {
@@ -599,7 +691,7 @@ static hipError_t launch3_f32(const ginsim_mc_params& p, hipStream_t stream, cha
 }
 
 template <int RF, int ALGOS>
-static hipError_t launch2_f32(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
+static hipError_t launch2_f32(const ginsim_mc_params& p, const float* truth32, hipStream_t stream, char* name, size_t cap) {
     if (p.given_sensors) {
         if (name) {
             snprintf(name, cap, "ginsim::f32::mc_kernel_f32<%d, %d, true, false>", RF, ALGOS);
@@ -611,20 +703,28 @@ static hipError_t launch2_f32(const ginsim_mc_params& p, hipStream_t stream, cha
         hipLaunchKernelGGL((f32::mc_kernel_f32<RF, ALGOS, true, false>), dim3((unsigned)((p.runs + 255) / 256)), dim3(256), lds, stream, p);
         return hipGetLastError();
     }
-    return any_white_drift_f32(p) ? launch3_f32<RF, ALGOS, true>(p, stream, name, cap) : launch3_f32<RF, ALGOS, false>(p, stream, name, cap);
+    return any_white_drift_f32(p) ? launch3_f32<RF, ALGOS, true>(p, truth32, stream, name, cap) : launch3_f32<RF, ALGOS, false>(p, truth32, stream, name, cap);
 }
 
 template <int RF>
-static hipError_t launch1_f32(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
+static hipError_t launch1_f32(const ginsim_mc_params& p, const float* truth32, hipStream_t stream, char* name, size_t cap) {
     switch (p.algo_mask) {
-        case GINSIM_ALGO_FREE: return launch2_f32<RF, GINSIM_ALGO_FREE>(p, stream, name, cap);
-        case GINSIM_ALGO_ODO: return launch2_f32<RF, GINSIM_ALGO_ODO>(p, stream, name, cap);
-        default: return launch2_f32<RF, GINSIM_ALGO_FREE | GINSIM_ALGO_ODO>(p, stream, name, cap);
+        case GINSIM_ALGO_FREE: return launch2_f32<RF, GINSIM_ALGO_FREE>(p, truth32, stream, name, cap);
+        case GINSIM_ALGO_ODO: return launch2_f32<RF, GINSIM_ALGO_ODO>(p, truth32, stream, name, cap);
+        default: return launch2_f32<RF, GINSIM_ALGO_FREE | GINSIM_ALGO_ODO>(p, truth32, stream, name, cap);
     }
 }
 
-hipError_t launch_mc_f32(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
-    return p.ref_frame == 1 ? launch1_f32<1>(p, stream, name, cap) : launch1_f32<0>(p, stream, name, cap);
+// truth32: device scratch of n x 8 floats (mc_f32_truth_bytes) the wave-specialised kernel's truth is converted into
+size_t mc_f32_truth_bytes(const ginsim_mc_params& p) { return mc_variant_f32(p) ? sizeof(float) * 8 * (size_t)p.n : 0; }
+
+hipError_t launch_mc_f32(const ginsim_mc_params& p_in, float* truth32, hipStream_t stream, char* name, size_t cap) {
+    ginsim_mc_params p = p_in;
+#ifdef GINSIM_EXPERIMENT
+    static const int exp = [] { const char* e = getenv("GINSIM_EXP"); return e ? atoi(e) : 0; }();
+    p.accel.reserved = exp;
+#endif
+    return p.ref_frame == 1 ? launch1_f32<1>(p, truth32, stream, name, cap) : launch1_f32<0>(p, truth32, stream, name, cap);
 }
 
 // gather selected runs of a float series: [C][n][runs] (float) -> out [nsel][n][C] (double), optional per-component origin

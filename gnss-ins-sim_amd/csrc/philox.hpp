@@ -2,9 +2,10 @@
 //
 // Philox4x32-7 (Salmon, Moraes, Dror, Shaw, SC'11: seven rounds is the paper's Crush-resistant Philox4x32, ten its
 // conservative default; Random123 constants and known-answer vectors for both round counts are in the tests) +
-// a Box-Muller transform defined bit-exactly in single precision (fastmath.hpp).  A pair of normals takes the two words
-// of a half block -- a 32-bit radius uniform (|z| up to 6.8 sigma) and a 24-bit angle uniform -- so one 128-bit block
-// yields TWO pairs, and the six pairs (twelve normals) of an IMU step cost exactly three blocks:
+// a normal transform defined bit-exactly in single precision (fastmath.hpp normal_icdf: one 32-bit word -> one normal by
+// piecewise-cubic inversion of the tail probability, |z| up to 6.23 sigma).  A stream's pair of normals takes the two
+// words of a half block, so one 128-bit block yields TWO pairs (four normals), and the six pairs (twelve normals) of an
+// IMU step cost exactly three blocks:
 //     stream s at sample j  =  half (s & 1) of block  philox4x32_7(counter = (j, s >> 1, run_lo, run_hi), key = seed)
 // It replaces the reference's serial global np.random.randn stream
 // (gnss_ins_sim/pathgen/pathgen.py:495,557,588,593,621-622,639,660): every (run, stream, sample)
@@ -56,56 +57,19 @@ struct RngKey {
     uint32_t r0, r1;    // global run id
 };
 
-// Box-Muller on N (radius word, angle word) draws, phase by phase -- all logarithms, then all square roots, then
-// all sin/cos -- instead of N complete transforms in a row: each phase is N independent dependency chains (ILP for
-// a lone wavefront on its SIMD).  The normals are single-precision numbers.
+// N (word a, word b) draws -> N pairs of normals: z0 = normal_icdf(a), z1 = normal_icdf(b) (fastmath.hpp).  The normals are
+// single-precision numbers.
 template <int N>
-__device__ __forceinline__ void box_muller(const uint32_t (&a)[N], const uint32_t (&b)[N], float (&z0)[N], float (&z1)[N],
-                                           const NormalTables& tab) {
-#pragma clang fp contract(off)
-    float r[N];
-#ifdef GINSIM_BM_SCALAR
-#pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = radius2_f32(a[k], tab);
-#else
-#pragma unroll
-    for (int k = 0; k + 1 < N; k += 2) {
-        const v2f x = radius2_f32x2(a[k], a[k + 1], tab);
-        r[k] = x.x;
-        r[k + 1] = x.y;
-    }
-    if (N & 1) r[N - 1] = radius2_f32(a[N - 1], tab);
-#endif
-#pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = sqrt_rn_f32(r[k]);
-#ifdef GINSIM_BM_SCALAR
+__device__ __forceinline__ void normal_transform(const uint32_t (&a)[N], const uint32_t (&b)[N], float (&z0)[N], float (&z1)[N],
+                                                 const NormalTables& tab) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        float s, c;
-        sincos_f32(b[k], s, c, tab);
-        z0[k] = r[k] * c;
-        z1[k] = r[k] * s;
+        z0[k] = normal_icdf(a[k], tab);
+        z1[k] = normal_icdf(b[k], tab);
     }
-#else
-#pragma unroll
-    for (int k = 0; k + 1 < N; k += 2) {
-        v2f s, c;
-        sincos_f32x2(b[k], b[k + 1], s, c, tab);
-        const v2f rr = {r[k], r[k + 1]};
-        const v2f c0 = rr * c, c1 = rr * s;
-        z0[k] = c0.x; z0[k + 1] = c0.y;
-        z1[k] = c1.x; z1[k + 1] = c1.y;
-    }
-    if (N & 1) {
-        float s, c;
-        sincos_f32(b[N - 1], s, c, tab);
-        z0[N - 1] = r[N - 1] * c;
-        z1[N - 1] = r[N - 1] * s;
-    }
-#endif
 }
 
-// The two words (a: radius, b: angle, of which the low 24 bits count) of the N consecutive streams FIRST .. FIRST+N-1
+// The two words (a, b) of the N consecutive streams FIRST .. FIRST+N-1
 // at sample j: blocks FIRST >> 1 .. (FIRST+N-1) >> 1, each computed once.
 template <uint32_t FIRST, int N>
 __device__ __forceinline__ void draw_streams(const RngKey& key, uint32_t j, uint32_t* a, uint32_t* b) {
@@ -129,7 +93,7 @@ template <uint32_t FIRST, int N>
 __device__ __forceinline__ void normal_pairs_f32(const RngKey& key, uint32_t j, float (&z0)[N], float (&z1)[N], const NormalTables& tab) {
     uint32_t a[N], b[N];
     draw_streams<FIRST, N>(key, j, a, b);
-    box_muller<N>(a, b, z0, z1, tab);
+    normal_transform<N>(a, b, z0, z1, tab);
 }
 
 // ... and widened to fp64 (exact) for the fp64 sensor models
@@ -151,7 +115,7 @@ __device__ __forceinline__ void normal_pair(const RngKey& key, uint32_t stream, 
     const bool hi = (stream & 1u) != 0;
     const uint32_t a[1] = {hi ? w.z : w.x}, b[1] = {hi ? w.w : w.y};
     float f0[1], f1[1];
-    box_muller<1>(a, b, f0, f1, tab);
+    normal_transform<1>(a, b, f0, f1, tab);
     z0 = (double)f0[0];
     z1 = (double)f1[0];
 }

@@ -5,4 +5,4 @@ built.  There is no CPU implementation behind it.
 """
 from ._lib import lib, LIB_PATH, EXPORTS, GinsimError, ALGO_FREE, ALGO_ODO          # noqa: F401
 from .engine import (Context, DeviceBuffer, MonteCarloJob, AuxSensorJob, StatsResult, device_count, pathgen, pinned_empty,  # noqa: F401
-                     sensor_model, ini_table, free_integration_host, rng_normals, box_muller, default_context, allan_var, allan_var_host)
+                     sensor_model, ini_table, free_integration_host, rng_normals, normal_transform, default_context, allan_var, allan_var_host)

@@ -107,7 +107,7 @@ _SIGS = {
     'ginsim_allan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_double, _PD, _PD,
                                C.POINTER(C.c_int32), C.c_int32]),
     'ginsim_runs_to_series': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
-    'ginsim_box_muller': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int64, _PD, _PD]),
+    'ginsim_normal_transform': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int64, _PD, _PD]),
     'ginsim_rng_normals': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, _PD, _PD,
                                      C.POINTER(C.c_uint32)]),
 }

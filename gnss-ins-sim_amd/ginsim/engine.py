@@ -494,14 +494,15 @@ class MonteCarloJob(object):
             return self._gather(self._bufs['odo'].ptr, 1, run_ids)[:, :, 0]
         return self._gather(self._bufs[name].ptr, 3, run_ids)
 
-    def trajectories(self, algo, run_ids):
-        """(att, pos, vel) of selected runs, each (k,n,3)."""
+    def trajectories(self, algo, run_ids, displacement=False):
+        """(att, pos, vel) of selected runs, each (k,n,3).  displacement=True (fp32 jobs): the position series as the kernel
+        wrote it -- the displacement from the run's initial position -- instead of initial position + displacement."""
         if not self.keep_traj:
             raise ValueError('trajectories were not kept (keep_traj=False)')
         base = self._bufs['traj_' + algo].ptr
         plane = self.n * self.runs * self._esize
         att, pos, vel = (self._gather(base + 3 * k * plane, 3, run_ids) for k in range(3))
-        if self.precision == 'f32':         # the device series is the displacement from the run's initial position
+        if self.precision == 'f32' and not displacement:         # the device series is the displacement from the run's initial position
             from gnss_ins_sim.geoparams import geoparams
             ids = np.asarray(run_ids, dtype=np.int64).reshape(-1)
             for k, r in enumerate(ids):
@@ -627,11 +628,12 @@ def rng_normals(ctx, seed, run, stream, count, words=False):
     return (z0, z1, w) if words else (z0, z1)
 
 
-def box_muller(ctx, words):
-    """Device Box-Muller on given Philox words (count, 4) uint32 -> (z0, z1).  Test hook for corner cases."""
+def normal_transform(ctx, words):
+    """The device's normal transform on given Philox words (count, 4) uint32 -> (z0 from word 0, z1 from word 1).  Test hook
+    for corner cases."""
     w = np.ascontiguousarray(np.asarray(words, dtype=np.uint32).reshape(-1, 4))
     z0, z1 = np.empty(w.shape[0]), np.empty(w.shape[0])
-    check(lib.ginsim_box_muller(ctx.handle, w.ctypes.data_as(C.POINTER(C.c_uint32)), w.shape[0], dptr(z0), dptr(z1)))
+    check(lib.ginsim_normal_transform(ctx.handle, w.ctypes.data_as(C.POINTER(C.c_uint32)), w.shape[0], dptr(z0), dptr(z1)))
     return z0, z1
 
 

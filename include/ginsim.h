@@ -237,19 +237,19 @@ int ginsim_allan(ginsim_ctx* ctx, const double* x, int64_t n, int32_t nseries, i
 int ginsim_runs_to_series(ginsim_ctx* ctx, const double* series, int32_t ncomp, int64_t n, int64_t runs, double* out);
 
 /* ---- RNG self-test hook: first `count` normal pairs of (seed, run, stream) computed ON DEVICE.  Stream s at sample j is
- *      half (s & 1) of the Philox4x32-7 block with counter (j, s >> 1, run_lo, run_hi) and key = seed: a 32-bit radius
- *      uniform and a 24-bit angle uniform per pair, transformed by a Box-Muller that is defined operation by operation
- *      in IEEE single precision (csrc/fastmath.hpp; spelled out in oracle/philox.py, which reproduces the device's
- *      normals to the bit).  The normals are single-precision numbers returned as doubles.  host_words, if given,
- *      receives the raw block with counter (j, stream, run_lo, run_hi). ---- */
+ *      half (s & 1) of the Philox4x32-7 block with counter (j, s >> 1, run_lo, run_hi) and key = seed; each of its two words
+ *      gives one normal by a piecewise-cubic inversion of the tail probability that is defined operation by operation in
+ *      IEEE single precision on a committed coefficient table (csrc/fastmath.hpp normal_icdf; spelled out in
+ *      oracle/philox.py, which reproduces the device's normals to the bit).  |z| <= 6.23.  The normals are single-precision
+ *      numbers returned as doubles.  host_words, if given, receives the raw block with counter (j, stream, run_lo, run_hi). ---- */
 int ginsim_rng_normals(ginsim_ctx* ctx, uint64_t seed, uint64_t run, uint32_t stream, int64_t count,
                        double* host_z0, double* host_z1, uint32_t* host_words /*[count][4] or NULL*/);
 
-/* Test hook: the device Box-Muller transform applied to caller-chosen Philox words (w[i][0..1] = the two words of a half
- * block: radius uniform from w[i][0], angle from the low 24 bits of w[i][1]; w[i][2..3] unused), so that corner cases no seed will produce in a test (largest / smallest u, table-bin and sector edges) can be
- * pinned against the oracle. */
-int ginsim_box_muller(ginsim_ctx* ctx, const uint32_t* host_words /*[count][4]*/, int64_t count, double* host_z0,
-                      double* host_z1);
+/* Test hook: the device's normal transform applied to caller-chosen Philox words (z0 from w[i][0], z1 from w[i][1]; w[i][2..3]
+ * unused), so that corner cases no seed will produce in a test (smallest / largest magnitude, every segment edge of the
+ * coefficient table) can be pinned against the oracle. */
+int ginsim_normal_transform(ginsim_ctx* ctx, const uint32_t* host_words /*[count][4]*/, int64_t count, double* host_z0,
+                            double* host_z1);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@
  *   geo_param / lla2ecef              gnss_ins_sim/geoparams/geoparams.py:25-53 / 70-87
  *   array_error (end point)           gnss_ins_sim/sim/ins_data_manager.py:537-541, 737
  *
- * The noise source is the engine's Philox4x32-7 + single-precision Box-Muller stream (see oracle/philox.py for the
+ * The noise source is the engine's Philox4x32-7 + single-precision inverse-CDF stream (see oracle/philox.py for the
  * definition, which is exact to the bit, and why the reference's own np.random stream is "parity unpinned").
  * Pinned against the NumPy oracle (itself pinned against the executed reference) in
  * tests/test_oracle_c.py.  Compile with -ffp-contract=off.
@@ -49,57 +49,38 @@ static void philox4x32_7(uint32_t c[4], uint32_t k0, uint32_t k1) {
     }
 }
 
-/* The two fp32 tables of the generator: the committed numbers the device uses (csrc/normal_tables.inc, made by
- * tools/gen_normal_tables.py; oracle/philox.py builds them independently and the tests compare the bits). */
-static const uint32_t normal_table_bits[256 * 4 + 512 * 2] = {
+/* The coefficient table of the generator: the committed numbers the device uses (csrc/normal_tables.inc, made by
+ * tools/gen_normal_tables.py; oracle/philox.py reads the same file). */
+static const uint32_t normal_table_bits[31 * 8 * 4] = {
 #include "normal_tables.inc"
 };
 static float bits_f32(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static uint32_t f32_bits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
 
-/* stream s at sample j = half (s & 1) of block (j, s >> 1); the transform is defined operation by operation in IEEE
- * single precision (no fused multiply-adds: this file is compiled with -ffp-contract=off) -- oracle/philox.py */
-static void normal_pair(uint64_t seed, uint64_t run, uint32_t stream, uint32_t j, double* z0, double* z1) {
+/* one standard normal from one 32-bit word: piecewise-cubic inversion of the upper tail probability t = m 2^-32,
+ * defined operation by operation (oracle/philox.py normal_icdf) */
+static float normal_icdf(uint32_t w) {
+    const uint32_t m = (w & 0x7fffffffu) | 1u;
+    const int lz = __builtin_clz(m);                                   /* 1 .. 31 */
+    const uint32_t y = m << lz;
+    const uint32_t* c = normal_table_bits + 4 * ((lz - 1) * 8 + (int)((y >> 28) & 7u));
+    const float x = bits_f32(0x3f800000u | ((y << 4) >> 9));
+    const float z = fmaf(fmaf(fmaf(bits_f32(c[3]), x, bits_f32(c[2])), x, bits_f32(c[1])), x, bits_f32(c[0]));
+    return bits_f32((f32_bits(z) & 0x7fffffffu) | (w & 0x80000000u));
+}
+
+/* stream s at sample j = half (s & 1) of block (j, s >> 1): z0 from its first word, z1 from its second */
+static void normal_pair_f32(uint64_t seed, uint64_t run, uint32_t stream, uint32_t j, float* z0, float* z1) {
     uint32_t W[4] = {j, stream >> 1, (uint32_t)run, (uint32_t)(run >> 32)};
     philox4x32_7(W, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const uint32_t a = (stream & 1u) ? W[2] : W[0], b = (stream & 1u) ? W[3] : W[1];
-    /* radius: x = -2 ln u, u = (f32(a) + 1/2) 2^-32 */
-    const float t = (float)a;
-    const float u = (t + 0.5f) * 0x1.0p-32f;
-    const uint32_t hx = f32_bits(u) + (0x3f800000u - 0x3f3504f3u);
-    const float ef = (float)((int32_t)(hx >> 23) - 127);
-    const uint32_t* lg = normal_table_bits + 4 * ((hx >> 15) & 255u);
-    const float m = bits_f32((hx & 0x007fffffu) + 0x3f3504f3u);
-    const float d = m - bits_f32(lg[0]);
-    const float r = d * bits_f32(lg[1]);
-    float q = r * (1.0f / 12.0f);
-    q = q + 0.25f;
-    const float r2 = r * r;
-    q = q * r2;
-    const float small = r + q;
-    float x = ef * -1.3862943611198906f;
-    x = x + bits_f32(lg[2]);
-    x = x + small;
-    const float rad = sqrtf(x);
-    /* direction: sin, cos of 2 pi ((b & 0xffffff) + 1/2) 2^-24 */
-    const uint32_t* sc = normal_table_bits + 256 * 4 + 2 * ((b >> 15) & 511u);
-    const float sn_i = bits_f32(sc[0]), cs_i = bits_f32(sc[1]);
-    float bb = (float)(int32_t)(b & 0x7fffu) + (0.5f - 16384.0f);
-    bb = bb * 3.7450703562e-07f;               /* f32(2 pi 2^-24) */
-    const float tt = bb * bb;
-    float u1 = tt * (-1.0f / 6.0f);
-    u1 = u1 * bb;
-    const float sb = bb + u1;
-    const float cm = tt * -0.5f;
-    float p1 = cs_i * sb;
-    const float p2 = sn_i * cm;
-    p1 = p1 + p2;
-    const float sn = sn_i + p1;
-    float q1 = cs_i * cm;
-    const float q2 = sn_i * sb;
-    q1 = q1 - q2;
-    const float cs = cs_i + q1;
-    const float a0 = rad * cs, a1 = rad * sn;
+    *z0 = normal_icdf((stream & 1u) ? W[2] : W[0]);
+    *z1 = normal_icdf((stream & 1u) ? W[3] : W[1]);
+}
+
+/* the fp64 path widens the single-precision normals (exactly) */
+static void normal_pair(uint64_t seed, uint64_t run, uint32_t stream, uint32_t j, double* z0, double* z1) {
+    float a0, a1;
+    normal_pair_f32(seed, run, stream, j, &a0, &a1);
     *z0 = (double)a0;
     *z1 = (double)a1;
 }
@@ -322,6 +303,318 @@ int oracle_mc_run(const oracle_mc_t* p, const double* ini_table, const double* r
                                 sens[(r * n + j) * 6 + k] = acc[3 * j + k];
                                 sens[(r * n + j) * 6 + 3 + k] = gyr[3 * j + k];
                             }
+                }
+            }
+        }
+        free(acc); free(gyr); free(odo); free(att); free(pos); free(vel);
+    }
+    return fail ? -1 : 0;
+}
+
+
+/* ================================================================ fp32 path (BASELINE config 5)
+ *
+ * Float restatement of the SAME reference functions (acc_gen / gyro_gen / bias_drift, odo_gen, FreeIntegration.run for both
+ * plugins and both frames), written to the numerical scheme of the fp32 HIP kernel (csrc/mc_kernel_f32.hip) OPERATION BY
+ * OPERATION: every product, sum, quotient and square root is one IEEE single-precision operation in the kernel's order
+ * (this file is compiled with -ffp-contract=off; fused multiply-adds are the explicit fmaf / fma calls), the attitude
+ * carries Kahan-compensated Euler angles and a cached sin/cos that is rotated by the step and re-evaluated exactly
+ * (sincos_def: fp64 quadrant reduction + Taylor polynomials, rounded to float once) every 32 steps, on a pitch fold and
+ * for steps > 0.25 rad; position is accumulated in fp64 (ref_frame 1: the displacement from the initial ECEF position).
+ * The kernel's sensor series and trajectories must equal this function's BIT FOR BIT (tests/test_gpu_fp32.py); against
+ * the reference's fp64 outputs it is held to the stated fp32 tolerances (tests/test_oracle_c.py, reference-executed
+ * goldens T1 / T2 / T3).  The noise is the fp64 path's: the same single-precision normals, not widened. */
+#define TRIG_RESYNC 32
+static const float PI_F = 3.14159265358979323846f, HALF_PI_F = 1.57079632679489661923f;
+static const float TWO_PI_HI = 6.28318548202514648438f, TWO_PI_LO = -1.74845553146951715e-07f;
+
+static void sincos_def(double x, float* sn, float* cs) {
+    const double k = rint(x * 0.63661977236758134308);
+    double r = fma(-k, 1.57079632679489655800e+00, x);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const double t = r * r;
+    double ps = -1.0 / 39916800.0;
+    ps = fma(ps, t, 1.0 / 362880.0);
+    ps = fma(ps, t, -1.0 / 5040.0);
+    ps = fma(ps, t, 1.0 / 120.0);
+    ps = fma(ps, t, -1.0 / 6.0);
+    const double s = fma(r * t, ps, r);
+    double pc = 1.0 / 479001600.0;
+    pc = fma(pc, t, -1.0 / 3628800.0);
+    pc = fma(pc, t, 1.0 / 40320.0);
+    pc = fma(pc, t, -1.0 / 720.0);
+    pc = fma(pc, t, 1.0 / 24.0);
+    pc = fma(pc, t, -0.5);
+    const double c = fma(t, pc, 1.0);
+    const int q = (int)k & 3;
+    const double so = (q & 1) ? c : s, co = (q & 1) ? s : c;
+    *sn = (float)((q & 2) ? -so : so);
+    *cs = (float)(((q + 1) & 2) ? -co : co);
+}
+
+typedef struct { float v, comp; } kahan_t;
+static void kadd(kahan_t* a, float inc) {
+    const float t = inc - a->comp;
+    const float s = a->v + t;
+    a->comp = (s - a->v) - t;
+    a->v = s;
+}
+
+static void rotate_f32(float d, float* s, float* c) {      /* sin/cos(a + d) from sin/cos(a), |d| <= 0.25 */
+    const float t = d * d;
+    const float sd = d * fmaf(t, fmaf(t, 8.3333333e-3f, -1.6666667e-1f), 1.0f);
+    const float cm1 = t * fmaf(t, fmaf(t, -1.3888889e-3f, 4.1666667e-2f), -0.5f);
+    const float s0 = *s, c0 = *c;
+    *s = fmaf(c0, sd, fmaf(s0, cm1, s0));
+    *c = fmaf(-s0, sd, fmaf(c0, cm1, c0));
+}
+
+typedef struct { kahan_t yaw, pit, rol; float sy, cy, sp, cp, sr, cr; } att32_t;
+
+static void att_resync(att32_t* a) {
+    sincos_def((double)a->yaw.v, &a->sy, &a->cy);
+    sincos_def((double)a->pit.v, &a->sp, &a->cp);
+    sincos_def((double)a->rol.v, &a->sr, &a->cr);
+}
+
+/* attitude.euler2dcm(., 'zyx') (attitude.py:360-368, n -> b) from the cached trig */
+static void dcm_f32(const att32_t* a, float c[3][3]) {
+    const float srsp = a->sr * a->sp, spcr = a->sp * a->cr;
+    c[0][0] = a->cp * a->cy;                          c[0][1] = a->cp * a->sy;                          c[0][2] = -a->sp;
+    c[1][0] = fmaf(srsp, a->cy, -(a->cr * a->sy));    c[1][1] = fmaf(srsp, a->sy, a->cr * a->cy);       c[1][2] = a->cp * a->sr;
+    c[2][0] = fmaf(spcr, a->cy, a->sy * a->sr);       c[2][1] = fmaf(spcr, a->sy, -(a->cy * a->sr));    c[2][2] = a->cp * a->cr;
+}
+static void mat_vec_f32(float c[3][3], const float* v, float* o) {
+    for (int i = 0; i < 3; ++i) o[i] = fmaf(c[i][2], v[2], fmaf(c[i][1], v[1], c[i][0] * v[0]));
+}
+static void mat_t_vec_f32(float c[3][3], const float* v, float* o) {
+    for (int i = 0; i < 3; ++i) o[i] = fmaf(c[2][i], v[2], fmaf(c[1][i], v[1], c[0][i] * v[0]));
+}
+static void cross_f32(const float* a, const float* b, float* o) {
+    o[0] = fmaf(a[1], b[2], -(a[2] * b[1]));
+    o[1] = fmaf(a[2], b[0], -(a[0] * b[2]));
+    o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+
+/* attitude.euler_update_zyx (attitude.py:679-721) */
+static void att_step_f32(att32_t* a, const float* w, float dt, int resync) {
+    const float q = fmaf(w[2], a->cr, w[1] * a->sr);
+    const float icp = 1.0f / a->cp;
+    const float dy = (q * icp) * dt;
+    const float dp = fmaf(w[1], a->cr, -(w[2] * a->sr)) * dt;
+    const float dr = fmaf(q, a->sp * icp, w[0]) * dt;
+    kadd(&a->yaw, dy); kadd(&a->pit, dp); kadd(&a->rol, dr);
+    const int fold = (a->pit.v > HALF_PI_F) || (a->pit.v < -HALF_PI_F);
+    if (fold) {
+        a->pit.v = a->pit.v > 0.f ? PI_F - a->pit.v : -PI_F - a->pit.v;
+        a->pit.comp = 0.f;
+        kadd(&a->yaw, PI_F); kadd(&a->rol, PI_F);
+    }
+    if (a->yaw.v > PI_F) { kadd(&a->yaw, -TWO_PI_HI); kadd(&a->yaw, -TWO_PI_LO); }
+    else if (a->yaw.v < -PI_F) { kadd(&a->yaw, TWO_PI_HI); kadd(&a->yaw, TWO_PI_LO); }
+    if (a->rol.v > PI_F) { kadd(&a->rol, -TWO_PI_HI); kadd(&a->rol, -TWO_PI_LO); }
+    else if (a->rol.v < -PI_F) { kadd(&a->rol, TWO_PI_HI); kadd(&a->rol, TWO_PI_LO); }
+    const float big = fmaxf(fabsf(dy), fmaxf(fabsf(dp), fabsf(dr)));
+    if (resync || fold || !(big <= 0.25f)) {
+        att_resync(a);
+    } else {
+        rotate_f32(dy, &a->sy, &a->cy); rotate_f32(dp, &a->sp, &a->cp); rotate_f32(dr, &a->sr, &a->cr);
+    }
+}
+
+/* float sensor series of one run: meas[n][3] (pathgen.py:441-594), the normals of streams s0 .. s0+2 as they are */
+static void sensor_gen_f32(uint64_t seed, uint64_t run, uint32_t s0, int64_t n, const double* ref,
+                           const sensor_model_t* m, float* meas) {
+    float d[3] = {0.f, 0.f, 0.f};
+    for (int64_t j = 0; j < n; ++j) {
+        float zd[3], zw[3];
+        normal_pair_f32(seed, run, s0, (uint32_t)j, &zd[0], &zd[1]);
+        normal_pair_f32(seed, run, s0 + 1, (uint32_t)j, &zd[2], &zw[0]);
+        normal_pair_f32(seed, run, s0 + 2, (uint32_t)j, &zw[1], &zw[2]);
+        for (int i = 0; i < 3; ++i) {
+            const float bz = (float)m->gm_b[i] * zd[i];
+            const float dj = m->white_drift[i] ? bz : d[i];
+            const float base = ((float)ref[3 * j + i] + (float)m->bias[i]) + dj;
+            meas[3 * j + i] = fmaf((float)m->white[i], zw[i], base);
+            d[i] = fmaf((float)m->gm_a[i], d[i], bz);
+        }
+    }
+}
+
+/* FreeIntegration.run in float (free_integration.py:63-174; odo != NULL: free_integration_odo.py:63-160).
+ * att / vel [n][3] float; dpos [n][3] float = position MINUS the initial position (ECEF displacement for ref_frame 1,
+ * lat / lon / alt differences for ref_frame 0); end_pos[3] = the fp64 position at the last sample. */
+void oracle_free_integration_f32(int ref_frame, double fs, int earth_rot, int64_t n, const float* gyro,
+                                 const float* accel, const float* odo, const double* ini, int has_g,
+                                 float* att, float* dpos, float* vel, double* end_pos) {
+    const float dt = (float)(1.0 / fs);
+    att32_t a;
+    a.yaw.v = (float)ini[6]; a.pit.v = (float)ini[7]; a.rol.v = (float)ini[8];
+    a.yaw.comp = a.pit.comp = a.rol.comp = 0.f;
+    att_resync(&a);
+    float c[3][3];
+    kahan_t vb[3], vn[3];
+    float vb0[3] = {(float)ini[3], (float)ini[4], (float)ini[5]}, v[3];
+    for (int k = 0; k < 3; ++k) { vb[k].v = vb0[k]; vb[k].comp = 0.f; }
+    dcm_f32(&a, c);
+    mat_t_vec_f32(c, vb0, v);
+    for (int k = 0; k < 3; ++k) { vn[k].v = v[k]; vn[k].comp = 0.f; }
+    double pos[3], pos0[3];
+    float g, sl, cl;
+    if (ref_frame == 1) {
+        lla2ecef(ini, pos0);
+        pos[0] = pos[1] = pos[2] = 0.0;
+        g = (float)(has_g ? ini[9] : geo_param(ini[0], ini[2]).g);
+    } else {
+        for (int k = 0; k < 3; ++k) pos0[k] = pos[k] = ini[k];
+        g = has_g ? (float)ini[9] : 0.f;
+    }
+    sincos_def(ini[0], &sl, &cl);
+    for (int64_t i = 0;; ++i) {
+        att[3 * i] = a.yaw.v; att[3 * i + 1] = a.pit.v; att[3 * i + 2] = a.rol.v;
+        for (int k = 0; k < 3; ++k) {
+            dpos[3 * i + k] = ref_frame == 1 ? (float)pos[k] : (float)(pos[k] - pos0[k]);
+            vel[3 * i + k] = v[k];
+        }
+        if (i == n - 1) break;
+        const float* w = gyro + 3 * i;
+        const int resync = ((i + 1) & (TRIG_RESYNC - 1)) == 0;
+        if (ref_frame == 1) {
+            const float v_prev[3] = {v[0], v[1], v[2]};
+            if (!odo) {
+                const float gb[3] = {-a.sp, a.cp * a.sr, a.cp * a.cr};          /* C . [0, 0, 1] */
+                const float vbv[3] = {vb[0].v, vb[1].v, vb[2].v};
+                float wxv[3];
+                cross_f32(w, vbv, wxv);
+                for (int k = 0; k < 3; ++k) kadd(&vb[k], (fmaf(gb[k], g, accel[3 * i + k]) - wxv[k]) * dt);
+            }
+            att_step_f32(&a, w, dt, resync);
+            if (odo) {
+                v[0] = (a.cp * a.cy) * odo[i]; v[1] = (a.cp * a.sy) * odo[i]; v[2] = (-a.sp) * odo[i];
+            } else {
+                const float vbv[3] = {vb[0].v, vb[1].v, vb[2].v};
+                dcm_f32(&a, c);
+                mat_t_vec_f32(c, vbv, v);
+            }
+            for (int k = 0; k < 3; ++k) pos[k] += (double)(v_prev[k] * dt);
+        } else {
+            /* geoparams.geo_param (geoparams.py:25-53) in float on the cached sin / cos of the latitude */
+            const float h = (float)pos[2];
+            const float s2 = sl * sl;
+            const float qq = fmaf(-(float)ESQ, s2, 1.0f);
+            const float sq = sqrtf(qq);
+            const float rn = (float)RE / sq;
+            const float rm = (float)(RE * (1.0 - ESQ)) / (qq * sq);
+            const float g1 = ((float)9.7803253359 * fmaf((float)0.00193185265241, s2, 1.0f)) / sq;
+            const float gh = fmaf((float)(3.0 / (RE * RE)), h * h,
+                                  fmaf(-((float)(2.0 / RE) * fmaf(-2.0f * (float)FLAT, s2, (float)(1.0 + FLAT + 0.00344978650684))), h, 1.0f));
+            const float gm = g1 * gh;
+            const float irm = 1.0f / (rm + h), irn = 1.0f / (rn + h), icl = 1.0f / cl;
+            const float w_en[3] = {v[1] * irn, -(v[0] * irm), -(((v[1] * sl) * icl) * irn)};
+            float w_ie[3] = {0.f, 0.f, 0.f};
+            if (earth_rot) { w_ie[0] = (float)WIE * cl; w_ie[2] = -((float)WIE * sl); }
+            const float wsum[3] = {w_en[0] + w_ie[0], w_en[1] + w_ie[1], w_en[2] + w_ie[2]};
+            float wb[3], w_nb[3];
+            dcm_f32(&a, c);
+            mat_vec_f32(c, wsum, wb);
+            for (int k = 0; k < 3; ++k) w_nb[k] = w[k] - wb[k];
+            if (!odo) {
+                float an[3], cor[3];
+                const float w2[3] = {fmaf(2.f, w_ie[0], w_en[0]), fmaf(2.f, w_ie[1], w_en[1]), fmaf(2.f, w_ie[2], w_en[2])};
+                mat_t_vec_f32(c, accel + 3 * i, an);
+                cross_f32(w2, v, cor);
+                const float gg = has_g ? g : gm;
+                kadd(&vn[0], (an[0] - cor[0]) * dt);
+                kadd(&vn[1], (an[1] - cor[1]) * dt);
+                kadd(&vn[2], ((an[2] + gg) - cor[2]) * dt);
+            }
+            att_step_f32(&a, w_nb, dt, resync);
+            const float dlat = (v[0] * irm) * dt;
+            pos[0] += (double)dlat;
+            pos[1] += (double)(((v[1] * irn) * icl) * dt);
+            pos[2] += (double)(-(v[2] * dt));
+            if (resync) sincos_def(pos[0], &sl, &cl);
+            else rotate_f32(dlat, &sl, &cl);
+            if (odo) {
+                v[0] = (a.cp * a.cy) * odo[i]; v[1] = (a.cp * a.sy) * odo[i]; v[2] = (-a.sp) * odo[i];
+            } else {
+                v[0] = vn[0].v; v[1] = vn[1].v; v[2] = vn[2].v;
+            }
+        }
+    }
+    for (int k = 0; k < 3; ++k) end_pos[k] = ref_frame == 1 ? pos0[k] + pos[k] : pos[k];
+}
+
+/* the given-data boundary in float: fp64 series rounded to float as they are read (the kernel's GIVEN mode) */
+void oracle_free_integration_f32_given(int ref_frame, double fs, int earth_rot, int64_t n, const double* gyro,
+                                       const double* accel, const double* odo, const double* ini, int has_g,
+                                       float* att, float* dpos, float* vel, double* end_pos) {
+    float* g = (float*)malloc(sizeof(float) * 3 * n);
+    float* a = (float*)malloc(sizeof(float) * 3 * n);
+    float* o = (float*)malloc(sizeof(float) * n);
+    for (int64_t i = 0; i < 3 * n; ++i) { g[i] = (float)gyro[i]; a[i] = accel ? (float)accel[i] : 0.f; }
+    for (int64_t i = 0; i < n; ++i) o[i] = odo ? (float)odo[i] : 0.f;
+    oracle_free_integration_f32(ref_frame, fs, earth_rot, n, g, a, odo ? o : NULL, ini, has_g, att, dpos, vel, end_pos);
+    free(g); free(a); free(o);
+}
+
+/* end_err [runs][9] (double); traj (optional) [n_keep][n][9] float = att3, position displacement3, vel3; sens (optional)
+ * [n_keep][n][6] float; odo_out (optional) [n_keep][n] float */
+int oracle_mc_run_f32(const oracle_mc_t* p, const double* ini_table, const double* ref_accel, const double* ref_gyro,
+                      const double* ref_odo, double* end_err, int64_t n_keep, float* traj, float* sens, float* odo_out) {
+    const int64_t n = p->n;
+    int fail = 0;
+#pragma omp parallel
+    {
+        float* acc = (float*)malloc(sizeof(float) * 3 * n);
+        float* gyr = (float*)malloc(sizeof(float) * 3 * n);
+        float* odo = (float*)malloc(sizeof(float) * n);
+        float* att = (float*)malloc(sizeof(float) * 3 * n);
+        float* pos = (float*)malloc(sizeof(float) * 3 * n);
+        float* vel = (float*)malloc(sizeof(float) * 3 * n);
+        if (!acc || !gyr || !odo || !att || !pos || !vel) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+#pragma omp for schedule(dynamic, 4)
+            for (int64_t r = 0; r < p->runs; ++r) {
+                const uint64_t run = p->run_offset + (uint64_t)r;
+                const uint64_t call = p->ini_first + (uint64_t)r;
+                const double* ini = ini_table + 10 * (call < (uint64_t)p->n_ini ? call : 0);
+                sensor_gen_f32(p->seed, run, 0, n, ref_accel, &p->accel, acc);
+                sensor_gen_f32(p->seed, run, 3, n, ref_gyro, &p->gyro, gyr);
+                if (ref_odo) {
+                    for (int64_t j = 0; j < n; ++j) {
+                        float z0, z1;
+                        normal_pair_f32(p->seed, run, 6, (uint32_t)j, &z0, &z1);
+                        odo[j] = fmaf((float)p->odo_stdv, z0, (float)p->odo_scale * (float)ref_odo[j]);
+                    }
+                }
+                double end_pos[3];
+                oracle_free_integration_f32(p->ref_frame, p->fs, p->earth_rot, n, gyr, acc, p->algo_odo ? odo : NULL,
+                                            ini, p->ini_has_g, att, pos, vel, end_pos);
+                double* e = end_err + 9 * r;
+                for (int k = 0; k < 3; ++k) {
+                    e[k] = angle_range_pi((double)att[3 * (n - 1) + k] - p->ref_end[k]);
+                    e[3 + k] = end_pos[k] - p->ref_end[3 + k];
+                    e[6 + k] = (double)vel[3 * (n - 1) + k] - p->ref_end[6 + k];
+                }
+                if (r < n_keep) {
+                    if (traj)
+                        for (int64_t j = 0; j < n; ++j)
+                            for (int k = 0; k < 3; ++k) {
+                                traj[(r * n + j) * 9 + k] = att[3 * j + k];
+                                traj[(r * n + j) * 9 + 3 + k] = pos[3 * j + k];
+                                traj[(r * n + j) * 9 + 6 + k] = vel[3 * j + k];
+                            }
+                    if (sens)
+                        for (int64_t j = 0; j < n; ++j)
+                            for (int k = 0; k < 3; ++k) {
+                                sens[(r * n + j) * 6 + k] = acc[3 * j + k];
+                                sens[(r * n + j) * 6 + 3 + k] = gyr[3 * j + k];
+                            }
+                    if (odo_out && ref_odo)
+                        for (int64_t j = 0; j < n; ++j) odo_out[r * n + j] = odo[j];
                 }
             }
         }

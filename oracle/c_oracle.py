@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'c', 'ginsim_oracle.c')
 LIB = os.path.join(HERE, '_build', 'libginsim_oracle.so')
 _PD = C.POINTER(C.c_double)
+_PF = C.POINTER(C.c_float)
 
 
 TABLES = os.path.join(os.path.dirname(HERE), 'gnss-ins-sim_amd', 'csrc')      # normal_tables.inc: committed constants of the stream
@@ -51,6 +52,11 @@ def lib():
                                                  _PD, _PD, _PD]
         _lib.oracle_normals.restype = None
         _lib.oracle_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, _PD, _PD]
+        _lib.oracle_mc_run_f32.restype = C.c_int
+        _lib.oracle_mc_run_f32.argtypes = [C.POINTER(McParams), _PD, _PD, _PD, _PD, _PD, C.c_int64, _PF, _PF, _PF]
+        _lib.oracle_free_integration_f32_given.restype = None
+        _lib.oracle_free_integration_f32_given.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int64, _PD, _PD, _PD, _PD, C.c_int,
+                                                           _PF, _PF, _PF, _PD]
         _lib.oracle_allan_var.restype = C.c_int
         _lib.oracle_allan_var.argtypes = [_PD, C.c_int64, C.c_double, _PD, _PD]
     return _lib
@@ -103,6 +109,60 @@ def mc_run(seed, run_offset, runs, fs, ref_frame, truth, accel_err, gyro_err, in
     if rc:
         raise MemoryError('oracle_mc_run')
     return out, traj, sens
+
+
+def _pf(a):
+    return None if a is None else a.ctypes.data_as(_PF)
+
+
+def mc_run_f32(seed, run_offset, runs, fs, ref_frame, truth, accel_err, gyro_err, ini, algo='free', odo_err=None,
+               earth_rot=True, ini_first=0, keep=0):
+    """The float restatement (oracle_mc_run_f32): what the fp32 kernel must reproduce to the bit.
+    Returns (end_err (runs,9) float64, traj (keep,n,9) float32 = att3, position DISPLACEMENT3, vel3, sens (keep,n,6) float32,
+    odo (keep,n) float32 or None)."""
+    ini = np.asarray(ini, dtype=np.float64)
+    if ini.ndim == 1:
+        ini = ini.reshape(-1, 1)
+    table = np.zeros((ini.shape[1], 10))
+    table[:, :min(10, ini.shape[0])] = ini[:10].T
+    n = truth['ref_accel'].shape[0]
+    p = McParams()
+    p.n, p.runs, p.run_offset, p.seed, p.fs = n, int(runs), int(run_offset), int(seed) & (2 ** 64 - 1), float(fs)
+    p.ref_frame, p.algo_odo, p.earth_rot = int(ref_frame), int(algo == 'odo'), int(bool(earth_rot))
+    p.n_ini, p.ini_first, p.ini_has_g = table.shape[0], int(ini_first), int(ini.shape[0] > 9)
+    p.accel, p.gyro = _model(accel_err, 'vrw', fs), _model(gyro_err, 'arw', fs)
+    if odo_err is not None:
+        p.odo_scale, p.odo_stdv = float(odo_err['scale']), float(odo_err['stdv'])
+    end = np.concatenate([truth['ref_att'][-1], truth['ref_pos'][-1], truth['ref_vel'][-1]])
+    p.ref_end[:] = [float(x) for x in end]
+    ra = np.ascontiguousarray(truth['ref_accel'], dtype=np.float64)
+    rg = np.ascontiguousarray(truth['ref_gyro'], dtype=np.float64)
+    ro = np.ascontiguousarray(truth['ref_odo'], dtype=np.float64) if (odo_err is not None and 'ref_odo' in truth) else None
+    out = np.empty((int(runs), 9))
+    traj = np.empty((keep, n, 9), dtype=np.float32) if keep else None
+    sens = np.empty((keep, n, 6), dtype=np.float32) if keep else None
+    odo = np.empty((keep, n), dtype=np.float32) if (keep and ro is not None) else None
+    rc = lib().oracle_mc_run_f32(C.byref(p), _p(table), _p(ra), _p(rg), _p(ro), _p(out), int(keep), _pf(traj), _pf(sens), _pf(odo))
+    if rc:
+        raise MemoryError('oracle_mc_run_f32')
+    return out, traj, sens, odo
+
+
+def free_integration_f32(ref_frame, fs, gyro, accel, ini, earth_rot=True, odo=None):
+    """Given-data mechanisation in float (fp64 series rounded to float as read).  Returns att (n,3), position displacement
+    (n,3), vel (n,3) as float32 and the fp64 end position (3,)."""
+    g = np.ascontiguousarray(gyro, dtype=np.float64)
+    a = None if accel is None else np.ascontiguousarray(accel, dtype=np.float64)
+    o = None if odo is None else np.ascontiguousarray(odo, dtype=np.float64)
+    ini = np.ascontiguousarray(np.asarray(ini, dtype=np.float64).reshape(-1))
+    ini10 = np.zeros(10)
+    ini10[:ini.size] = ini
+    n = g.shape[0]
+    att, dpos, vel = (np.empty((n, 3), dtype=np.float32) for _ in range(3))
+    end_pos = np.empty(3)
+    lib().oracle_free_integration_f32_given(int(ref_frame), float(fs), int(bool(earth_rot)), n, _p(g), _p(a), _p(o), _p(ini10),
+                                            int(ini.size > 9), _pf(att), _pf(dpos), _pf(vel), _p(end_pos))
+    return att, dpos, vel, end_pos
 
 
 def free_integration(ref_frame, fs, gyro, accel, ini, earth_rot=True, odo=None):

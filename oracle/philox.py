@@ -7,24 +7,27 @@ engine therefore defines its own stream -- Philox4x32-7 (Salmon et al., SC'11,
 "Parallel random numbers: as easy as 1, 2, 3": seven rounds is the Crush-resistant
 Philox4x32 of the paper, ten its conservative default; Random123 v1.14 constants and
 known-answer vectors for both round counts are checked in the tests) followed by
-a Box-Muller transform that is DEFINED operation by operation in IEEE single precision
-(every multiplication, addition and square root rounded separately, no fused multiply-adds,
-two committed lookup tables) -- so the device, this file and the C oracle produce the SAME BITS,
+a normal transform that is DEFINED operation by operation in IEEE single precision
+(integer bit manipulation, one row of a committed coefficient table, three fused multiply-adds)
+-- so the device, this file and the C oracle produce the SAME BITS,
 and parity is "identical injected normals": the unmodified reference is fed THESE normals
 through a ``np.random.randn`` shim (``oracle/ref_shim.py``).
 
 Stream definition (shared by this file, ``oracle/c/ginsim_oracle.c`` and
-``gnss-ins-sim_amd/csrc/philox.hpp`` / ``fastmath.hpp``).  A normal pair takes the two words of a half block, so one
-128-bit block gives TWO pairs and the six pairs of an IMU step are exactly three blocks:
+``gnss-ins-sim_amd/csrc/philox.hpp`` / ``fastmath.hpp``; the FOURTH one, round 3: one word per normal by inversion
+instead of the single-precision Box-Muller of round 2 -- 13 ns instead of 30 ns of SIMD time per normal).  A stream's
+pair of normals takes the two words of a half block, so one 128-bit block gives TWO pairs and the six pairs of an IMU
+step are exactly three blocks:
 
     key     = (seed & 0xffffffff, seed >> 32)
     W       = philox4x32_7((j, s >> 1, run & 0xffffffff, run >> 32), key)      j = sample index, s = stream id
     (a, b)  = (W0, W1) if s is even else (W2, W3)
-    u   = (f32(a) + 0.5) * 2**-32                                   radius uniform in (0, 1]: |z| up to 6.7 sigma
-    x   = -2 ln u        by exponent / 256-bin mantissa table / cubic   (radius2_f32 below)
-    r   = sqrt(x)        correctly rounded
-    s,c = sin, cos of 2 pi ((b & 0xffffff) + 1/2) 2**-24     by 512-sector table / two-term series (sincos_f32 below)
-    z0 = f64(r * c) ;  z1 = f64(r * s)
+    z0 = f64(normal_icdf(a)) ;  z1 = f64(normal_icdf(b))
+    normal_icdf(w):  m = (w & 0x7fffffff) | 1          upper tail probability t = m 2^-32 in (0, 1/2): |z| <= 6.23
+                     lz = clz32(m);  y = m << lz       octave of t, then its eighth: seg = (lz - 1) 8 + ((y >> 28) & 7)
+                     x = f32 bits 0x3f800000 | ((y << 4) >> 9)          in [1, 2)
+                     z = fma(fma(fma(c3, x, c2), x, c1), x, c0)         (c0..c3) = table[seg], csrc/normal_tables.inc
+                     |z| with the sign bit of w
 
 Stream ids (one stream -> two normals (z0, z1)):
 
@@ -78,68 +81,52 @@ def philox4x32(c0, c1, c2, c3, k0, k1, rounds=ROUNDS):
 
 
 F32 = np.float32
-SQRT_HALF_BITS = np.uint32(0x3f3504f3)          # bits of f32(sqrt(1/2))
-NEG_2LN2 = F32(-1.3862943611198906)
-ANG_SCALE = F32(2.0 * np.pi * 2.0 ** -24)
+N_OCT, N_SUB = 31, 8
 
 
 def normal_tables():
-    """The two fp32 tables of the generator -- the same construction as tools/gen_normal_tables.py, whose output
-    (csrc/normal_tables.inc) the device and the C oracle use; tests/test_oracle_golden.py compares the bits."""
-    k = np.arange(256, dtype=np.uint32)
-    lo = (SQRT_HALF_BITS + (k << np.uint32(15))).view(F32).astype(np.float64)
-    hi = (SQRT_HALF_BITS + (k << np.uint32(15)) + np.uint32(0x8000)).view(F32).astype(np.float64)
-    unit = (lo <= 1.0) & (1.0 < hi)
-    c = np.where(unit, 1.0, 0.5 * (lo + hi)).astype(F32)
-    c64 = c.astype(np.float64)
-    lg = np.zeros((256, 3), dtype=F32)
-    lg[:, 0] = c
-    lg[:, 1] = (-2.0 / c64).astype(F32)
-    lg[:, 2] = np.where(unit, 0.0, -2.0 * np.log(c64)).astype(F32)
-    ang = 2.0 * np.pi * (np.arange(512) + 0.5) / 512.0
-    return lg, np.stack([np.sin(ang), np.cos(ang)], axis=1).astype(F32)
+    """The coefficient table of the generator: the committed numbers (csrc/normal_tables.inc, made by
+    tools/gen_normal_tables.py), which the device and the C oracle use as they are.  (248, 4) float32."""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gnss-ins-sim_amd', 'csrc', 'normal_tables.inc')
+    words = [int(t, 16) for t in re.findall(r'0x([0-9a-fA-F]{8})u', open(path).read())]
+    return np.array(words, dtype=np.uint32).view(F32).reshape(N_OCT * N_SUB, 4)
 
 
-_LG, _SC = normal_tables()
+_Q = normal_tables()
 
 
-def radius2_f32(a):
-    """x = -2 ln u, u = (f32(a) + 1/2) 2^-32, in single precision: u = m 2^e with m in [sqrt(1/2), sqrt(2)),
-    x = e (-2 ln 2) + (-2 ln c_k) + (r + r^2 (1/4 + r/12)),  r = (m - c_k)(-2 / c_k).  Every operation is one IEEE op."""
-    t = np.asarray(a, dtype=np.uint64).astype(F32)                  # uint32 -> f32, round to nearest even
-    u = (t + F32(0.5)) * F32(2.0 ** -32)
-    hx = u.view(np.uint32) + (np.uint32(0x3f800000) - SQRT_HALF_BITS)
-    ef = ((hx >> np.uint32(23)).astype(np.int32) - 127).astype(F32)
-    tab = _LG[(hx >> np.uint32(15)) & np.uint32(255)]
-    m = ((hx & np.uint32(0x007fffff)) + SQRT_HALF_BITS).view(F32)
-    d = m - tab[..., 0]
-    r = d * tab[..., 1]
-    q = r * F32(1.0 / 12.0)
-    q = q + F32(0.25)
-    q = q * (r * r)
-    small = r + q
-    x = ef * NEG_2LN2
-    x = x + tab[..., 2]
-    return x + small
+def normal_icdf(w):
+    """One standard normal from one 32-bit word by inversion of the upper tail probability t = m 2^-32, m = (w & 0x7fffffff) | 1:
+    octave lz = clz(m), eighth of the octave = the 3 bits below the leading one, x in [1, 2) = the next 23 bits,
+    z = c0 + x (c1 + x (c2 + x c3)) evaluated as three fused multiply-adds in single precision, sign = bit 31 of w.
+    The fused multiply-add is emulated exactly (_fma32)."""
+    w = np.asarray(w, dtype=np.uint64).astype(np.uint32)
+    m = (w & np.uint32(0x7fffffff)) | np.uint32(1)
+    nbits = np.floor(np.log2(m.astype(np.float64))).astype(np.int64) + 1            # bit length of m: 1 .. 31 (exact: m < 2^53)
+    lz = 32 - nbits
+    y = ((m.astype(np.uint64) << lz.astype(np.uint64)) & np.uint64(0xffffffff)).astype(np.uint32)
+    c = _Q[(lz - 1) * N_SUB + ((y >> np.uint32(28)) & np.uint32(7)).astype(np.int64)]
+    x = (np.uint32(0x3f800000) | ((y << np.uint32(4)) >> np.uint32(9))).view(F32)
+    x64 = x.astype(np.float64)
+    z = c[..., 3]
+    for k in (2, 1, 0):
+        z = _fma32(z, x64, c[..., k])
+    zb = (z.view(np.uint32) & np.uint32(0x7fffffff)) | (w & np.uint32(0x80000000))
+    return zb.view(F32)
 
 
-def sincos_f32(b):
-    """sin, cos of 2 pi ((b & 0xffffff) + 1/2) 2^-24: sector = top 9 of the 24 bits, remainder centred, in radians."""
-    w = np.asarray(b, dtype=np.uint64).astype(np.uint32)
-    tab = _SC[(w >> np.uint32(15)) & np.uint32(511)]
-    sn_i, cs_i = tab[..., 0], tab[..., 1]
-    bb = (w & np.uint32(0x7fff)).astype(F32) + F32(0.5 - 16384.0)
-    bb = bb * ANG_SCALE
-    tt = bb * bb
-    u1 = tt * F32(-1.0 / 6.0)
-    u1 = u1 * bb
-    sb = bb + u1                                                     # sin b
-    cm = tt * F32(-0.5)                                              # cos b - 1
-    p1 = cs_i * sb
-    p1 = p1 + sn_i * cm
-    q1 = cs_i * cm
-    q1 = q1 - sn_i * sb
-    return sn_i + p1, cs_i + q1
+LD = np.longdouble
+assert np.finfo(LD).nmant >= 63, 'the fused multiply-add emulation needs an extended-precision long double (x86-64)'
+
+
+def _fma32(a32, x64, c32):
+    """float32(a * x + c) with ONE rounding: the product of two floats is exact in float64 (48 bits); its sum with a float of
+    comparable size (the Horner terms here differ by < 2^16) is exact in the 64-bit significand of the x87 long double; the
+    conversion to float32 then rounds once."""
+    p = (a32.astype(np.float64) * x64).astype(LD)
+    return (p + c32.astype(LD)).astype(F32)
 
 
 def stream_words(seed, run, stream, j):
@@ -152,18 +139,15 @@ def stream_words(seed, run, stream, j):
     return (w[2], w[3]) if int(stream) & 1 else (w[0], w[1])
 
 
-def box_muller(a, b):
-    """(z0, z1) from the two words of a half block; the values are exact single-precision numbers held in float64."""
-    with np.errstate(all='ignore'):
-        r = np.sqrt(radius2_f32(a))                                   # float32 sqrt: correctly rounded
-        sn, cs = sincos_f32(b)
-        assert r.dtype == F32 and sn.dtype == F32
-        return (r * cs).astype(np.float64), (r * sn).astype(np.float64)
+def normal_transform(a, b):
+    """(z0, z1) from the two words of a half block: z0 = normal_icdf(a), z1 = normal_icdf(b); the values are exact
+    single-precision numbers held in float64."""
+    return normal_icdf(a).astype(np.float64), normal_icdf(b).astype(np.float64)
 
 
 def normal_pair(seed, run, stream, j):
     """Two standard normals (z0, z1) for (run, stream, sample j); arrays broadcast."""
-    return box_muller(*stream_words(seed, run, stream, j))
+    return normal_transform(*stream_words(seed, run, stream, j))
 
 
 def imu_normals(seed, run, n):

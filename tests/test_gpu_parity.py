@@ -43,49 +43,63 @@ def test_rng_words_bit_exact_and_normals(ctx):
         assert np.array_equal(z1.view(np.uint64), r1.view(np.uint64))
 
 
-def test_box_muller_corner_cases(ctx):
-    """Words no seed will produce in a test: the largest and the smallest radius uniform, mantissas on the edges of the
-    log table's bins (around 1 and around sqrt(1/2) / sqrt(2)), exponent changes, angles on sector edges of the sin/cos
-    table, plus two million random words -- the device's normals must be the oracle's, bit for bit (both are defined as the
-    same sequence of IEEE single-precision operations), and close to the textbook transform in double precision.
-    A row is (a, b, -, -): the two words of a half block (radius uniform from a, angle = low 24 bits of b)."""
+def test_normal_transform_corner_cases(ctx):
+    """Words no seed will produce in a test: the smallest and the largest magnitude, both edges of every one of the 248
+    segments of the coefficient table (and the words next to them), octave changes, both signs, plus two million random
+    words -- the device's normals must be the oracle's, bit for bit (both are defined as the same sequence of integer and
+    IEEE single-precision operations), and within 6e-7 of scipy's inverse normal CDF in double precision.
+    A row is (a, b, -, -): the two words of a half block (z0 from a, z1 from b)."""
     import ginsim
     from oracle import philox
+    from scipy.special import ndtri
     rng = np.random.default_rng(7)
     rows = []
     full, zero = 0xFFFFFFFF, 0
-    rows += [(full, full, zero, zero), (zero, zero, full, full), (zero, 0x00FFFFFF, zero, zero), (full, 0xFF000000, full, full)]
-    # radius uniforms around u = 1/2, 1/4 (exponent change), around m = sqrt(2), just below 1, and the smallest ones
-    for a in (0x7FFFFFFF, 0x80000000, 0x3FFFFFFF, 0x40000000, 0xB504F333, 0xB504F334, 0x5A827999, 0x5A82799A,
-              0xFFFFFF00, 0xFFFFFE80, 0xFFFFFF7F, 0xFFFFFF80, 1, 2, 3, 0xFF, 0x100, 0xFFFFFF, 0x1000000, 0x1000001):
-        for b in (zero, full, 0x12345678, 0xFF000000, 0x00FFFFFF):
-            rows.append((a, b, 0x9E3779B9, 0x3C6EF372))
-    for k in range(0, 2048, 7):                       # mantissa bins: top 11 bits of a sweep, the rest at both ends
-        rows.append(((k << 21) | 0x100000, zero, 1, 2))
-        rows.append(((k << 21) | 0x0FFFFF, full, 3, 4))
-    for k in range(256):                              # both edges of every bin of the log table, for u in [1/2, 1)
-        for e in (0x3f3504f3 + (k << 15), 0x3f3504f3 + (k << 15) - 1):
-            u = np.array([e], dtype=np.uint32).view(np.float32)[0]
-            a = int(np.clip(np.float64(u) * 2.0 ** 32 - 0.5, 0, full))
-            rows += [(a, 0x555555, 0, 0), (max(a - 1, 0), 0xAAAAAA, 0, 0), (min(a + 1, full), 0x333333, 0, 0)]
-    for i in range(512):                              # sector edges of the 24-bit angle: i 2^15 - 1 and i 2^15
-        rows.append((0xDEADBEEF, 0x67000000 | (i << 15), zero, zero))
-        rows.append((0xDEADBEEF, 0x67000000 | (((i << 15) - 1) & 0xFFFFFF), full, full))
+    rows += [(full, full, zero, zero), (zero, zero, full, full), (zero, 0x7FFFFFFF, zero, zero), (full, 0x80000000, full, full),
+             (1, 2, 0, 0), (3, 0x80000001, 0, 0), (0x40000000, 0x3FFFFFFF, 0, 0), (0xC0000000, 0xBFFFFFFF, 0, 0)]
+    for lz in range(1, 32):
+        for sub in range(8):
+            for frac in (0, 1, 2 ** 28 - 1, 2 ** 28 - 2, 0x5555555, 0xAAAAAAA):
+                y = (1 << 31) | (sub << 28) | frac
+                m = y >> lz
+                for sign in (0, 0x80000000):
+                    rows.append((m | sign, (m ^ 1) | sign, 0x9E3779B9, 0x3C6EF372))
     w = np.array(rows, dtype=np.uint64)
     w = np.vstack([w, rng.integers(0, 2 ** 32, size=(2000000, 4), dtype=np.uint64)])
-    z0, z1 = ginsim.box_muller(ctx, w.astype(np.uint32))
-    r0, r1 = philox.box_muller(w[:, 0], w[:, 1])
+    z0, z1 = ginsim.normal_transform(ctx, w.astype(np.uint32))
+    r0, r1 = philox.normal_transform(w[:, 0], w[:, 1])
     assert np.isfinite(z0).all() and np.isfinite(z1).all()
     bad = np.flatnonzero((z0.view(np.uint64) != r0.view(np.uint64)) | (z1.view(np.uint64) != r1.view(np.uint64)))
     assert bad.size == 0, (bad[:5], w[bad[:5]], z0[bad[:5]], r0[bad[:5]])
-    # and the textbook transform on the same uniforms
-    u1 = (w[:, 0].astype(np.float64) + 0.5) * 2.0 ** -32
-    u2 = ((w[:, 1] & np.uint64(0xFFFFFF)).astype(np.float64) + 0.5) * 2.0 ** -24
-    r = np.sqrt(-2.0 * np.log(u1))
-    a = (2.0 * np.pi) * u2
-    np.testing.assert_array_less(np.abs(z0 - r * np.cos(a)), 1e-6 + 1e-6 * r + 2e-7 / np.maximum(r, 1e-4))
-    np.testing.assert_array_less(np.abs(z1 - r * np.sin(a)), 1e-6 + 1e-6 * r + 2e-7 / np.maximum(r, 1e-4))
-    assert np.abs(z0).max() < 6.8 and np.abs(z0).max() > 6.5
+    # and scipy's inverse CDF on the same tail probabilities
+    for col, z in ((0, z0), (1, z1)):
+        m = (w[:, col] & np.uint64(0x7fffffff)) | np.uint64(1)
+        want = -ndtri(m.astype(np.float64) * 2.0 ** -32) * np.where(w[:, col] >> np.uint64(31), -1.0, 1.0)
+        assert np.abs(z - want).max() < 6e-7
+    assert np.abs(z0).max() == np.float32(6.2302604)
+
+
+def test_device_normals_distribution(ctx):
+    """1e8 normals generated ON THE DEVICE: moments within 5 sigma of their sampling error, tail counts beyond
+    4 and 5 sigma against erfc, nothing beyond the 6.23-sigma bound."""
+    import ginsim
+    from scipy.special import erfc
+    n_tot, s1, s2, s3, s4, t4, t5, zmax = 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0.0
+    for chunk in range(10):
+        z0, z1 = ginsim.rng_normals(ctx, 424242, chunk, chunk % 6, 5000000)
+        for z in (z0, z1):
+            n_tot += z.size
+            s1 += z.sum(); s2 += (z ** 2).sum(); s3 += (z ** 3).sum(); s4 += (z ** 4).sum()
+            t4 += int((np.abs(z) > 4.0).sum()); t5 += int((np.abs(z) > 5.0).sum())
+            zmax = max(zmax, float(np.abs(z).max()))
+    N = float(n_tot)
+    assert n_tot == 100000000
+    assert abs(s1 / N) < 5 / np.sqrt(N) and abs(s2 / N - 1.0) < 5 * np.sqrt(2.0 / N)
+    assert abs(s3 / N) < 5 * np.sqrt(15.0 / N) and abs(s4 / N - 3.0) < 5 * np.sqrt(96.0 / N)
+    for k, got in ((4.0, t4), (5.0, t5)):
+        expect = N * erfc(k / np.sqrt(2.0))
+        assert abs(got - expect) < 5 * np.sqrt(expect), (k, got, expect)
+    assert zmax <= 6.2302604
 
 
 @pytest.mark.parametrize('name', ['bosch', 'nxp', 'tumble'])

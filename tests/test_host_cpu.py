@@ -228,7 +228,7 @@ def test_hot_kernels_keep_two_wavefronts_per_simd():
         checked += 1
         two_algos = 'ILi0ELi3E' in name or 'ILi1ELi3E' in name
         assert occ >= 2, '%s: %d wavefront(s) per SIMD' % (name, occ)
-        if '15mc_kernel_splitI' in name and name.split('EEEv')[0].endswith('ELi2'):     # 768 threads: three per SIMD
+        if ('15mc_kernel_splitI' in name or '19mc_kernel_f32_splitI' in name) and name.split('EEEv')[0].endswith('ELi2'):     # 768 threads: three per SIMD
             assert occ >= 3, '%s: %d wavefront(s) per SIMD' % (name, occ)
         assert agpr == 0, '%s parks %d registers in AGPRs' % (name, agpr)
         assert scratch <= (128 if two_algos else 32), '%s: %d bytes of scratch per lane' % (name, scratch)

@@ -91,3 +91,103 @@ def test_c_t1_both_plugins_at_other_rates():
                                                   earth_rot=erot, odo=c['odo'] if plug == 'odo' else None)
         assert_traj_close(att[k], pos[k], vel[k], c['%s_%s_att' % (plug, tag)], c['%s_%s_pos' % (plug, tag)],
                           c['%s_%s_vel' % (plug, tag)], rtol=1e-11, what='%s %s %g Hz' % (plug, tag, float(c['fs'])))
+
+
+# ------------------------------------------------------------------ the FLOAT restatement (fp32 kernel path, BASELINE config 5)
+# Stated fp32 tolerances against the reference's fp64 outputs (10 s / 1000 steps unless noted): attitude 2e-6 rad (the float
+# ulp of a 5.5 rad yaw is 4.8e-7), velocity 5e-5 m/s, position 1e-4 m (ref_frame 1: ECEF via the fp64 displacement;
+# ref_frame 0: lat / lon 1e-11 rad, altitude 1e-4 m); sensors: accel 2e-6 m/s^2 (float ulp at 9.8 is 9.5e-7), gyro 1e-7 rad/s.
+F32_TOL = {'att': 2e-6, 'vel': 5e-5, 'pos_m': 1e-4, 'pos_rad': 1e-11, 'accel': 2e-6, 'gyro': 1e-7}
+
+
+def assert_f32_close(att, dpos, vel, ini, rf, g_att, g_pos, g_vel, what='', scale=1.0, att_tol=None):
+    from gnss_ins_sim.geoparams import geoparams
+    pos0 = geoparams.lla2ecef(np.asarray(ini[:3], dtype=np.float64)) if rf == 1 else np.asarray(ini[:3], dtype=np.float64)
+    pos = dpos.astype(np.float64) + pos0
+    assert ang_close(att, g_att, att_tol or F32_TOL['att']), what + ' att'
+    assert np.abs(vel - g_vel).max() <= F32_TOL['vel'] * scale, what + ' vel %.2e' % np.abs(vel - g_vel).max()
+    dp = np.abs(pos - g_pos)
+    if rf == 1:
+        assert dp.max() <= F32_TOL['pos_m'] * scale, what + ' pos %.2e' % dp.max()
+    else:
+        assert dp[..., :2].max() <= F32_TOL['pos_rad'] * scale and dp[..., 2].max() <= F32_TOL['pos_m'] * scale, what + ' pos'
+
+
+@pytest.mark.parametrize('name', ['bosch', 'nxp', 'tumble'])
+def test_c_f32_t1_fixture(name):
+    """oracle_free_integration_f32 on the reference's logged-IMU fixtures (and the tumble that drives the pitch over the pole
+    twice: cos(pitch) down to 6e-3 amplifies float rounding, stated attitude tolerance 1e-4 rad there)."""
+    g = load_golden('t1_fixture_' + name)
+    k = g['rows']
+    for tag, rf, ini, erot in (('extg', 0, g['ini'], False), ('wgs', 0, g['ini'][:9], True), ('rf1', 1, g['ini'][:9], True)):
+        att, dpos, vel, _ = c_oracle.free_integration_f32(rf, float(g['fs']), g['gyro'], g['accel'], ini, earth_rot=erot)
+        assert_f32_close(att[k], dpos[k], vel[k], ini, rf, g['att_' + tag], g['pos_' + tag], g['vel_' + tag], what=name + tag,
+                         att_tol=1e-4 if name == 'tumble' else None)
+
+
+@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'])
+def test_c_f32_t3_injected_noise(name):
+    """The float restatement consumes the SAME normals as the fp64 path: against the reference executed with those normals
+    injected, every sensor sample and every trajectory sample of every run agrees within the stated fp32 tolerances
+    (t3_drive200: 4400 steps / 22 s, position and velocity tolerances x 5)."""
+    g = load_golden(name)
+    R, k, fs, rf = int(g['R']), g['rows'], float(g['fs']), int(g['ref_frame'])
+    acc_err, gyr_err = _errs(g)
+    truth = {'ref_accel': g['ref_accel'], 'ref_gyro': g['ref_gyro'], 'ref_att': g['ref_att'], 'ref_pos': g['ref_pos'],
+             'ref_vel': g['ref_vel']}
+    odo_err = None
+    if 'odo' in g:
+        truth['ref_odo'] = g['ref_odo']
+        odo_err = {'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])}
+    scale = 5.0 if g['ref_accel'].shape[0] > 1000 else 1.0
+    for a, tag in (('free', 'fi'), ('odo', 'odo')):
+        if tag + '_att' not in g:
+            continue
+        end, traj, sens, odo = c_oracle.mc_run_f32(int(g['seed']), 0, R, fs, rf, truth, acc_err, gyr_err, g['ini'], algo=a,
+                                                   odo_err=odo_err, keep=R)
+        np.testing.assert_allclose(sens[:, k, 0:3], g['accel'], rtol=0, atol=F32_TOL['accel'])
+        np.testing.assert_allclose(sens[:, k, 3:6], g['gyro'], rtol=0, atol=F32_TOL['gyro'])
+        if odo is not None:
+            np.testing.assert_allclose(odo[:, k], g['odo'], rtol=0, atol=2e-6)
+        assert_f32_close(traj[:, k, 0:3], traj[:, k, 3:6], traj[:, k, 6:9], g['ini'], rf, g[tag + '_att'], g[tag + '_pos'],
+                         g[tag + '_vel'], what=name + a, scale=scale)
+        # and the end-point error record against the fp64 restatement of the same runs
+        end64, _, _ = c_oracle.mc_run(int(g['seed']), 0, R, fs, rf, truth, acc_err, gyr_err, g['ini'], algo=a, odo_err=odo_err)
+        assert ang_close(end[:, :3], end64[:, :3], F32_TOL['att'])
+        np.testing.assert_allclose(end[:, 6:9], end64[:, 6:9], rtol=0, atol=F32_TOL['vel'] * scale)
+
+
+def test_c_f32_noise_free_closed_loop():
+    """T2 in float: truth through the float sensor model with zero noise -> mechanisation -> the reference's closed-loop rows."""
+    import ginsim
+    from ginsim import workloads
+    zero = {'b': np.zeros(3), 'b_drift': np.zeros(3), 'b_corr': np.full(3, 100.0), 'arw': np.zeros(3), 'vrw': np.zeros(3)}
+    for rf in (0, 1):
+        g = load_golden('t2_turn_rf%d' % rf)
+        ini, truth, _ = workloads.truth_from_profile('turn_90deg', 100.0, rf)
+        k = g['rows']
+        for a, tag in (('free', 'fi'), ('odo', 'odo')):
+            _, traj, sens, _ = c_oracle.mc_run_f32(1, 0, 1, 100.0, rf, truth, zero, zero, ini, algo=a, odo_err={'scale': 1.0, 'stdv': 0.0},
+                                                   keep=1)
+            assert_f32_close(traj[0, k, 0:3], traj[0, k, 3:6], traj[0, k, 6:9], ini, rf, g[tag + '_att'], g[tag + '_pos'],
+                             g[tag + '_vel'], what='t2 rf%d %s' % (rf, a))
+            assert np.array_equal(sens[0, :, 3:6], truth['ref_gyro'].astype(np.float32))
+
+
+def test_c_f32_sincos_def_is_float_accurate():
+    """The defined sin / cos (fp64 reduction + Taylor, rounded to float once) is the correctly rounded float of the true value
+    on the angles the mechanisation uses (|x| <= 2 pi), except where fp64 libm itself would round the other way (none here)."""
+    import ctypes as C
+    lib = c_oracle.lib()
+    rng = np.random.RandomState(4)
+    x = np.concatenate([rng.uniform(-2 * np.pi, 2 * np.pi, 200000), np.array([0.0, np.pi / 2, -np.pi / 2, np.pi, -np.pi, 5.497787143782138])])
+    att, dpos, vel = (np.empty((2, 3), dtype=np.float32) for _ in range(3))
+    bad = 0
+    for chunk in np.array_split(x, 50):
+        for v in chunk[:200]:            # through the public entry: attitude (v, 0, 0) -> att cached trig drives vel = C^T [1, 0, 0]
+            ini = np.array([0.5, 1.0, 0.0, 1.0, 0.0, 0.0, v, 0.0, 0.0])
+            a, _, vv, _ = c_oracle.free_integration_f32(1, 100.0, np.zeros((2, 3)), np.zeros((2, 3)), ini)
+            vf = np.float64(np.float32(v))
+            want = np.array([np.float32(np.cos(vf)), np.float32(np.sin(vf))])
+            bad += int(abs(float(vv[0, 0]) - float(want[0])) > 6e-8) + int(abs(float(vv[0, 1]) - float(want[1])) > 6e-8)
+    assert bad == 0

@@ -24,27 +24,35 @@ def test_philox_known_answers():
             assert tuple(int(x) for x in got) == want
 
 
-def test_normal_tables_are_the_committed_ones():
-    """The two fp32 tables are part of the definition of the stream: the NumPy oracle's own construction must give the
-    bits of csrc/normal_tables.inc (what the device and the C oracle read), and the constants of the transform must be the
-    single-precision numbers the device code spells."""
+def test_normal_table_is_committed_and_accurate():
+    """The coefficient table is part of the definition of the stream: the oracle reads the committed file the device and the
+    C oracle compile in.  Its cubics must invert the normal tail probability: |z - Phi^-1(1 - t)| <= 6e-7 on every segment
+    (tools/gen_normal_tables.py), i.e. one float ulp at |z| ~ 6."""
     import os
     import re
+    from scipy.special import ndtri
     from conftest import PKG
     txt = open(os.path.join(PKG, 'csrc', 'normal_tables.inc')).read()
     w = np.array([int(x, 16) for x in re.findall(r'0x([0-9a-f]{8})u', txt)], dtype=np.uint32)
-    lg, sc = philox.normal_tables()
-    assert w.size == 256 * 4 + 512 * 2
-    assert np.array_equal(w[:1024].reshape(256, 4)[:, :3], lg.view(np.uint32)) and not w[:1024].reshape(256, 4)[:, 3].any()
-    assert np.array_equal(w[1024:].reshape(512, 2), sc.view(np.uint32))
-    assert (lg[:, 0] == 1.0).sum() == 1 and lg[lg[:, 0] == 1.0, 2] == 0.0            # the bin that contains 1
-    assert philox.ANG_SCALE == np.float32(3.7450703562e-07) and philox.NEG_2LN2 == np.float32(-1.3862943611198906)
-    # known answers of the transform itself (words -> normals), exact single-precision numbers
-    z0, z1 = philox.box_muller(np.array([0, 1, 2 ** 32 - 1, 2 ** 31], dtype=np.uint64),
-                               np.array([0, 0xffffff, 0x800000, 12345], dtype=np.uint64))
-    assert np.array_equal(z0.astype(np.float32).astype(np.float64), z0)
-    np.testing.assert_allclose(z0, [6.76370573, 6.5992794, -0.0, 1.17739749], rtol=2e-8)
-    np.testing.assert_allclose(z1, [1.26613759e-06, -1.23535767e-06, -0.0, 5.44370804e-03], rtol=2e-8)
+    assert w.size == 31 * 8 * 4
+    assert np.array_equal(w.view(np.float32).reshape(248, 4), philox.normal_tables())
+    # every segment: both edges, the words next to them and a sweep inside (magnitudes m = ((8 + sub) << 27 | frac) >> lz)
+    rng = np.random.RandomState(3)
+    worst = 0.0
+    for lz in range(1, 32):
+        for sub in range(8):
+            frac = np.concatenate([[0, 1, 2 ** 28 - 1, 2 ** 28 - 2], rng.randint(0, 2 ** 28, 400)]).astype(np.uint64)
+            y = (np.uint64(1) << np.uint64(31)) | (np.uint64(sub) << np.uint64(28)) | frac
+            m = (y >> np.uint64(lz)) | np.uint64(1)
+            z = philox.normal_icdf(m).astype(np.float64)
+            worst = max(worst, np.abs(z + ndtri(m.astype(np.float64) * 2.0 ** -32)).max())
+    assert worst < 6e-7, worst
+    # known answers of the transform itself (word -> normal), exact single-precision numbers; sign = bit 31
+    z = philox.normal_icdf(np.array([0, 1, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1, 0x40000000, 0x3fffffff, 12345], dtype=np.uint64))
+    assert z.dtype == np.float32
+    np.testing.assert_allclose(z[[0, 1, 3]], [6.2302604, 6.2302604, -6.2302604], rtol=1e-7)      # m = 1: t = 2^-32
+    np.testing.assert_allclose(z[[5, 6]], [0.67448956, 0.6744898], rtol=2e-7)                      # t = 1/4: the quartile
+    assert 0 < z[2] < 1e-7 and -1e-7 < z[4] < 0
 
 
 def test_normals_moments():
@@ -80,18 +88,50 @@ def test_stream_cut_statistics():
         assert abs(np.corrcoef(z[a][:-1], z[a][1:])[0, 1]) < lim            # consecutive samples
     other = philox.normal_pair(12345, 78, 5, j)[0]                             # the neighbouring run
     assert abs(np.corrcoef(z[4], other)[0, 1]) < lim
-    # radius and angle uniforms of one stream come from the two words of a half block: independent
+    # the two words of a half block are independent uniforms
     w = philox.stream_words(12345, 77, 4, j)
     u1 = (w[0].astype(np.float64) + 0.5) * 2.0 ** -32
-    u2 = ((w[1] & np.uint64(0xFFFFFF)).astype(np.float64) + 0.5) * 2.0 ** -24
+    u2 = (w[1].astype(np.float64) + 0.5) * 2.0 ** -32
     assert abs(np.corrcoef(u1, u2)[0, 1]) < lim
     assert stats.kstest(u1, 'uniform').pvalue > 1e-3 and stats.kstest(u2, 'uniform').pvalue > 1e-3
-    # the single-precision transform against the textbook one in double precision on the same uniforms: the radius
-    # uniform has a 24-bit mantissa, so the squared radius is off by up to ~1e-7 absolute (visible only where it is tiny)
-    x = philox.radius2_f32(w[0]).astype(np.float64)
-    assert np.abs(x - (-2.0 * np.log(u1))).max() < 4e-6 and (x >= 0).all()
-    sn, cs = philox.sincos_f32(w[1])
-    assert np.abs(sn - np.sin(2 * np.pi * u2)).max() < 1.5e-7 and np.abs(cs - np.cos(2 * np.pi * u2)).max() < 1.5e-7
+    # the single-precision inversion against scipy's inverse CDF in double precision on the same words
+    from scipy.special import ndtri
+    m = (w[0] & np.uint64(0x7fffffff)) | np.uint64(1)
+    want = -ndtri(m.astype(np.float64) * 2.0 ** -32) * np.where(w[0] >> np.uint64(31), -1.0, 1.0)
+    assert np.abs(philox.normal_icdf(w[0]).astype(np.float64) - want).max() < 6e-7
+
+
+def test_normal_distribution_of_the_generator():
+    """Distribution of the generator itself: 2e7 draws of four streams -- mean, variance, skewness, kurtosis
+    within 4.5 sigma of their sampling error, tail counts beyond 3 / 4 / 5 sigma against erfc (Poisson limits), no draw beyond
+    the 6.23-sigma bound of a 31-bit magnitude, and no correlation between streams, between the words of a block, or along
+    the sample index (lags 1, 2, 3 and 12 = one IMU step apart in the consumption order)."""
+    from scipy import stats
+    from scipy.special import erfc
+    n = 5000000
+    j = np.arange(n, dtype=np.uint64)
+    zs = []
+    for stream in (0, 1, 4, 5):
+        a, b = philox.normal_pair(20260924, 5, stream, j)
+        zs += [a, b]
+    z = np.concatenate(zs)
+    N = z.size
+    assert abs(z.mean()) < 4.5 / np.sqrt(N)
+    assert abs(z.var() - 1.0) < 4.5 * np.sqrt(2.0 / N)
+    assert abs(stats.skew(z)) < 4.5 * np.sqrt(6.0 / N)
+    assert abs(stats.kurtosis(z)) < 4.5 * np.sqrt(24.0 / N)
+    assert np.abs(z).max() <= 6.2302604
+    for k in (3.0, 4.0, 5.0):
+        expect = N * erfc(k / np.sqrt(2.0))
+        got = int((np.abs(z) > k).sum())
+        assert abs(got - expect) < 4.5 * np.sqrt(expect) + 1, (k, got, expect)
+    lim = 4.5 / np.sqrt(n)
+    zz = np.array(zs)
+    c = np.corrcoef(zz)
+    assert np.abs(c - np.eye(8)).max() < lim
+    for lag in (1, 2, 3, 12):
+        assert abs(np.mean(zz[0][:-lag] * zz[0][lag:])) < lim
+    assert stats.kstest(z[::40], 'norm').pvalue > 1e-3
 
 
 @pytest.mark.parametrize('name', ['bosch', 'nxp', 'tumble'])
