@@ -20,6 +20,12 @@ Workload (config.workload names it):
           all-reduce of the statistics records per step (backend nccl).  Weak scaling: every rank integrates its own
           runs (global run ids are disjoint, the Philox counter carries the global id).
 
+`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset) re-executes itself under torch.distributed.run with
+N ranks on 127.0.0.1, so the driver's command line works for every N.  Before the counted --warmup steps the headline
+kernel is pre-warmed by TIME (launches of this kernel get faster for the first 20-30 ms of back-to-back execution:
+clock / power management settling), reported as `prewarm_ms`.  At N > 1 rank 0 first measures `per_gpu_single`: the SAME
+per-GPU load (131 072 runs) on one GPU with the other ranks idle, so that scaling efficiency compares like with like.
+
 The JSON line (rank 0) also carries, measured in the same process after the timed region (N = 1 only):
   roofline             dominant kernel: algorithmic bytes / HIP-event launch time, vs 8 TB/s; `traffic` = HBM bytes per
                        launch from rocprofv3 PMC passes (WRITE_SIZE, FETCH_SIZE x 2 on gfx950) run live on this build,
@@ -146,9 +152,18 @@ def reference_python_baseline(budget_s):
                               '%.1f s, single-threaded by construction' % (r, float(dt))}
         except Exception as e:                                     # noqa: BLE001 -- a baseline must not fail the bench
             return {'value': None, 'kind': 'reference', 'error': repr(e)[:200]}
-    return {'value': 4.76e4, 'unit': 'sample*MC/s', 'cores': 1, 'kind': 'quoted',
-            'sample': 'BASELINE.md section 2: unmodified reference Sim.run(1000) on config 1 in the survey container (Xeon 2.1 GHz, '
-                      '1 core; the reference is single-threaded); /root/reference does not exist on this host, so it is not timed here'}
+    # not importable here (the GPU box): the committed, host-stamped timing of the unmodified reference made by
+    # tools/time_reference.py in the build container (profiles/reference_cpu.json), else the BASELINE.md figure
+    try:
+        with open(os.path.join(REPO, 'profiles', 'reference_cpu.json')) as f:
+            rec = json.load(f)
+        return {'value': rec['value'], 'unit': 'sample*MC/s', 'cores': 1, 'kind': 'quoted',
+                'sample': 'profiles/reference_cpu.json: %s (host %s, %s); /root/reference does not exist on this host, so it is '
+                          'not timed here' % (rec['sample'], rec.get('host', '?'), rec.get('date', '?'))}
+    except (OSError, ValueError, KeyError):
+        return {'value': 4.76e4, 'unit': 'sample*MC/s', 'cores': 1, 'kind': 'quoted',
+                'sample': 'BASELINE.md section 2: unmodified reference Sim.run(1000) on config 1 in the survey container (Xeon 2.1 GHz, '
+                          '1 core; the reference is single-threaded); /root/reference does not exist on this host, so it is not timed here'}
 
 
 # --------------------------------------------------------------------------------------------- PMC traffic
@@ -291,6 +306,53 @@ def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0):
     return out
 
 
+def leg_sim_e2e(workloads):
+    """End-to-end wall of the drop-in Sim ("also report end-to-end Sim.run wall"): constructor + run() + results()
+    as demo_free_integration.py calls them, host work included (motion parsing, native pathgen, uploads, the launch, the
+    device reductions, the summary text) -- C2 with everything kept on the device, and C3 (statistics only, pathgen of
+    193 036 samples on the host inside the wall)."""
+    import contextlib
+    import io
+    import numpy as np
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration
+    out = {'name': 'sim_e2e', 'dtype': 'f64', 'workload': 'Sim(...).run(R); Sim.results() through the drop-in package, wall clock'}
+    for tag, profile, fs, fs_gps, rf, R, axis, gps in (('C2', 'turn_90deg', 100.0, 0.0, 1, 65536, 6, False),
+                                                      ('C3', 'long_drive', 200.0, 10.0, 0, 262144, 6, True)):
+        csv = workloads.profile_path(profile)
+        ini = np.genfromtxt(csv, delimiter=',', skip_header=1, max_rows=1)
+        ini[0:2] *= np.pi / 180
+        ini[6:9] *= np.pi / 180
+        best = None
+        for rep in range(2):                         # second pass: scratch allocations and the library are warm
+            imu = imu_model.IMU(accuracy='mid-accuracy', axis=axis, gps=gps)
+            t0 = time.perf_counter()
+            sim = ins_sim.Sim([fs, fs_gps, 0.0], csv, ref_frame=rf, imu=imu, mode=None, env=None,
+                              algorithm=free_integration.FreeIntegration(ini), seed=SEED)
+            sim.run(R)
+            t1 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                sim.results(err_stats_start=-1 if tag == 'C2' else 0)
+            t2 = time.perf_counter()
+            n = int(sim.dmgr.time.data.shape[0])
+            rec = {'runs': R, 'samples_per_run': n, 'run_wall_s': t1 - t0, 'results_wall_s': t2 - t1,
+                   'sample_MC_per_s_end_to_end': R * n / (t2 - t0),
+                   'statistics': 'end point' if tag == 'C2' else 'process error of every run from t = 0 (the reference default), accumulated online'}
+            best = rec if best is None or rec['sample_MC_per_s_end_to_end'] > best['sample_MC_per_s_end_to_end'] else best
+            del sim
+        out[tag] = best
+    return out
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 # --------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -321,10 +383,13 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # started without a launcher: become `torch.distributed.run --nproc-per-node N bench.py <same arguments>` (one rank per GPU)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
+               '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
-                     % (args.gpus, args.gpus))
         args.gpus = world
 
     import numpy as np
@@ -404,6 +469,35 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
 
+    # pre-warm by TIME: WARM_MS of this kernel's own launches, outside the counted --warmup steps (whatever the driver passes
+    # for --warmup, the timed steps then run in the steady state the profiles are taken in)
+    prewarm_ms, done = 0.0, 0
+    while prewarm_ms < WARM_MS and done < 64 and not args.pmc_child:
+        ctx.timer_begin()
+        job.launch()
+        prewarm_ms += ctx.timer_end()
+        done += 1
+
+    # N > 1: the same per-GPU load on ONE GPU while the other ranks wait -- the reference point scaling efficiency needs
+    single = None
+    if use_dist and world > 1:
+        fence()
+        if rank == 0:
+            k = max(2, min(args.steps, 20))
+            ctx.sync()
+            t0 = time.perf_counter()
+            for s in range(k):
+                job.params.run_offset = s * R
+                job.launch()
+                job.stats_begin('free', s & 1)
+                job.stats_finish(s & 1)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            single = {'value': R * n * k / dt, 'unit': 'sample*MC/s', 'ms_per_step': dt / k * 1e3, 'steps': k, 'runs': R,
+                      'note': 'rank 0 alone (the other ranks idle at a barrier), same runs per GPU, launch + device reduction per '
+                              'step, no exchange: efficiency(N) = value / (N x this)'}
+        fence()
+
     for s in range(args.warmup):
         step(s)
     drain()
@@ -457,10 +551,13 @@ def main():
                                    (cfg_name, args.profile, fs, n, rf, R,
                                     'sensors+trajectories materialised (%d B/sample*MC)' % unit_bytes if keep else 'stats-only'),
                        'runs_per_gpu': R, 'samples_per_run': n, 'total_runs_per_step': world * R,
-                       'parallelism': 'mc-shard x%d, one all-reduce (%s) of the 28-double stats record per step' % (
-                           world, 'RCCL' if args.backend == 'nccl' else args.backend),
+                       'parallelism': ('mc-shard x%d, one all-reduce (%s) of the 28-double stats record per step' % (
+                           world, 'RCCL' if args.backend == 'nccl' else args.backend)) if use_dist else
+                                      'one GPU, no collective (runs shard over ranks by global run id at N > 1)',
                        'device': ctx.name(), 'libginsim_sha256': build,
-                       'rng': 'Philox4x32-7, 3 blocks per IMU step, Box-Muller defined bit-exactly in single precision'},
+                       'rng': 'Philox4x32-7, 3 blocks per IMU step, one word per normal by piecewise-cubic inversion defined bit-exactly '
+                              'in single precision (|z| <= 6.23)'},
+            'prewarm_ms': prewarm_ms,
             'roofline': roofline(alg_bytes, kern_avg_ms, kname, (traffic or {}).get(kname, {}).get('hbm_bytes_per_launch'),
                                  traffic_source=traffic_source,
                                  note='writes exactly its algorithmic bytes; limited by fp64/integer VALU issue at the power-capped clock, '
@@ -468,6 +565,8 @@ def main():
             'result': {'att_std_deg': (merged.std[:3] * r2d).tolist(), 'vel_std_mps': merged.std[6:9].tolist(),
                        'runs': merged.count},
         }
+        if single is not None:
+            out['per_gpu_single'] = single
         if world == 1 and not args.no_legs:
             legs = []
             if keep and args.precision == 'f64':
@@ -489,6 +588,7 @@ def main():
             legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32_262144', 'fp32 kernel, 262 144 runs, materialised', 'turn_90deg', 100.0, 1,
                                262144, True, 'f32', 10))
             legs.append(leg_allan(ginsim, workloads, ctx))
+            legs.append(leg_sim_e2e(workloads))
             out['configs'] = legs
         if world == 1 and args.cpu_baseline_seconds > 0:
             out['cpu_baseline'] = cpu_baseline(fs, rf, ini, truth, acc, gyr, args.cpu_baseline_seconds)

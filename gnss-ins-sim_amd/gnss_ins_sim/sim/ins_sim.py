@@ -26,7 +26,9 @@ Keyword-only extras (defaults keep the reference behaviour):
     device             GPU index (default LOCAL_RANK or 0).
     geo_mag_n          geomagnetic field [uT] in the N frame at the initial position, needed for a 9-axis IMU.  The
                        reference evaluates the WMM model once per run for this vector (pathgen.py:164-168,
-                       date = today); that model is outside the accelerated path, so the caller supplies the vector.
+                       date = today); that model is outside the accelerated path: either the caller supplies the vector, or
+                       a checkout of the reference is reachable (sys.path / $GNSS_INS_SIM_REFERENCE) and ITS geomag.py is
+                       evaluated once on the host (geoparams.reference_geomag_n; geo_mag_date pins the date).
 """
 import os
 import sys
@@ -119,7 +121,7 @@ class _McResults(object):
 class Sim(object):
     def __init__(self, fs, motion_def, ref_frame=0, imu=None, mode=None, env=None, algorithm=None, *,
                  seed=None, keep_trajectories='auto', max_device_bytes=64 * 2 ** 30, device=None, geo_mag_n=None, precision='f64',
-                 keep_runs=0, stats_start=0):
+                 keep_runs=0, stats_start=0, geo_mag_date=None):
         self.name, self.version = NAME, VERSION
         self.fs, self.imu, self.mode, self.env = fs, imu, mode, env
         self.ref_frame = ref_frame if ref_frame in (0, 1) else 0
@@ -133,7 +135,7 @@ class Sim(object):
         self.interested_error = {'att_euler': 'angle', 'pos': None, 'vel': None}
         self.sum = ''
         self.seed, self.keep_trajectories, self.max_device_bytes, self.device = seed, keep_trajectories, max_device_bytes, device
-        self.geo_mag_n = geo_mag_n
+        self.geo_mag_n, self.geo_mag_date = geo_mag_n, geo_mag_date
         self.precision = precision      # 'f32': single-precision kernel (tolerances: tests/test_gpu_fp32.py)
         self.keep_runs, self.stats_start = max(int(keep_runs), 0), stats_start
         self.mc = None
@@ -190,8 +192,15 @@ class Sim(object):
         mobility = self._parse_mode(self.mode)
         fs_imu = self.fs[0]
         if self.imu.magnetometer and self.geo_mag_n is None:
-            raise NotImplementedError('a 9-axis IMU needs the local geomagnetic field: pass Sim(..., geo_mag_n=[bx,by,bz] uT) '
-                                      '(the WMM evaluation of pathgen.py:164-168 is outside the accelerated path)')
+            # pathgen.py:164-168 evaluates the World Magnetic Model ONCE, on the host, at the initial position: done here with the
+            # reference's own geomag.py when a reference checkout is reachable (unchanged 9-axis scripts then run unchanged)
+            from ..geoparams import geoparams
+            self.geo_mag_n = geoparams.reference_geomag_n(ini_pva[0], ini_pva[1], ini_pva[2], self.geo_mag_date)
+            if self.geo_mag_n is None:
+                raise NotImplementedError('a 9-axis IMU needs the local geomagnetic field: pass Sim(..., geo_mag_n=[bx,by,bz] uT), or '
+                                          'put a checkout of the reference (its gnss_ins_sim/geoparams/geomag.py + WMM.COF) on sys.path '
+                                          'or in $GNSS_INS_SIM_REFERENCE (the WMM evaluation of pathgen.py:164-168 is outside the '
+                                          'accelerated path)')
         raw = ginsim.pathgen(ini_pva, motion_def, fs_imu, self.fs[1] if self.imu.gps else 0.0, mobility,
                              self.ref_frame, gps=self.imu.gps,
                              geo_mag_n=self.geo_mag_n if self.imu.magnetometer else None)
@@ -437,10 +446,11 @@ class Sim(object):
                 d.add_data(oname, out[j])
 
     # ------------------------------------------------------------------------------------ results
-    def results(self, data_dir=None, err_stats_start=0, gen_kml=False, extra_opt='', *, max_saved_runs=16, max_summary_runs=32):
-        """Sim.results (ins_sim.py:194-251).  CSV files are written for at most ``max_saved_runs`` Monte-Carlo runs and the
-        printed summary lists the per-run process statistics of at most ``max_summary_runs`` runs (``sim.err_stats``
-        holds all of them)."""
+    def results(self, data_dir=None, err_stats_start=0, gen_kml=False, extra_opt='', *, max_saved_runs=16, max_summary_runs=None):
+        """Sim.results (ins_sim.py:194-251).  CSV files are written for at most ``max_saved_runs`` Monte-Carlo runs.  The printed
+        summary lists the per-run process statistics of EVERY run in the reference's order (ins_sim.py:387-392) unless there are
+        more than ``max_summary_runs`` of them (default: 2048 entries, i.e. far beyond what the reference is ever run with);
+        then the first ones by (algorithm, run number) are printed with a note -- ``sim.err_stats`` holds all of them."""
         if not self.sim_complete:
             print("Call Sim.run() to run the simulaltion first.")
             return None
@@ -458,7 +468,7 @@ class Sim(object):
         self.sim_results = True
         return self.dmgr.available
 
-    def _summary(self, data_dir, data_saved, err_stats_start=0, extra_opt='', max_summary_runs=32):
+    def _summary(self, data_dir, data_saved, err_stats_start=0, extra_opt='', max_summary_runs=None):
         """Same text as Sim.__summary (ins_sim.py:339-413)."""
         d = self.dmgr
         line = '\n------------------------------------------------------------\n'
@@ -487,14 +497,20 @@ class Sim(object):
             s += '\n-----------statistics for ' + d.get_data_all(data_name).description + \
                  ' (in units of ' + st['units'] + ')\n'
             if hasattr(st['max'], 'keys'):
-                keys = sorted(st['max'].keys())
-                for k in keys[:max_summary_runs]:
+                keys = sorted(st['max'].keys())          # the reference's (lexicographic) order
+                limit = 2048 if max_summary_runs is None else int(max_summary_runs)
+                if len(keys) > limit:                    # truncating: first runs of every algorithm by run NUMBER
+                    def run_order(k):
+                        name, _, num = str(k).rpartition('_')
+                        return (name, int(num)) if num.isdigit() else (str(k), -1)
+                    keys = sorted(keys, key=run_order)
+                for k in keys[:limit]:
                     s += '\tSimulation run ' + str(k) + ':\n'
                     s += '\t\t--Max error: ' + str(st['max'][k]) + '\n'
                     s += '\t\t--Avg error: ' + str(st['avg'][k]) + '\n'
                     s += '\t\t--Std of error: ' + str(st['std'][k]) + '\n'
-                if len(keys) > max_summary_runs:
-                    s += '\t... %d more runs: sim.err_stats[%r]\n' % (len(keys) - max_summary_runs, data_name)
+                if len(keys) > limit:
+                    s += '\t... %d more runs: sim.err_stats[%r]\n' % (len(keys) - limit, data_name)
             else:
                 s += '\t--Max error: ' + str(st['max']) + '\n'
                 s += '\t--Avg error: ' + str(st['avg']) + '\n'

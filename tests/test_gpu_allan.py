@@ -101,6 +101,54 @@ def test_allan_full_size_white_noise_slope(ctx):
     assert np.all(np.abs(ad[k] / (N / np.sqrt(tau[k])) - 1.0) < tol[k]), (ad[k] / (N / np.sqrt(tau[k])) - 1.0, tol[k])
 
 
+def test_allan_config5_size_against_the_oracle(ctx):
+    """BASELINE config 5 at its real size: 3600 s static @ 400 Hz (n = 1 440 000), 32 runs -> 192 series generated on the device
+    by the time-parallel sensor kernels (mid-accuracy IMU: white noise + Gauss-Markov drift), re-laid out and analysed by ONE
+    Allan call with the 192-series batch grid (46 averaging factors; the levels 1 440 000 / 144 000 / 14 400 run chunked, 1440 /
+    144 / 14 in the finishing launch).  Twelve series spread over the batch (first / last run, every axis of both sensors) are
+    pulled to the host and pushed through the oracle (allan.py:18-59 restated): all 46 tau to 1e-10."""
+    import ginsim
+    from ginsim import workloads
+    from oracle import ins_np, c_oracle
+    fs, seconds, runs = 400.0, 3600.0, 32
+    text = open(workloads.profile_path('static_1800s')).read().split('\n')
+    ini, _ = workloads.parse_motion('\n'.join(text[:4]))
+    raw = ginsim.pathgen(ini, np.array([[1.0, 0, 0, 0, 0, 0, 0, seconds, 0.0]]), fs, 0.0, workloads.HIGH_MOBILITY, 1)
+    truth = {'ref_accel': np.ascontiguousarray(raw['imu'][:, 1:4]), 'ref_gyro': np.ascontiguousarray(raw['imu'][:, 4:7]),
+             'ref_pos': raw['nav'][:, 1:4], 'ref_vel': raw['nav'][:, 4:7], 'ref_att': raw['nav'][:, 7:10]}
+    n = truth['ref_accel'].shape[0]
+    assert n == 1440000
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    job = ginsim.MonteCarloJob(ctx, fs, 1, truth, acc, gyr, None, runs=runs, algos=(), seed=20260924, keep_sensors=True).run()
+    tau, ad = job.allan(fs)
+    assert tau.size == 46 and tau[0] == 1.0 / fs and tau[-1] == 250.0
+    assert ad['gyro'].shape == (runs, 46, 3)
+    worst = 0.0
+    for name in ('accel', 'gyro'):
+        series = job.sensors(name, [0, runs - 1])                  # (2, n, 3) host copies
+        for k, r in enumerate((0, runs - 1)):
+            for ax in range(3):
+                # the NumPy oracle: reshape + mean as allan.py:44-50 does it (pairwise summation).  The plain-C restatement sums
+                # a bin sequentially and is the LESS accurate side on the accel-z series (offset -9.79 m/s^2 under 5e-3 of noise:
+                # 1e-9 at tau = 250 s against a long-double evaluation, where the device and NumPy agree to 1e-11)
+                va, ta = ins_np.allan_var(series[k][:, ax], fs)
+                np.testing.assert_allclose(tau, ta, rtol=1e-15)
+                np.testing.assert_allclose(ad[name][r][:, ax], np.sqrt(va), rtol=1e-10)
+                worst = max(worst, float(np.abs(ad[name][r][:, ax] / np.sqrt(va) - 1.0).max()))
+                if name == 'gyro' or ax < 2:                        # zero-mean series: the C oracle as well
+                    vc, _ = c_oracle.allan_var(series[k][:, ax], fs)
+                    np.testing.assert_allclose(ad[name][r][:, ax], np.sqrt(vc), rtol=1e-10)
+    try:
+        from test_gpu_full_size import _record
+        _record('c5_allan_192x1440000_vs_oracle', rel=worst)
+    except ImportError:
+        pass
+    # the model shows: white noise -1/2 slope at short tau (ARW), the Gauss-Markov bump above it at long tau
+    k1 = int(np.argmin(np.abs(tau - 1.0)))
+    assert abs(ad['gyro'][:, k1, 0].mean() / float(np.asarray(gyr['arw'])[0]) - 1.0) < 0.02
+    job.release()
+
+
 @pytest.mark.parametrize('runs', [1, 3])
 def test_sim_allan_flow_stays_on_the_device_and_matches_the_host_plugin(ctx, runs):
     """demo_allan.py's flow (BASELINE config 5, second half): Sim on a static profile with the Allan plugin.  Inside this
@@ -127,10 +175,20 @@ def test_sim_allan_flow_stays_on_the_device_and_matches_the_host_plugin(ctx, run
     tau = sim.dmgr.algo_time.data
     ad_g, ad_a = sim.dmgr.ad_gyro.data, sim.dmgr.ad_accel.data
     assert len(ad_g) == runs and len(ad_a) == runs
+    from oracle import ins_np
     host = allan_analysis.Allan()
     for r in range(runs):
         key = 'algo0_%d' % r
-        host.run([fs, sim.dmgr.accel.data[r], sim.dmgr.gyro.data[r]])
+        acc_r, gyr_r = sim.dmgr.accel.data[r], sim.dmgr.gyro.data[r]
+        # the ORACLE (allan.py:18-59 restated in NumPy) on the host copy of this run's series, axis by axis
+        for ax in range(3):
+            va, ta = ins_np.allan_var(gyr_r[:, ax], fs)
+            np.testing.assert_allclose(tau[key], ta, rtol=1e-15)
+            np.testing.assert_allclose(ad_g[key][:, ax], np.sqrt(va), rtol=1e-9)
+            va, _ = ins_np.allan_var(acc_r[:, ax], fs)
+            np.testing.assert_allclose(ad_a[key][:, ax], np.sqrt(va), rtol=1e-9)
+        # and the plugin's plain run(set_of_input) on host arrays (the form the reference's own Sim calls)
+        host.run([fs, acc_r, gyr_r])
         t_h, a_h, g_h = host.get_results()
         np.testing.assert_allclose(tau[key], t_h, rtol=1e-15)
         np.testing.assert_allclose(ad_g[key], g_h, rtol=1e-9)

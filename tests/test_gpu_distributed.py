@@ -23,12 +23,16 @@ def _port():
     return p
 
 
-def _bench(nproc, extra):
+def _bench(nproc, extra, launcher=True):
     env = dict(os.environ, OMP_NUM_THREADS='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr',
            '127.0.0.1', '--master-port', str(_port()), os.path.join(REPO, 'bench.py'), '--gpus', str(nproc)] + extra
     if nproc == 1:
         cmd = [sys.executable, os.path.join(REPO, 'bench.py')] + extra
+    elif not launcher:          # the driver's BENCH form of the command: no launcher in front
+        cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(nproc)] + extra
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1]
@@ -46,6 +50,20 @@ def test_bench_two_ranks_share_the_work():
     assert two['value'] > 0 and 'roofline' in two and 'cpu_baseline' not in two
 
 
+def test_bench_starts_itself_for_n_gt_1():
+    """`python bench.py --gpus 2 ...` with NO launcher in front (the form of the driver's command): the script re-executes itself
+    under torch.distributed.run with two ranks; the N > 1 line carries per_gpu_single (rank 0 alone on the same per-GPU load)
+    and the time-based pre-warm."""
+    common = ['--steps', '3', '--warmup', '1', '--runs-per-gpu', '8192', '--cpu-baseline-seconds', '0', '--no-legs', '--pmc', 'off']
+    two = _bench(2, common + ['--backend', 'gloo', '--shared-device'], launcher=False)
+    assert two['n_gpus'] == 2 and two['config']['total_runs_per_step'] == 16384 and two['result']['runs'] == 16384
+    s = two['per_gpu_single']
+    assert s['runs'] == 8192 and s['value'] > 0 and s['unit'] == 'sample*MC/s'
+    assert two['prewarm_ms'] >= 30.0 and 'gloo' in two['config']['parallelism']
+    # two ranks sharing ONE GPU cannot beat one rank by more than the overlap of host work: a sanity bound, not a scaling claim
+    assert two['value'] < 2.5 * s['value']
+
+
 def test_bench_line_contract():
     """The ONE JSON line the driver reads: every field of the contract, on the C2 workload at its real size (few steps), with
     a short CPU-baseline sample and one leg-free pass; the roofline object must be consistent with itself."""
@@ -57,6 +75,7 @@ def test_bench_line_contract():
     assert d['dtype'] == 'f64' and d['data'] == 'synthetic' and d['scaling'] == 'weak' and d['unit'] == 'sample*MC/s'
     assert 'workload' in d['config'] and 'configs[1]' in d['config']['workload'] and 'model' not in d['config']
     assert d['config']['runs_per_gpu'] == 65536 and d['config']['samples_per_run'] == 1000
+    assert 'no collective' in d['config']['parallelism'] and d['prewarm_ms'] >= 30.0 and 'per_gpu_single' not in d
     # value = units of all timed steps / wall time
     np.testing.assert_allclose(d['value'], 65536 * 1000 / (d['ms_per_step'] * 1e-3), rtol=1e-6)
     r = d['roofline']
