@@ -190,24 +190,37 @@ __device__ __forceinline__ double angle_range_pi_mul(double x) {
 }
 
 // Online process-error statistics of one run (InsDataMgr.__process_error_stats, ins_data_manager.py:761-795, on
-// array_error :519-553): Welford mean / M2 and max|e| of the nine error components over the samples >= proc_first.
-// The same recurrence, in the same order, as process_stats_kernel applies to kept trajectories -- here the samples
-// never leave the registers, which is what makes the statistics available when the trajectories are not kept.
+// array_error :519-553): max|e|, mean and std(ddof=0) of the nine error components over the samples >= proc_first, without
+// the samples ever leaving the registers -- which is what makes the statistics available when the trajectories are not kept.
+//
+// Round 3: RAW sums (sum e, sum e^2) instead of round 2's Welford recurrence (a Newton reciprocal and five dependent fp64
+// operations per component and step; now one add, one fused multiply-add, one max).  Conditioning: every run starts on the
+// truth, so e is the drift accumulated since sample 0 and |mean| is of the order of the std; the variance comes out as
+// sum e^2 / n - mean^2 with a relative rounding error of ~ 2^-53 (1 + mean^2 / var) sqrt(n) -- 1e-12 for mean^2 / var up
+// to 1e3 at n = 2e5.  process_stats_kernel (stats.hip), which reads kept trajectories, keeps the Welford / Chan-merge form
+// and is the checker: the two agree to 1e-9 relative (tests/test_process_stats.py), the online form to 1e-7 with the oracle.
+// The attitude error is wrapped to [-pi, pi] only when some lane of the wavefront is outside it (wrap_pi3).
+__device__ __forceinline__ double wrap_pi_lane(double x) { return fabs(x) <= kPi ? x : angle_range_pi_mul(x); }
+
+__device__ __forceinline__ void wrap_pi3(double (&e)[9]) {
+    const bool out = !(fabs(e[0]) <= kPi) || !(fabs(e[1]) <= kPi) || !(fabs(e[2]) <= kPi);
+    if (__builtin_amdgcn_ballot_w64(out) != 0) {
+        e[0] = wrap_pi_lane(e[0]); e[1] = wrap_pi_lane(e[1]); e[2] = wrap_pi_lane(e[2]);
+    }
+}
+
 struct Proc {
-    double mean[9], m2[9], mx[9];
-    double cnt;
+    double s1[9], s2[9], mx[9];
     __device__ __forceinline__ void clear() {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) { mean[c] = 0.0; m2[c] = 0.0; mx[c] = 0.0; }
-        cnt = 0.0;
+        for (int c = 0; c < 9; ++c) { s1[c] = 0.0; s2[c] = 0.0; mx[c] = 0.0; }
     }
     // t = truth att3, pos3, vel3 of this sample (wave-uniform); NED: position error in local NED metres (:542-552)
     template <bool NED>
     __device__ __forceinline__ void add(const Nav& s, const double (&t)[9]) {
         double e[9];
-        e[0] = angle_range_pi_mul(s.att.yaw - t[0]);
-        e[1] = angle_range_pi_mul(s.att.pit - t[1]);
-        e[2] = angle_range_pi_mul(s.att.rol - t[2]);
+        e[0] = s.att.yaw - t[0]; e[1] = s.att.pit - t[1]; e[2] = s.att.rol - t[2];
+        wrap_pi3(e);
         if (NED) {
             const Vec3 d = lla_error_ned(s.pos, Vec3{t[3], t[4], t[5]});
             e[3] = d.x; e[4] = d.y; e[5] = d.z;
@@ -215,23 +228,21 @@ struct Proc {
             e[3] = s.pos.x - t[3]; e[4] = s.pos.y - t[4]; e[5] = s.pos.z - t[5];
         }
         e[6] = s.vel.x - t[6]; e[7] = s.vel.y - t[7]; e[8] = s.vel.z - t[8];
-        cnt += 1.0;
-        const double icnt = rcp_nr(cnt);
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
-            const double d = e[c] - mean[c];
-            mean[c] = __builtin_fma(d, icnt, mean[c]);
-            m2[c] = __builtin_fma(d, e[c] - mean[c], m2[c]);
-            const double a = fabs(e[c]);
-            mx[c] = a > mx[c] ? a : mx[c];
+            s1[c] += e[c];
+            s2[c] = __builtin_fma(e[c], e[c], s2[c]);
+            mx[c] = fmax(mx[c], fabs(e[c]));
         }
     }
-    __device__ __forceinline__ void store(double* __restrict__ out, int64_t runs, int64_t r) const {
+    __device__ __forceinline__ void store(double* __restrict__ out, int64_t runs, int64_t r, double cnt) const {
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
+            const double mean = cnt > 0.0 ? s1[c] / cnt : 0.0;
+            const double var = cnt > 0.0 ? s2[c] / cnt - mean * mean : 0.0;
             out[(0 * 9 + c) * runs + r] = mx[c];
-            out[(1 * 9 + c) * runs + r] = mean[c];
-            out[(2 * 9 + c) * runs + r] = cnt > 0.0 ? sqrt(m2[c] / cnt) : 0.0;
+            out[(1 * 9 + c) * runs + r] = mean;
+            out[(2 * 9 + c) * runs + r] = var > 0.0 ? sqrt(var) : 0.0;
         }
     }
 };
@@ -401,7 +412,7 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
         if (FREE && a.out_end_ned[0]) store_end_ned(a.out_end_ned[0], runs, r, fi);
         if (ODO && a.out_end_ned[1]) store_end_ned(a.out_end_ned[1], runs, r, od);
     }
-    if (PS) ps.store(a.out_proc[FREE ? 0 : 1], runs, r);
+    if (PS) ps.store(a.out_proc[FREE ? 0 : 1], runs, r, (double)(n - (a.proc_first > 0 ? a.proc_first : 0)));
     if (trace) trace[3] = __builtin_amdgcn_s_memtime();
 }
 

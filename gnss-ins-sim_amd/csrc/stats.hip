@@ -113,7 +113,10 @@ __global__ void __launch_bounds__(64 * kSeg) process_stats_kernel(const double* 
 #pragma unroll
             for (int c = 0; c < 9; ++c) { x[c] = traj[c * plane + j * runs + r]; t[c] = truth[9 * j + c]; }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) e[c] = angle_range_pi_mul(x[c] - t[c]);
+            for (int c = 0; c < 3; ++c) {       // wrapped only when outside [-pi, pi], exactly as the online accumulator does (mc_kernel.hip wrap_pi3)
+                const double d = x[c] - t[c];
+                e[c] = fabs(d) <= kPi ? d : angle_range_pi_mul(d);
+            }
             if (pos_ned) {
                 const Vec3 d = lla_error_ned(Vec3{x[3], x[4], x[5]}, Vec3{t[3], t[4], t[5]});
                 e[3] = d.x; e[4] = d.y; e[5] = d.z;

@@ -198,7 +198,7 @@ def test_c3_sim_for_real(ctx):
         sim.results()                                       # the reference's defaults: err_stats_start = 0
     text = out.getvalue()
     st = sim.err_stats
-    assert len(st['vel']['std']) == R and ('... %d more runs' % (R - 32)) in text
+    assert len(st['vel']['std']) == R and ('... %d more runs' % (R - 2048)) in text
     # sampled runs vs the C oracle's trajectories -> host process statistics (oracle/ins_np.py)
     acc, gyr = imu.accel_err, imu.gyro_err
     worst = 0.0

@@ -235,7 +235,10 @@ def test_sim_stats_only_results_with_reference_defaults_and_keep_runs(tmp_path):
                     assert len(b[name][s]) == 2 * R
                     for key in ('algo0_0', 'algo1_7', 'algo0_%d' % (R - 1), 'algo1_%d' % (R - 1)):
                         np.testing.assert_allclose(b[name][s][key], a[name][s][key], rtol=1e-9, atol=atol)
-        assert '... %d more runs' % (2 * R - 32) in text_b or kw.get('err_stats_start', 0) == -1
+        if kw.get('err_stats_start', 0) != -1:          # every run is listed, as the reference does (ins_sim.py:387-392)
+            assert 'Simulation run algo1_%d:' % (R - 1) in text_b and 'Simulation run algo0_150:' in text_b and 'more runs' not in text_b
+    _, short = stats(lean, max_summary_runs=5)          # an explicit limit truncates by (algorithm, run NUMBER)
+    assert '... %d more runs' % (2 * R - 5) in short and 'Simulation run algo0_4:' in short and 'Simulation run algo0_10:' not in short
     with contextlib.redirect_stdout(io.StringIO()):
         lean.results(str(tmp_path), err_stats_start=-1)
     files = set(os.listdir(tmp_path))

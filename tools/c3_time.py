@@ -9,8 +9,8 @@ ctx = ginsim.Context(0)
 acc, gyr = workloads.imu_grade('mid-accuracy')
 ini, truth, _ = workloads.truth_from_profile('long_drive', 200.0, 0)
 t = {k: (v[:20000] if hasattr(v, 'shape') and v.shape and v.shape[0] > 20000 else v) for k, v in truth.items()}
-for prec in ('f64', 'f32'):
-    job = ginsim.MonteCarloJob(ctx, 200.0, 0, t, acc, gyr, ini, runs=262144, seed=1, precision=prec).run()
+for prec, kw in (('f64', {}), ('f64', {'proc_first': 0, 'end_ned': True}), ('f32', {})):
+    job = ginsim.MonteCarloJob(ctx, 200.0, 0, t, acc, gyr, ini, runs=262144, seed=1, precision=prec, **kw).run()
     ts = []
     for _ in range(3):
         ctx.timer_begin(); job.launch(); ts.append(ctx.timer_end())
