@@ -238,6 +238,7 @@ def test_sim_stats_only_results_with_reference_defaults_and_keep_runs(tmp_path):
         if kw.get('err_stats_start', 0) != -1:          # every run is listed, as the reference does (ins_sim.py:387-392)
             assert 'Simulation run algo1_%d:' % (R - 1) in text_b and 'Simulation run algo0_150:' in text_b and 'more runs' not in text_b
     _, short = stats(lean, max_summary_runs=5)          # an explicit limit truncates by (algorithm, run NUMBER)
+    short = short[short.rindex('Sample frequency of IMU'):]      # Sim.sum accumulates the summaries of every results() call, as the reference's does
     assert '... %d more runs' % (2 * R - 5) in short and 'Simulation run algo0_4:' in short and 'Simulation run algo0_10:' not in short
     with contextlib.redirect_stdout(io.StringIO()):
         lean.results(str(tmp_path), err_stats_start=-1)
