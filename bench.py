@@ -371,6 +371,9 @@ def main():
                     help='roofline.traffic: rocprofv3 PMC passes of this build (live), the stamped profiles/pmc_traffic.json, or null')
     ap.add_argument('--pmc-child', action='store_true', help='internal: the short workload the live PMC passes profile')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for tests)')
+    ap.add_argument('--exchange', choices=['abi', 'torch'], default=None,
+                    help="N > 1: 'abi' = the library's own RCCL all-gather on the kernel stream (ginsim_end_stats_all_begin/_finish, "
+                         "default with --backend nccl), 'torch' = torch.distributed all-reduce of the record table (default otherwise)")
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise torch.distributed and run the exchange also with ONE rank (a one-GPU box can then execute '
                          'the RCCL code path: communicator set-up, device-tensor all-reduce, non-blocking work handles)')
@@ -433,6 +436,21 @@ def main():
     # never waits for a collective that has not had a whole kernel time to complete -- also when the RCCL kernel
     # cannot be scheduled next to the MC kernel, which fills every CU's LDS.
     pending_stats, pending_coll = [], []
+    exchange, exchange_note = (args.exchange or ('abi' if args.backend == 'nccl' else 'torch')) if use_dist else None, None
+    if exchange == 'abi':
+        # the library's own communicator (RCCL, resolved at run time); torch.distributed only carries the 128-byte id.  All ranks
+        # must agree on the outcome, so the success flags are reduced before anyone relies on it.
+        ok = 1.0
+        try:
+            distributed.init_abi_comm(ctx, group)
+        except Exception as e:                                     # noqa: BLE001 -- fall back to the torch exchange, say so
+            ok, exchange_note = 0.0, 'abi exchange unavailable on rank %d: %s' % (rank, repr(e)[:160])
+        flag = torch.tensor([ok], dtype=torch.float64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if float(flag.item()) < 1.0:
+            if ok:
+                ctx.comm_destroy()
+            exchange, exchange_note = 'torch', exchange_note or 'abi exchange unavailable on another rank'
 
     def collect():
         """finish what can be finished: the all-reduce of batch s-2, then the record of batch s-1 -> issue its all-reduce"""
@@ -444,6 +462,10 @@ def main():
 
     def drain():
         merged = None
+        if exchange == 'abi':
+            while pending_stats:
+                merged = job.stats_all_finish(pending_stats.pop())
+            return merged
         while pending_stats or pending_coll:
             m = collect()
             merged = m if m is not None else merged
@@ -456,6 +478,11 @@ def main():
         job.launch()
         if s % stride == 0:
             ctx.event_record(2 * (s // stride) + 1)
+        if exchange == 'abi':       # reduction -> RCCL all-gather -> pinned copy, all on the kernel stream; one batch behind
+            merged = job.stats_all_finish(pending_stats.pop()) if pending_stats else None
+            job.stats_all_begin('free', s & 1)
+            pending_stats.append(s & 1)
+            return merged
         merged = collect()
         job.stats_begin('free', s & 1)
         pending_stats.append(s & 1)
@@ -497,6 +524,22 @@ def main():
                       'note': 'rank 0 alone (the other ranks idle at a barrier), same runs per GPU, launch + device reduction per '
                               'step, no exchange: efficiency(N) = value / (N x this)'}
         fence()
+
+    if exchange == 'abi':
+        # one batch through BOTH exchanges before anything is timed: the library's all-gather must give the record the
+        # torch.distributed all-reduce gives; if not, the timed region uses the torch exchange and the line says so
+        job.params.run_offset = rank * R
+        job.launch()
+        job.stats_all_begin('free', 0)
+        a = job.stats_all_finish(0)
+        b = distributed.allreduce_stats(job.stats('free'), group, device)
+        same = a.count == b.count and np.allclose(a.mean, b.mean, rtol=1e-12, atol=1e-18) and np.allclose(a.m2, b.m2, rtol=1e-12) \
+            and np.array_equal(a.maxabs, b.maxabs)
+        flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if float(flag.item()) < 1.0:
+            ctx.comm_destroy()
+            exchange, exchange_note = 'torch', 'abi exchange disagreed with the torch.distributed all-reduce on the check batch'
 
     for s in range(args.warmup):
         step(s)
@@ -551,8 +594,10 @@ def main():
                                    (cfg_name, args.profile, fs, n, rf, R,
                                     'sensors+trajectories materialised (%d B/sample*MC)' % unit_bytes if keep else 'stats-only'),
                        'runs_per_gpu': R, 'samples_per_run': n, 'total_runs_per_step': world * R,
-                       'parallelism': ('mc-shard x%d, one all-reduce (%s) of the 28-double stats record per step' % (
-                           world, 'RCCL' if args.backend == 'nccl' else args.backend)) if use_dist else
+                       'parallelism': ('mc-shard x%d, one exchange of the 28-double stats record per step: %s' % (world, (
+                           'RCCL all-gather behind the C ABI on the kernel stream (ginsim_end_stats_all_begin/_finish)' if exchange == 'abi'
+                           else 'torch.distributed all-reduce (%s)' % ('RCCL' if args.backend == 'nccl' else args.backend))
+                           + ('; ' + exchange_note if exchange_note else ''))) if use_dist else
                                       'one GPU, no collective (runs shard over ranks by global run id at N > 1)',
                        'device': ctx.name(), 'libginsim_sha256': build,
                        'rng': 'Philox4x32-7, 3 blocks per IMU step, one word per normal by piecewise-cubic inversion defined bit-exactly '

@@ -35,6 +35,8 @@ SOURCES = [
     ('ginsim_api.hip', ['--offload-arch=' + ARCH]),
     # host-only truth generator; no fused multiply-adds (see the file header)
     ('pathgen.cpp', ['-x', 'c++', '-ffp-contract=off']),
+    # RCCL behind the C ABI (host code; librccl is dlopen()ed at run time, nothing is linked)
+    ('comm.cpp', ['-x', 'hip', '--offload-arch=' + ARCH]),
 ]
 
 
@@ -87,7 +89,7 @@ def build(force=False, verbose=False, tag=None, defines=(), xflags=()):
             if p.returncode != 0:
                 raise subprocess.CalledProcessError(p.returncode, cmd)
     if force or any(newer(o, LIB) for o in objs):
-        cmd = [HIPCC, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + objs
+        cmd = [HIPCC, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + objs + ['-ldl']
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

@@ -12,6 +12,7 @@
 
 #include "ginsim.h"
 #include "allan.hpp"
+#include "comm.hpp"
 
 namespace ginsim {
 
@@ -68,6 +69,11 @@ struct ginsim_ctx {
     uint64_t* allan_flag = nullptr;                       // host-coherent word the finishing launch releases its sequence number into
     uint32_t* allan_counter = nullptr;                    // device: workgroups of the finishing launch that are done
     uint64_t allan_seq = 0;
+    ginsim::Comm* comm = nullptr;                         // RCCL communicator of this rank (ginsim_comm_init), or nullptr
+    double* comm_recv = nullptr;                          // device [8 slots][nranks][28]: the gathered records
+    ginsim_stats* comm_host = nullptr;                    // pinned host copy of the same
+    hipEvent_t comm_ev[8] = {};
+    bool comm_pending[8] = {};
     ginsim_stats* stat_slots = nullptr;                   // pinned host records of ginsim_end_stats_begin/_finish
     hipEvent_t stat_ev[8] = {};
     bool stat_pending[8] = {};
@@ -171,6 +177,11 @@ int ginsim_destroy(ginsim_ctx* c) {
     if (c->stat_slots) (void)hipHostFree(c->stat_slots);
     if (c->allan_host) (void)hipHostFree(c->allan_host);
     if (c->allan_flag) (void)hipHostFree(c->allan_flag);
+    if (c->comm) ginsim::comm_destroy(c->comm);
+    if (c->comm_recv) (void)hipFree(c->comm_recv);
+    if (c->comm_host) (void)hipHostFree(c->comm_host);
+    for (hipEvent_t e : c->comm_ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->allan_counter) (void)hipFree(c->allan_counter);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -431,6 +442,76 @@ int ginsim_end_stats_finish(ginsim_ctx* c, int32_t slot, ginsim_stats* host_out)
     HIP_TRY(hipEventSynchronize(c->stat_ev[slot]));
     *host_out = c->stat_slots[slot];
     c->stat_pending[slot] = false;
+    return GINSIM_OK;
+}
+
+// ---- multi-GPU exchange behind the ABI (RCCL on the context's stream; csrc/comm.cpp)
+int ginsim_comm_unique_id(unsigned char* id) {
+    REQUIRE(id, "comm_unique_id: NULL output");
+    const char* err = comm_unique_id(id);
+    if (err) { set_error("comm_unique_id: %s", err); return GINSIM_ERR_HIP; }
+    return GINSIM_OK;
+}
+
+int ginsim_comm_init(ginsim_ctx* c, int32_t nranks, int32_t rank, const unsigned char* id) {
+    REQUIRE(c && id && nranks >= 1 && rank >= 0 && rank < nranks, "comm_init: bad arguments");
+    REQUIRE(!c->comm, "comm_init: this context already has a communicator");
+    HIP_TRY(hipSetDevice(c->device));
+    const char* err = comm_create(nranks, rank, id, &c->comm);
+    if (err) { set_error("comm_init: %s", err); return GINSIM_ERR_HIP; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->comm_recv), sizeof(ginsim_stats) * 8 * (size_t)nranks));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->comm_host), sizeof(ginsim_stats) * 8 * (size_t)nranks, hipHostMallocDefault));
+    return GINSIM_OK;
+}
+
+int ginsim_comm_destroy(ginsim_ctx* c) {
+    REQUIRE(c, "comm_destroy: NULL context");
+    if (!c->comm) return GINSIM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    comm_destroy(c->comm);
+    c->comm = nullptr;
+    if (c->comm_recv) { (void)hipFree(c->comm_recv); c->comm_recv = nullptr; }
+    if (c->comm_host) { (void)hipHostFree(c->comm_host); c->comm_host = nullptr; }
+    for (bool& p : c->comm_pending) p = false;
+    return GINSIM_OK;
+}
+
+int ginsim_end_stats_all_begin(ginsim_ctx* c, const double* end_err, int64_t runs, int32_t slot) {
+    REQUIRE(c && runs >= 0 && (runs == 0 || end_err) && slot >= 0 && slot < 8, "end_stats_all_begin: bad arguments");
+    REQUIRE(c->comm, "end_stats_all_begin: no communicator (ginsim_comm_init)");
+    REQUIRE(!c->comm_pending[slot], "end_stats_all_begin: slot %d is still pending (call ginsim_end_stats_all_finish first)", slot);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->comm_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&c->comm_ev[slot], hipEventDisableTiming));
+    const int nranks = comm_nranks(c->comm);
+    void* ws = nullptr;
+    const size_t wb = stats_scratch_bytes(runs > 0 ? runs : 1);
+    HIP_TRY(scratch(c, 0, wb, &ws));
+    double* rec = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + wb - sizeof(ginsim_stats));
+    if (runs > 0) HIP_TRY(launch_end_stats(end_err, runs, ws, c->stream));
+    else HIP_TRY(hipMemsetAsync(rec, 0, sizeof(ginsim_stats), c->stream));      // a rank without runs: the empty record
+    double* recv = c->comm_recv + (size_t)slot * nranks * (sizeof(ginsim_stats) / sizeof(double));
+    const char* err = comm_allgather_f64(c->comm, rec, recv, sizeof(ginsim_stats) / sizeof(double), c->stream);
+    if (err) { set_error("end_stats_all_begin: %s", err); return GINSIM_ERR_HIP; }
+    HIP_TRY(hipMemcpyAsync(c->comm_host + (size_t)slot * nranks, recv, sizeof(ginsim_stats) * nranks, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->comm_ev[slot], c->stream));
+    c->comm_pending[slot] = true;
+    return GINSIM_OK;
+}
+
+int ginsim_end_stats_all_finish(ginsim_ctx* c, int32_t slot, ginsim_stats* merged) {
+    REQUIRE(c && merged && slot >= 0 && slot < 8, "end_stats_all_finish: bad arguments");
+    REQUIRE(c->comm && c->comm_pending[slot], "end_stats_all_finish: nothing was begun in slot %d", slot);
+    HIP_TRY(hipEventSynchronize(c->comm_ev[slot]));
+    c->comm_pending[slot] = false;
+    const int nranks = comm_nranks(c->comm);
+    std::vector<ginsim_stats> parts;
+    for (int r = 0; r < nranks; ++r) {
+        const ginsim_stats& p = c->comm_host[(size_t)slot * nranks + r];
+        if (p.count > 0) parts.push_back(p);
+    }
+    memset(merged, 0, sizeof(*merged));
+    if (!parts.empty()) stats_merge_host(parts.data(), (int)parts.size(), merged);     // fixed order: rank 0 .. nranks-1
     return GINSIM_OK;
 }
 

@@ -93,6 +93,11 @@ _SIGS = {
     'ginsim_end_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Stats)]),
     'ginsim_end_stats_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     'ginsim_end_stats_finish': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
+    'ginsim_comm_unique_id': (C.c_int, [C.c_char_p]),
+    'ginsim_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
+    'ginsim_comm_destroy': (C.c_int, [C.c_void_p]),
+    'ginsim_end_stats_all_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    'ginsim_end_stats_all_finish': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     'ginsim_process_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _PD]),
     'ginsim_end_stats_from_traj': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                              C.POINTER(Stats)]),

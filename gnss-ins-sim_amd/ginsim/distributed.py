@@ -57,6 +57,18 @@ def allreduce_stats_end(handle):
     return StatsResult.merge(table.cpu().numpy())
 
 
+def init_abi_comm(ctx, group=None):
+    """Give `ctx` the library's own RCCL communicator over the ranks of a torch.distributed group: rank 0 draws the unique id
+    (ginsim_comm_unique_id), torch.distributed only carries those 128 bytes to the other ranks (bootstrap, outside any timed
+    region); afterwards MonteCarloJob.stats_all_begin / _finish exchange the records on the context's stream without torch."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ctx.comm_init(world, rank, box[0])
+    return world, rank
+
+
 def stats_from_errors(e):
     """Packed record of a host array of end-point errors (runs,9) -- used by tests to fabricate partials."""
     e = np.asarray(e, dtype=np.float64)

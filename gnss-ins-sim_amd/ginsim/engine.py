@@ -109,6 +109,23 @@ class Context(object):
         check(lib.ginsim_event_elapsed(self.handle, int(slot_a), int(slot_b), C.byref(ms)))
         return ms.value
 
+    # ---- multi-GPU exchange behind the C ABI (RCCL on this context's stream)
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes rank 0 hands to the other ranks (ncclGetUniqueId)."""
+        buf = C.create_string_buffer(128)
+        check(lib.ginsim_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        check(lib.ginsim_comm_init(self.handle, int(nranks), int(rank), bytes(unique_id)))
+        self.comm_ranks = int(nranks)
+
+    def comm_destroy(self):
+        if self.handle:
+            check(lib.ginsim_comm_destroy(self.handle))
+        self.comm_ranks = 0
+
     def close(self):
         if self.handle:
             lib.ginsim_destroy(self.handle)
@@ -449,6 +466,17 @@ class MonteCarloJob(object):
         """Wait for stats_begin(slot) only (later launches on the stream keep running) and return its record."""
         s = _lib.Stats()
         check(lib.ginsim_end_stats_finish(self.ctx.handle, int(slot), C.byref(s)))
+        return StatsResult(s)
+
+    def stats_all_begin(self, algo, slot=0):
+        """stats_begin over ALL ranks (the context needs comm_init): reduction -> RCCL all-gather of the records -> pinned slot,
+        enqueued on the stream without waiting."""
+        check(lib.ginsim_end_stats_all_begin(self.ctx.handle, self._bufs['end_' + algo].ptr, self.runs, int(slot)))
+
+    def stats_all_finish(self, slot=0):
+        """Wait for stats_all_begin(slot) only; the merged record of every rank's runs (identical on every rank)."""
+        s = _lib.Stats()
+        check(lib.ginsim_end_stats_all_finish(self.ctx.handle, int(slot), C.byref(s)))
         return StatsResult(s)
 
     def process_stats(self, algo, first_sample=0, pos_ned=False):

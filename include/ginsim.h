@@ -196,6 +196,23 @@ int ginsim_end_stats(ginsim_ctx* ctx, const double* end_err /*device [9][runs]*/
 int ginsim_end_stats_begin(ginsim_ctx* ctx, const double* end_err, int64_t runs, int32_t slot);
 int ginsim_end_stats_finish(ginsim_ctx* ctx, int32_t slot, ginsim_stats* host_out);
 
+/* ---- multi-GPU: Monte-Carlo runs shard over ranks by global run id (run_offset), one process and one context per GPU; the
+ *      ONE exchange of the path is every rank's statistics record to every rank.  ABI 3 puts it behind the
+ *      boundary: an RCCL all-gather enqueued on the context's stream right behind the on-device reduction (librccl is
+ *      resolved at run time on first use; single-GPU callers never load it).  The reference has no counterpart
+ *      (gnss_ins_sim/sim/ins_sim.py:490 is a serial loop).
+ *      Bootstrap: rank 0 calls ginsim_comm_unique_id and hands the 128 bytes to the other ranks through whatever launcher the
+ *      caller uses (an environment variable, a file, torch.distributed's store ...); every rank then calls ginsim_comm_init. */
+#define GINSIM_COMM_ID_BYTES 128
+int ginsim_comm_unique_id(unsigned char* id /*[GINSIM_COMM_ID_BYTES]*/);
+int ginsim_comm_init(ginsim_ctx* ctx, int32_t nranks, int32_t rank, const unsigned char* id);
+int ginsim_comm_destroy(ginsim_ctx* ctx);
+/* ginsim_end_stats_begin / _finish over ALL ranks: reduction of this rank's end errors (runs may be 0: an empty record) ->
+ * all-gather of the 28-double records -> copy into pinned slot `slot` (0..7), all on the context's stream; _finish waits for
+ * that slot only and returns the Chan merge of the non-empty records in rank order (the same on every rank). */
+int ginsim_end_stats_all_begin(ginsim_ctx* ctx, const double* end_err, int64_t runs, int32_t slot);
+int ginsim_end_stats_all_finish(ginsim_ctx* ctx, int32_t slot, ginsim_stats* merged);
+
 /* Process-error statistics of every run: InsDataMgr.__process_error_stats (ins_data_manager.py:761-795) over
  * array_error (:519-553): e[j] = traj[j] - ref[j] for samples j >= first_sample, attitude wrapped to [-pi,pi];
  * pos_ned != 0 (ref_frame 0, extra_opt='ned'): LLA error -> metres in the local NED frame of the reference (:542-552).

@@ -95,9 +95,46 @@ def test_rccl_exchange_executes_on_one_gpu():
     non-blocking work handles and the barrier exactly as N ranks would; the merged record must equal the local one."""
     common = ['--steps', '3', '--warmup', '1', '--runs-per-gpu', '8192', '--cpu-baseline-seconds', '0', '--no-legs', '--pmc', 'off']
     plain = _bench(1, common)
-    rccl = _bench(1, common + ['--force-dist', '--backend', 'nccl'])
-    assert rccl['n_gpus'] == 1 and 'RCCL' in rccl['config']['parallelism']
+    rccl = _bench(1, common + ['--force-dist', '--backend', 'nccl', '--exchange', 'torch'])
+    assert rccl['n_gpus'] == 1 and 'all-reduce (RCCL)' in rccl['config']['parallelism']
     assert rccl['result'] == plain['result']
+    # the default with backend nccl: the library's own communicator, the all-gather on the kernel stream (C ABI), after one
+    # batch was cross-checked against the torch.distributed exchange
+    abi = _bench(1, common + ['--force-dist', '--backend', 'nccl'])
+    assert 'behind the C ABI' in abi['config']['parallelism'] and 'unavailable' not in abi['config']['parallelism'] \
+        and 'disagreed' not in abi['config']['parallelism'], abi['config']['parallelism']
+    assert abi['result'] == plain['result']
+
+
+def test_abi_exchange_one_rank_communicator():
+    """ginsim_comm_* / ginsim_end_stats_all_*: a one-rank RCCL communicator created by the library itself (librccl resolved at
+    run time), the all-gather enqueued on the context's stream behind the reduction; the merged record is the local one, two
+    slots can be in flight, and a second communicator on the same context is refused."""
+    import ginsim
+    from ginsim import workloads
+    ctx = ginsim.Context(0)
+    ctx.comm_init(1, 0, ctx.comm_unique_id())
+    with pytest.raises(ValueError, match='already has a communicator'):
+        ctx.comm_init(1, 0, ctx.comm_unique_id())
+    ini, truth, _ = workloads.truth_from_profile('turn_90deg', 100.0, 1)
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    job = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=5000, seed=3)
+    job.launch()
+    job.stats_all_begin('free', 0)
+    job.params.run_offset = 5000
+    job.launch()
+    job.stats_all_begin('free', 1)
+    first, second = job.stats_all_finish(0), job.stats_all_finish(1)
+    local = job.stats('free')                        # the second batch is the one still in the buffers
+    assert second.count == 5000 and np.array_equal(second.mean, local.mean) and np.array_equal(second.m2, local.m2)
+    assert first.count == 5000 and not np.array_equal(first.mean, second.mean)
+    with pytest.raises(ValueError, match='nothing was begun'):
+        job.stats_all_finish(0)
+    ctx.comm_destroy()
+    with pytest.raises(ValueError, match='no communicator'):
+        job.stats_all_begin('free', 0)
+    job.release()
+    ctx.close()
 
 
 _SIM_WORKER = r'''
