@@ -560,9 +560,15 @@ def main():
     kern_avg_ms = float(np.mean(kern_ms))
     assert merged.count == world * R, (merged.count, world * R)
 
-    if args.pmc_child:                                      # the given-sensors kernel is profiled in the same pass
+    if args.pmc_child:                                      # the given-sensors and the fp32 kernel are profiled in the same pass
         if keep and args.precision == 'f64':
             leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, None, reps=3)
+            job.release()
+            job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, algos=('free',), seed=SEED, keep_sensors=True,
+                                       keep_traj=True, precision='f32')
+            for _ in range(4):
+                job.launch()
+            ctx.sync()
         job.release()
         ctx.close()
         return

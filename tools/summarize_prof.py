@@ -108,8 +108,16 @@ if '--traffic' in sys.argv:
     with open(os.path.join(DST, 'pmc_traffic.json'), 'w') as f:
         json.dump(summary, f, indent=1)
 print(json.dumps(summary, indent=1))
+valu = {}
 for kn, c in pmc.items():
-    if 'mc_kernel_split' in kn and 'SQ_INSTS_VALU' in c and 'SQ_WAVES' in c:
+    if ('mc_kernel_split<' in kn or 'mc_kernel_f32_split<' in kn) and 'SQ_INSTS_VALU' in c and 'SQ_WAVES' in c:
         steps = 1000.0
-        groups = c['SQ_WAVES'][1] / (3.0 if (', 2, true>' in kn or ', 2, false>' in kn) else 2.0)     # PROD = 2: three wavefronts per 64 runs
-        print('%s: VALU per step and 64 runs = %.1f' % (kn[:60], c['SQ_INSTS_VALU'][1] / groups / steps))
+        args_ = kn[kn.index('<') + 1:kn.index('>')].split(', ')
+        prod = int(args_[3])                                # wavefronts per 64 runs = 1 consumer + PROD producers
+        groups = c['SQ_WAVES'][1] / (1.0 + prod)
+        name = kn[len('void '):kn.index('(')] if kn.startswith('void ') else kn[:kn.index('(')]
+        valu[name] = {'valu_per_step_and_64_runs': c['SQ_INSTS_VALU'][1] / groups / steps,
+                      'salu_per_step_and_64_runs': c['SQ_INSTS_SALU'][1] / groups / steps if 'SQ_INSTS_SALU' in c else None}
+        print('%s: VALU per step and 64 runs = %.1f' % (name, valu[name]['valu_per_step_and_64_runs']))
+with open(os.path.join(DST, tag + '_valu_per_step.json'), 'w') as f:
+    json.dump({'raw_run': 'gpurun_out/round_' + tag, 'libginsim_sha256': sha, 'kernels': valu}, f, indent=1)
