@@ -55,10 +55,25 @@ with open(os.path.join(DST, tag + '_kernel_trace_stats.csv'), 'w', newline='') a
     for r in rows:
         w.writerow([r[0], r[1], int(r[2]), int(r[3]), int(r[4]), int(r[5]), '%.2f' % (100.0 * r[2] / total)] + list(r[6:]))
 k = bench['roofline']['kernel']
-tr = [(r[1], r[3] / 1e6) for r in rows if r[0].startswith('void ' + k + '(')]
-tr.sort(reverse=True)       # the headline configuration is the one with the most launches (timed + warm-up steps)
-print('dominant kernel %s: HIP events %.4f ms (bench.json) vs rocprofv3 trace avg %.4f ms over %d launches' % (
-    k, bench['roofline']['kernel_ms_avg'], tr[0][1] if tr else float('nan'), tr[0][0] if tr else 0))
+tr = [(r[1], r[3] / 1e6, r[9]) for r in rows if r[0].startswith('void ' + k + '(')]
+tr.sort(reverse=True)       # the headline configuration is the one with the most launches (pre-warm + warm-up + timed steps)
+agree = {'raw_run': 'gpurun_out/round_' + tag, 'libginsim_sha256': sha, 'kernel': k,
+         'hip_events_ms_unprofiled_bench': bench['roofline']['kernel_ms_avg']}
+if tr:
+    # the TIMED launches are the last `steps` of that grid size; the same command's own HIP-event average (it ran under the
+    # profiler: prof_trace.json) is the number the trace must agree with -- the un-profiled bench.json runs a few % faster
+    durs = [r[0] / 1e6 for r in con.execute("select end - start from kernels where name like ? and grid_x = ? order by start",
+                                            ('void ' + k + '(%', tr[0][2]))]
+    steps = bench['steps']
+    agree.update({'trace_launches': len(durs), 'trace_ms_avg_all': sum(durs) / len(durs), 'trace_ms_avg_timed_steps': sum(durs[-steps:]) / len(durs[-steps:])})
+    try:
+        prof_line = [l for l in open(os.path.join(SRC, 'prof_trace.json')).read().splitlines() if l.startswith('{')][-1]
+        agree['hip_events_ms_same_profiled_command'] = json.loads(prof_line)['roofline']['kernel_ms_avg']
+    except (OSError, IndexError, ValueError, KeyError):
+        pass
+with open(os.path.join(DST, tag + '_headline_kernel_agreement.json'), 'w') as f:
+    json.dump(agree, f, indent=1)
+print(json.dumps(agree))
 
 con = db('prof_allan')
 if con:
