@@ -324,7 +324,7 @@ def leg_sim_e2e(workloads):
         ini[0:2] *= np.pi / 180
         ini[6:9] *= np.pi / 180
         best = None
-        for rep in range(2):                         # second pass: scratch allocations and the library are warm
+        for rep in range(3):                         # later passes: scratch allocations, the allocator and the library are warm
             imu = imu_model.IMU(accuracy='mid-accuracy', axis=axis, gps=gps)
             t0 = time.perf_counter()
             sim = ins_sim.Sim([fs, fs_gps, 0.0], csv, ref_frame=rf, imu=imu, mode=None, env=None,

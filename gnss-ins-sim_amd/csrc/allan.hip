@@ -497,24 +497,8 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ partial
 // passes of its own level(s) at the same time -- wavefront w level w, wavefront 2 also the tiny fourth one.  (One wavefront
 // doing the levels one after the other, each producing the next, took 30 us for 1440 / 144 / 14 entries.)
 constexpr int kTailWaves = 3;
-// Completion is signalled through memory, not through the stream: the last workgroup to finish (a device counter) releases
-// `seq` into a word of page-locked, host-coherent memory next to the sums, which the host polls -- the call returns a few
-// microseconds after the last store instead of after a stream synchronisation (15-40 us on these boxes).
-__device__ __forceinline__ void signal_done(uint32_t* __restrict__ counter, uint64_t* __restrict__ flag, uint64_t seq) {
-    __syncthreads();                                    // every wavefront of this workgroup has issued its stores
-    if (threadIdx.x == 0) {
-        __threadfence_system();                         // ... and they are visible to the host before the count moves
-        if (atomicAdd(counter, 1u) == gridDim.x - 1) {
-            *counter = 0;                               // ready for the next call on this stream
-            __threadfence_system();
-            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
 __global__ void __launch_bounds__(64 * kTailWaves) allan_tail_kernel(const double* __restrict__ in, const double* __restrict__ partial,
-                                                                     double* __restrict__ sums, const AllanTail t, const AllanFold f,
-                                                                     uint32_t* __restrict__ counter, uint64_t* __restrict__ flag, uint64_t seq) {
+                                                                     double* __restrict__ sums, const AllanTail t, const AllanFold f) {
     __shared__ __attribute__((aligned(16))) double stage[kTailWaves][kStage];
     __shared__ double lev_store[256 + 32 + 8];          // entries of the second, third and fourth tail level (<= 252, 25, 2)
     auto lev = [&](int l) -> double* { return lev_store + (l == 0 ? 0 : (l == 1 ? 256 : 288)); };
@@ -522,11 +506,9 @@ __global__ void __launch_bounds__(64 * kTailWaves) allan_tail_kernel(const doubl
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t ntail = t.nlevels > 0 ? t.nseries : 0;
     if ((int64_t)blockIdx.x >= ntail) {
-        if (wave == 0) {
-            const int64_t b = (int64_t)blockIdx.x - ntail;
-            fold_partials(partial, sums, f, b % t.nseries, (int)(b / t.nseries), t.nseries);
-        }
-        signal_done(counter, flag, seq);
+        if (wave != 0) return;
+        const int64_t b = (int64_t)blockIdx.x - ntail;
+        fold_partials(partial, sums, f, b % t.nseries, (int)(b / t.nseries), t.nseries);
         return;
     }
     const int64_t s = blockIdx.x;
@@ -570,7 +552,6 @@ __global__ void __launch_bounds__(64 * kTailWaves) allan_tail_kernel(const doubl
             if (lane == 0) sums[((int64_t)(t.first + l) * t.nseries + s) * 9 + j] = a;
         }
     }
-    signal_done(counter, flag, seq);
 }
 
 int allan_parts(const AllanLevel& lv) {
@@ -598,10 +579,9 @@ hipError_t launch_allan_pair(const double* in, double* out, double* partial, con
 }
 
 hipError_t launch_allan_finish(const double* in, const double* partial, double* sums, const AllanTail& t, const AllanFold& f,
-                               int64_t nseries, uint32_t* counter, uint64_t* flag, uint64_t seq, hipStream_t st) {
+                               int64_t nseries, hipStream_t st) {
     const int64_t blocks = (t.nlevels > 0 ? nseries : 0) + nseries * f.nlevels;
-    if (blocks > 0) hipLaunchKernelGGL(allan_tail_kernel, dim3((unsigned)blocks), dim3(64 * kTailWaves), 0, st, in, partial, sums, t, f,
-                                       counter, flag, seq);
+    if (blocks > 0) hipLaunchKernelGGL(allan_tail_kernel, dim3((unsigned)blocks), dim3(64 * kTailWaves), 0, st, in, partial, sums, t, f);
     return hipGetLastError();
 }
 

@@ -40,8 +40,7 @@ int allan_pair_parts(const AllanLevel& lv);
 hipError_t launch_allan_pair(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries, hipStream_t st);
 // ONE launch finishes the call: workgroups 0 .. nseries-1 run the levels that fit a chunk, the others fold the partial records
 // of the levels before (either part may be empty)
-// completion: the last workgroup zeroes *counter (device) and releases seq into *flag (host-coherent page-locked memory)
 hipError_t launch_allan_finish(const double* in, const double* partial, double* sums, const AllanTail& t, const AllanFold& f,
-                               int64_t nseries, uint32_t* counter, uint64_t* flag, uint64_t seq, hipStream_t st);
+                               int64_t nseries, hipStream_t st);
 
 }  // namespace ginsim

@@ -5,7 +5,6 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
-#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,9 +65,6 @@ struct ginsim_ctx {
     size_t ws_bytes[4] = {0, 0, 0, 0};
     double* allan_host = nullptr;                         // pinned host memory the Allan kernels write their sums into
     size_t allan_host_doubles = 0;
-    uint64_t* allan_flag = nullptr;                       // host-coherent word the finishing launch releases its sequence number into
-    uint32_t* allan_counter = nullptr;                    // device: workgroups of the finishing launch that are done
-    uint64_t allan_seq = 0;
     ginsim::Comm* comm = nullptr;                         // RCCL communicator of this rank (ginsim_comm_init), or nullptr
     double* comm_recv = nullptr;                          // device [8 slots][nranks][28]: the gathered records
     ginsim_stats* comm_host = nullptr;                    // pinned host copy of the same
@@ -176,13 +172,11 @@ int ginsim_destroy(ginsim_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->stat_slots) (void)hipHostFree(c->stat_slots);
     if (c->allan_host) (void)hipHostFree(c->allan_host);
-    if (c->allan_flag) (void)hipHostFree(c->allan_flag);
     if (c->comm) ginsim::comm_destroy(c->comm);
     if (c->comm_recv) (void)hipFree(c->comm_recv);
     if (c->comm_host) (void)hipHostFree(c->comm_host);
     for (hipEvent_t e : c->comm_ev)
         if (e) (void)hipEventDestroy(e);
-    if (c->allan_counter) (void)hipFree(c->allan_counter);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return GINSIM_OK;
@@ -750,30 +744,11 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
     const size_t nsums = (size_t)9 * nseries * levels;
     if (c->allan_host_doubles < nsums) {
         if (c->allan_host) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipHostFree(c->allan_host)); c->allan_host = nullptr; c->allan_host_doubles = 0; }
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->allan_host), sizeof(double) * (nsums + nsums / 4 + 64), hipHostMallocCoherent));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->allan_host), sizeof(double) * (nsums + nsums / 4 + 64), hipHostMallocDefault));
         c->allan_host_doubles = nsums + nsums / 4 + 64;
     }
-    if (!c->allan_flag) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->allan_flag), 64, hipHostMallocCoherent));
-        *c->allan_flag = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->allan_counter), 64));
-        HIP_TRY(hipMemsetAsync(c->allan_counter, 0, 64, c->stream));
-    }
-    const uint64_t seq = ++c->allan_seq;
-    HIP_TRY(launch_allan_finish(in, partial.d(), c->allan_host, t, fold, nseries, c->allan_counter, c->allan_flag, seq, c->stream));
-    {   // poll the completion word (a few microseconds after the last store); a stream synchronisation only as the safety net
-        static const bool poll = [] { const char* e = getenv("GINSIM_ALLAN_POLL"); return !(e && atoi(e) == 0); }();
-        volatile uint64_t* flag = c->allan_flag;
-        bool done = false;
-        if (poll) {
-            for (long spin = 0; spin < 400000000L; ++spin) {
-                if (*flag == seq) { done = true; break; }
-                __builtin_ia32_pause();
-            }
-        }
-        if (!done) HIP_TRY(hipStreamSynchronize(c->stream));
-        std::atomic_thread_fence(std::memory_order_acquire);
-    }
+    HIP_TRY(launch_allan_finish(in, partial.d(), c->allan_host, t, fold, nseries, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     const double* h = c->allan_host;
     for (int i = 0; i < nt; ++i) {
         const int64_t m = mult[i];
