@@ -132,6 +132,38 @@ def test_fp32_given_data_fixtures(ctx, name):
     ac.free()
 
 
+def test_fp32_given_data_both_plugins_at_other_rates(ctx):
+    """Both plugins' given-data form (FreeIntegration.run(set_of_input) of free_integration.py and free_integration_odo.py) in
+    fp32 at 50 / 200 / 400 Hz, both frames, external gravity / Earth rotation: the kernel equals the float oracle bit for bit."""
+    import ginsim
+    from oracle import c_oracle
+    from test_oracle_golden import _t1_rates_cases
+    bufs = {}
+    for c, tag, rf, ini, erot, plug in _t1_rates_cases():
+        fs, n, R = float(c['fs']), c['gyro'].shape[0], 2
+        key = id(c['gyro'])
+        if key not in bufs:
+            bufs[key] = {'gyro': ctx.upload(np.ascontiguousarray(np.repeat(c['gyro'].T[:, :, None], R, axis=2))),
+                         'accel': ctx.upload(np.ascontiguousarray(np.repeat(c['accel'].T[:, :, None], R, axis=2))),
+                         'odo': ctx.upload(np.ascontiguousarray(np.repeat(c['odo'][:, None], R, axis=1)))}
+        dummy = {'ref_accel': np.zeros((n, 3)), 'ref_gyro': np.zeros((n, 3)), 'ref_att': np.zeros((n, 3)), 'ref_pos': np.zeros((n, 3)),
+                 'ref_vel': np.zeros((n, 3))}
+        given = {'gyro': bufs[key]['gyro'], ('accel' if plug == 'free' else 'odo'): bufs[key]['accel' if plug == 'free' else 'odo']}
+        job = ginsim.MonteCarloJob(ctx, fs, rf, dummy, None, None, ini, runs=R, algos=(plug,), earth_rot=erot, keep_traj=True,
+                                   precision='f32', given=given).run()
+        att, dpos, vel = job.trajectories(plug, [R - 1], displacement=True)
+        o_att, o_dpos, o_vel, _ = c_oracle.free_integration_f32(rf, fs, c['gyro'], c['accel'] if plug == 'free' else None, ini, earth_rot=erot,
+                                                                odo=c['odo'] if plug == 'odo' else None)
+        what = '%s %s %g Hz' % (plug, tag, fs)
+        _bits_equal(att[0], o_att, what + ' att')
+        _bits_equal(dpos[0], o_dpos, what + ' displacement')
+        _bits_equal(vel[0], o_vel, what + ' vel')
+        job.release()
+    for b in bufs.values():
+        for v in b.values():
+            v.free()
+
+
 @pytest.mark.parametrize('R,plain', [(65536, False), (262144, False), (65536, True)])
 def test_fp32_real_launch_sampled_runs(ctx, R, plain):
     """BASELINE config 5's launch at its real sizes, materialised as the bench runs it: runs drawn from the first, middle

@@ -191,3 +191,18 @@ def test_c_f32_sincos_def_is_float_accurate():
             want = np.array([np.float32(np.cos(vf)), np.float32(np.sin(vf))])
             bad += int(abs(float(vv[0, 0]) - float(want[0])) > 6e-8) + int(abs(float(vv[0, 1]) - float(want[1])) > 6e-8)
     assert bad == 0
+
+
+def test_c_f32_both_plugins_at_other_rates():
+    """The float restatement of BOTH plugins' given-data form at 50 / 200 / 400 Hz (1600 samples: 32 / 8 / 4 s) against the
+    reference-executed golden: attitude 2e-6 rad, velocity and position tolerances scaled with the duration (x 3.2 at 32 s)."""
+    from test_oracle_golden import _t1_rates_cases
+    worst = {}
+    for c, tag, rf, ini, erot, plug in _t1_rates_cases():
+        k = c['rows']
+        fs = float(c['fs'])
+        att, dpos, vel, _ = c_oracle.free_integration_f32(rf, fs, c['gyro'], c['accel'] if plug == 'free' else None, ini, earth_rot=erot,
+                                                          odo=c['odo'] if plug == 'odo' else None)
+        scale = max(1.0, 1600.0 / fs / 10.0) ** 2
+        assert_f32_close(att[k], dpos[k], vel[k], ini, rf, c['%s_%s_att' % (plug, tag)], c['%s_%s_pos' % (plug, tag)],
+                         c['%s_%s_vel' % (plug, tag)], what='%s %s %g Hz' % (plug, tag, fs), scale=scale, att_tol=4e-6)
