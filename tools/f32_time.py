@@ -10,6 +10,8 @@ ctx = ginsim.Context(0)
 acc, gyr = workloads.imu_grade('mid-accuracy')
 P = os.environ.get('AB_PREC', 'f32')
 shapes = [(1, 65536, True), (1, 65536, False), (1, 262144, True), (0, 65536, True)]
+if os.environ.get('AB_SHAPES') == 'c4':
+    shapes = [(1, 65536, True), (1, 131072, True), (1, 262144, True), (0, 65536, False)]
 if os.environ.get('AB_SHAPES') == 'c2':
     shapes = shapes[:2]
 out = []
