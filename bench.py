@@ -442,7 +442,7 @@ def main():
         # must agree on the outcome, so the success flags are reduced before anyone relies on it.
         ok = 1.0
         try:
-            distributed.init_abi_comm(ctx, group)
+            distributed.init_abi_comm(ctx, group, device)
         except Exception as e:                                     # noqa: BLE001 -- fall back to the torch exchange, say so
             ok, exchange_note = 0.0, 'abi exchange unavailable on rank %d: %s' % (rank, repr(e)[:160])
         flag = torch.tensor([ok], dtype=torch.float64, device=device)

@@ -57,13 +57,26 @@ def allreduce_stats_end(handle):
     return StatsResult.merge(table.cpu().numpy())
 
 
-def init_abi_comm(ctx, group=None):
+def init_abi_comm(ctx, group=None, device=None):
     """Give `ctx` the library's own RCCL communicator over the ranks of a torch.distributed group: rank 0 draws the unique id
     (ginsim_comm_unique_id), torch.distributed only carries those 128 bytes to the other ranks (bootstrap, outside any timed
-    region); afterwards MonteCarloJob.stats_all_begin / _finish exchange the records on the context's stream without torch."""
+    region); afterwards MonteCarloJob.stats_all_begin / _finish exchange the records on the context's stream without torch.
+    Every rank first checks that it can reach librccl at all and the verdicts are reduced, so that either all ranks enter the
+    collective ncclCommInitRank or all of them raise (a rank that raised alone would leave the others waiting).
+    `device`: where the small verdict tensor lives (cuda:<local_rank> with backend nccl, cpu with gloo)."""
+    import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    box = [ctx.comm_unique_id() if rank == 0 else None]
+    uid, problem = None, None
+    try:
+        uid = ctx.comm_unique_id()              # local call: loads librccl; only rank 0's id is used
+    except Exception as e:                      # noqa: BLE001
+        problem = repr(e)
+    verdict = torch.tensor([0.0 if problem else 1.0], dtype=torch.float64, device=device)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+    if float(verdict.item()) < 1.0:
+        raise RuntimeError('librccl is not usable on every rank%s' % (': ' + problem if problem else ''))
+    box = [uid if rank == 0 else None]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     ctx.comm_init(world, rank, box[0])
     return world, rank

@@ -168,6 +168,23 @@ h = distributed.allreduce_stats_begin(part, dist.group.WORLD, torch.device('cpu'
 m2 = distributed.allreduce_stats_end(h)
 np.testing.assert_array_equal(m2.pack(), m.pack())
 assert distributed.allreduce_stats_end(distributed.allreduce_stats_begin(part)) is part      # single process: identity
+# bootstrap of the library's own communicator: a rank that cannot reach librccl must make EVERY rank raise before any of them
+# enters the collective initialisation (nobody is left waiting); with all ranks fine the id of rank 0 reaches every rank
+class FakeCtx(object):
+    def __init__(self, broken): self.broken, self.got = broken, None
+    def comm_unique_id(self):
+        if self.broken: raise OSError('librccl not found')
+        return bytes([rank]) * 128
+    def comm_init(self, nranks, r, uid): self.got = (nranks, r, uid)
+bad = FakeCtx(broken=(rank == 1))
+try:
+    distributed.init_abi_comm(bad, dist.group.WORLD, torch.device('cpu'))
+    raise SystemExit('init_abi_comm did not raise on rank %%d' %% rank)
+except RuntimeError as e:
+    assert 'not usable on every rank' in str(e) and bad.got is None
+good = FakeCtx(broken=False)
+assert distributed.init_abi_comm(good, dist.group.WORLD, torch.device('cpu')) == (world, rank)
+assert good.got == (world, rank, bytes([0]) * 128)
 dist.barrier()
 dist.destroy_process_group()
 print('rank', rank, 'ok')
