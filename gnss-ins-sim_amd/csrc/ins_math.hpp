@@ -111,6 +111,15 @@ struct Att {
     // re-evaluated exactly when `resync` is set (every kTrigResync steps, wave-uniform), when the pitch folds
     // over +-pi/2, or when a step exceeds 0.25 rad.  +-2pi wraps leave the trig untouched.  A lane that steps by no
     // more than 2^-6 rad uses the three-term series.
+    // EASY = true (the one-wavefront-per-run-group kernels in generate mode): ONE wave-uniform test in front of everything that is rare.  A lane
+    // is "easy" when it needs neither the exact trig, nor the pitch fold, nor a +-2 pi wrap, and steps by no more than 2^-6 rad
+    // -- every sample of a vehicle profile at >= 100 Hz; when all lanes of the wavefront are easy the step is three short
+    // rotations and no exec-mask juggling (the per-lane branches below are ~45 scalar instructions per step).  The general
+    // path does, lane by lane, exactly the same operations on an easy lane, so a run's bits do not depend on its wavefront
+    // neighbours.  Measured (round 3): C3-shaped launches -4.8 % (end-point only) / -2.8 % (online statistics); the given-sensors
+    // kernel, which waits for memory, does not gain when it materialises (+2 %) and stays as it was; the
+    // wave-specialised kernels do not gain (their consumer sits at the 168-register limit: 12-52 B of scratch with it).
+    template <bool EASY = false>
     GINSIM_HD void step(const Vec3& w, double dt, bool resync, const MathConsts& mk) {
         const double q = w.z * cr + w.y * sr;
         const double icp = rcp_n1(cp);      // 2^-46 relative on a rate that is multiplied by dt: far below the state's ulp
@@ -122,6 +131,16 @@ struct Att {
         double r = rol + dr;
         const bool fold = (p > kHalfPi) || (p < -kHalfPi);
         const double big = fmax(fabs(dy), fmax(fabs(dp), fabs(dr)));
+        if (EASY) {
+            const bool easy = !resync && !fold && (big <= 0x1.0p-6) && !(y > kPi) && !(y < -kPi) && !(r > kPi) && !(r < -kPi);
+            if (__builtin_amdgcn_ballot_w64(!easy) == 0) {
+                rotate_sincos_small(dy, sy, cy, mk);
+                rotate_sincos_small(dp, sp, cp, mk);
+                rotate_sincos_small(dr, sr, cr, mk);
+                yaw = y; pit = p; rol = r;
+                return;
+            }
+        }
         if (resync || fold || !(big <= 0.25)) {
             if (p > kHalfPi) {
                 p = kPi - p; y += kPi; r += kPi;

@@ -68,7 +68,7 @@ __device__ __forceinline__ void nav_init(Nav& s, const double* __restrict__ ini,
 
 // One time step.  ODO == false: free_integration.py:104-116 (RF 1) / :134-172 (RF 0);
 //                 ODO == true : free_integration_odo.py:96-105 (RF 1) / :118-152 (RF 0).
-template <int RF, bool ODO>
+template <int RF, bool ODO, bool EASY = false>
 __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& accel, double odo, double dt,
                                          int earth_rot, bool resync, const MathConsts& mk) {
     if (RF == 1) {
@@ -80,7 +80,7 @@ __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& a
             s.vb.y += (accel.y + gb.y * s.g) * dt - wxv.y * dt;
             s.vb.z += (accel.z + gb.z * s.g) * dt - wxv.z * dt;
         }
-        s.att.step(gyro, dt, resync, mk);
+        s.att.template step<EASY>(gyro, dt, resync, mk);
         if (ODO) {
             const Vec3 f = s.att.fwd_in_nav();
             s.vel = Vec3{f.x * odo, f.y * odo, f.z * odo};
@@ -108,13 +108,14 @@ __device__ __forceinline__ void nav_step(Nav& s, const Vec3& gyro, const Vec3& a
             const Vec3 cor = cross3(Vec3{2.0 * w_ie.x + w_en.x, 2.0 * w_ie.y + w_en.y, 2.0 * w_ie.z + w_en.z}, v);
             v_new = Vec3{v.x + (an.x - cor.x) * dt, v.y + (an.y - cor.y) * dt, v.z + (an.z + g - cor.z) * dt};
         }
-        s.att.step(w_nb, dt, resync, mk);
+        s.att.template step<EASY>(w_nb, dt, resync, mk);
         if (ODO) {
             const Vec3 f = s.att.fwd_in_nav();
             v_new = Vec3{f.x * odo, f.y * odo, f.z * odo};
         }
         const double dlat = v.x * irm * dt;
-        if (resync || !(fabs(dlat) <= 0.25)) sincos(s.pos.x + dlat, &s.sl, &s.cl);
+        if (EASY && __builtin_amdgcn_ballot_w64(resync || !(fabs(dlat) <= 0x1.0p-6)) == 0) rotate_sincos_small(dlat, s.sl, s.cl, mk);
+        else if (resync || !(fabs(dlat) <= 0.25)) sincos(s.pos.x + dlat, &s.sl, &s.cl);
         else if (fabs(dlat) <= 0x1.0p-6) rotate_sincos_small(dlat, s.sl, s.cl, mk);      // per lane: see Att::step
         else rotate_sincos(dlat, s.sl, s.cl, mk);
         s.pos.x += dlat;
@@ -391,11 +392,11 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
         }
         const bool resync = ((j + 1) & (kTrigResync - 1)) == 0;
         if (FREE) {
-            nav_step<RF, false>(fi, gyr, acc, 0.0, dt, a.earth_rot, resync, mk);
+            nav_step<RF, false, !GIVEN>(fi, gyr, acc, 0.0, dt, a.earth_rot, resync, mk);
             if (a.out_traj[0]) store9(a.out_traj[0], plane, off + runs, fi);
         }
         if (ODO) {
-            nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot, resync, mk);
+            nav_step<RF, true, !GIVEN>(od, gyr, acc, odo, dt, a.earth_rot, resync, mk);
             if (a.out_traj[1]) store9(a.out_traj[1], plane, off + runs, od);
         }
         if (PS) {
