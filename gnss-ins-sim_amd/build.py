@@ -29,7 +29,10 @@ SOURCES = [
     ('mc_kernel.hip', ['--offload-arch=' + ARCH, '-mllvm', '-disable-machine-licm', '-ffp-contract=on']),
     # the fp32 kernel is DEFINED operation by operation (the float oracle repeats it to the bit): no contraction at all,
     # fused multiply-adds only where the source spells __builtin_fmaf
-    ('mc_kernel_f32.hip', ['--offload-arch=' + ARCH, '-mllvm', '-disable-machine-licm', '-ffp-contract=off']),
+    # no SLP vectorisation either: it packed the consumer's float arithmetic into v_pk_*_f32 pairs (a 4-cycle-class
+    # instruction) and paid for the pairing with v_mov: 53 packed + 38 moves of 152 VALU on the common path;
+    # scalar, the same step is 169 plain VALU and the launch 15 % faster (nothing kept 0.685 -> 0.584 ms), 132 -> 120 VGPRs
+    ('mc_kernel_f32.hip', ['--offload-arch=' + ARCH, '-mllvm', '-disable-machine-licm', '-ffp-contract=off', '-fno-slp-vectorize']),
     ('stats.hip', ['--offload-arch=' + ARCH]),
     ('allan.hip', ['--offload-arch=' + ARCH]),
     ('ginsim_api.hip', ['--offload-arch=' + ARCH]),

@@ -138,10 +138,12 @@ struct Att {
         const float dr = fm(q, sp * icp, w.x) * dt;
         yaw.add(dy); pit.add(dp); rol.add(dr);
         const float big = fmaxf(fabsf(dy), fmaxf(fabsf(dp), fabsf(dr)));
-        // ONE wave-uniform branch for everything that is rare (exact trig every kTrigResync steps, pitch over the pole, yaw /
-        // roll over +-pi, a step > 0.25 rad): when no lane of the wavefront needs it, the step is three rotations and nothing
-        // else -- no per-lane exec juggling on the common path.  The general path does the same operations on a lane that
-        // did not need it, so a run's bits do not depend on its wavefront neighbours.
+        // The common step is three rotations of the cached sines / cosines and nothing else.  ONE wave-uniform branch, taken
+        // AFTER them, for everything that is rare (exact trig every kTrigResync steps, pitch over the pole, yaw / roll over
+        // +-pi, a step > 0.25 rad): it overwrites what the rotations left, so the common path carries no copies to a merge
+        // point.  A lane that did not need the branch keeps its rotated values inside it: a run's bits do not depend on
+        // its wavefront neighbours.
+        rotate(dy, sy, cy); rotate(dp, sp, cp); rotate(dr, sr, cr);
         const bool rare = do_resync || !(fabsf(pit.v) <= kHalfPiF) || !(fabsf(yaw.v) <= kPiF) || !(fabsf(rol.v) <= kPiF) || !(big <= 0.25f);
         if (__builtin_amdgcn_ballot_w64(rare) != 0) {
             const bool fold = (pit.v > kHalfPiF) || (pit.v < -kHalfPiF);
@@ -151,13 +153,7 @@ struct Att {
             }
             if (yaw.v > kPiF) { yaw.add(-kTwoPiHi); yaw.add(-kTwoPiLo); } else if (yaw.v < -kPiF) { yaw.add(kTwoPiHi); yaw.add(kTwoPiLo); }
             if (rol.v > kPiF) { rol.add(-kTwoPiHi); rol.add(-kTwoPiLo); } else if (rol.v < -kPiF) { rol.add(kTwoPiHi); rol.add(kTwoPiLo); }
-            if (do_resync || fold || !(big <= 0.25f)) {
-                resync();
-            } else {
-                rotate(dy, sy, cy); rotate(dp, sp, cp); rotate(dr, sr, cr);
-            }
-        } else {
-            rotate(dy, sy, cy); rotate(dp, sp, cp); rotate(dr, sr, cr);
+            if (do_resync || fold || !(big <= 0.25f)) resync();
         }
     }
 };
@@ -445,7 +441,9 @@ struct Planes3 {            // three consecutive [n][runs] float planes behind o
     F32_FM void store(uint32_t voff, uint32_t pl, float x, float y, float z) const {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, voff, 0, 2);         // aux 2 = nt
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs, voff, pl, 2);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), rs, voff, 2 * pl, 2);
+        // the doubled offset is made a scalar here: left to the compiler it ended up in a VGPR and every third store in a
+        // nine-instruction waterfall loop (v_readfirstlane / v_cmp / s_and_saveexec ...), five of them per step
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), rs, voff, __builtin_amdgcn_readfirstlane(2 * pl), 2);
     }
 };
 
@@ -539,7 +537,7 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const gi
     Planes3 o_acc, o_gyr, o_odo;
     TrajOut o_fi, o_od;
     const int64_t plane = (int64_t)n * runs;
-    const uint32_t pl = (uint32_t)plane * 4u, step_bytes = (uint32_t)runs * 4u;
+    const uint32_t pl = __builtin_amdgcn_readfirstlane((uint32_t)plane * 4u), step_bytes = (uint32_t)runs * 4u;
     uint32_t voff = (uint32_t)r * 4u;                   // byte offset of (sample j, run r) inside a plane
     if (KEEP) {
         o_acc.init(reinterpret_cast<float*>(a.out_accel));
@@ -552,37 +550,48 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const gi
             if (ODO) o_od.store<RF>(voff, pl, od);
         }
     }
+    // sensor outputs of sample j (kept or not) from the ring's normals at `zb`
+    auto sensors = [&](uint32_t j, const float* zb, V3& acc, V3& gyr, float& odo) {
+        const uniform_f32_ptr tj = truth + 8 * (uint64_t)j;
+        const double ta[3] = {(double)tj[0], (double)tj[1], (double)tj[2]};      // widened and narrowed again: exact
+        const double tg[3] = {(double)tj[3], (double)tj[4], (double)tj[5]};
+        float p0[6], p1[6];                   // z0 / z1 of streams 0..5
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            p0[k] = zb[(2 * k) * kSplitRunsF];
+            p1[k] = zb[(2 * k + 1) * kSplitRunsF];
+        }
+        const float zda[3] = {p0[0], p1[0], p0[1]}, zwa[3] = {p1[1], p0[2], p1[2]};
+        const float zdg[3] = {p0[3], p1[3], p0[4]}, zwg[3] = {p1[4], p0[5], p1[5]};
+        acc = sense3<WD>(ta, ma, da, zda, zwa);
+        gyr = sense3<WD>(tg, mg, dg, zdg, zwg);
+        if (KEEP) {
+            o_acc.store(voff, pl, acc.x, acc.y, acc.z);
+            o_gyr.store(voff, pl, gyr.x, gyr.y, gyr.z);
+        }
+        odo = 0.f;
+        if (ODO) {
+            odo = fm(odo_stdv, odo_normal(key, j, tab), odo_scale * tj[6]);
+            if (KEEP) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(odo), o_odo.rs, voff, 0, 2);
+        }
+    };
+    // samples 0 .. n-2 have a mechanisation step behind them: a COUNTED inner loop without a way out in the middle of its
+    // body (with the old `if (j == n - 1) break` after the sensors the loop's merge block took the un-stepped state from
+    // one side and the stepped state from the other, and the register allocator settled that with fourteen v_mov on the
+    // hot side).  The last sample, sensor output only, follows the loops: its normals are still in the ring.
+    const uint32_t n_steps = n - 1;
     for (uint32_t i = 0; i <= ntiles; ++i) {
         if (i >= 1 && active && !(exp_flags & 2)) {
             const float* stage = zringf + ((i - 1) & 1) * (kSplitTileF * kStepFloats);
+            const uint32_t j0 = (i - 1) * kSplitTileF;
+            const uint32_t left = j0 < n_steps ? n_steps - j0 : 0u;
+            const int cnt = (int)(left < (uint32_t)kSplitTileF ? left : (uint32_t)kSplitTileF);
 #pragma unroll 1
-            for (int t = 0; t < kSplitTileF; ++t) {
-                const uint32_t j = (i - 1) * kSplitTileF + t;
-                if (j >= n_noise) break;
-                const uniform_f32_ptr tj = truth + 8 * (uint64_t)j;
-                const double ta[3] = {(double)tj[0], (double)tj[1], (double)tj[2]};      // widened and narrowed again: exact
-                const double tg[3] = {(double)tj[3], (double)tj[4], (double)tj[5]};
-                const float* zb = stage + t * kStepFloats + lane;
-                float p0[6], p1[6];                   // z0 / z1 of streams 0..5
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    p0[k] = zb[(2 * k) * kSplitRunsF];
-                    p1[k] = zb[(2 * k + 1) * kSplitRunsF];
-                }
-                const float zda[3] = {p0[0], p1[0], p0[1]}, zwa[3] = {p1[1], p0[2], p1[2]};
-                const float zdg[3] = {p0[3], p1[3], p0[4]}, zwg[3] = {p1[4], p0[5], p1[5]};
-                const V3 acc = sense3<WD>(ta, ma, da, zda, zwa);
-                const V3 gyr = sense3<WD>(tg, mg, dg, zdg, zwg);
-                if (KEEP) {
-                    o_acc.store(voff, pl, acc.x, acc.y, acc.z);
-                    o_gyr.store(voff, pl, gyr.x, gyr.y, gyr.z);
-                }
-                float odo = 0.f;
-                if (ODO) {
-                    odo = fm(odo_stdv, odo_normal(key, j, tab), odo_scale * tj[6]);
-                    if (KEEP) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(odo), o_odo.rs, voff, 0, 2);
-                }
-                if (j == n - 1) break;
+            for (int t = 0; t < cnt; ++t) {
+                const uint32_t j = j0 + t;
+                V3 acc, gyr;
+                float odo;
+                sensors(j, stage + t * kStepFloats + lane, acc, gyr, odo);
                 voff += step_bytes;
                 const bool resync = ((j + 1) & (kTrigResync - 1)) == 0;
                 if (FREE) {
@@ -597,6 +606,11 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const gi
         }
         __syncthreads();
     }
+    if (KEEP && active && !(exp_flags & 2)) {
+        V3 acc, gyr;
+        float odo;
+        sensors(n_steps, zringf + ((n_steps / kSplitTileF) & 1) * (kSplitTileF * kStepFloats) + (n_steps % kSplitTileF) * kStepFloats + lane, acc, gyr, odo);
+    }
     if (active) {
         if (FREE && a.out_end[0]) store_end<RF>(a.out_end[0], runs, r, fi);
         if (ODO && a.out_end[1]) store_end<RF>(a.out_end[1], runs, r, od);
@@ -610,9 +624,9 @@ static int split_policy_f32() {
     return v;
 }
 
-// producer groups of the wave-specialised fp32 kernel: two (three wavefronts per SIMD) unless GINSIM_SPLIT_PROD=1
+// producer groups of the wave-specialised fp32 kernel asked for by GINSIM_SPLIT_PROD (1..3), 0: the default of the variant
 static int split_prod_f32() {
-    static const int v = [] { const char* e = getenv("GINSIM_SPLIT_PROD"); return e && atoi(e) == 1 ? 1 : 2; }();
+    static const int v = [] { const char* e = getenv("GINSIM_SPLIT_PROD"); const int k = e ? atoi(e) : 0; return k >= 1 && k <= 3 ? k : 0; }();
     return v;
 }
 
@@ -662,10 +676,11 @@ static hipError_t launch3_f32(const ginsim_mc_params& p, const float* truth32, h
     const int64_t waves = (p.runs + 63) / 64;
     if constexpr ((ALGOS & GINSIM_ALGO_FREE) != 0) {
         if (mc_variant_f32(p)) {
-            // two producer groups (three wavefronts per SIMD, <= 168 registers) where the kernel fits without spilling: one
-            // algorithm with the simple sensor model -- every standard IMU grade, config 5's launch
-            constexpr int PROD = (ALGOS == GINSIM_ALGO_FREE && !WD) ? 2 : 1;
-            const int prod = PROD == 2 ? split_prod_f32() : 1;
+            // producer groups: three (four wavefronts per SIMD, <= 128 registers) with one algorithm, two (<= 168) with both --
+            // one where both algorithms and the per-sample drift model together would spill at that bound
+            constexpr int MAXP = ALGOS == GINSIM_ALGO_FREE ? 3 : (WD ? 1 : 2);
+            const int want = split_prod_f32();
+            const int prod = want == 0 || want > MAXP ? MAXP : want;
             const bool keep = keep_mode_f32(p) == 1;
             if (name) {
                 snprintf(name, cap, "ginsim::f32::mc_kernel_f32_split<%d, %d, %s, %d, %s>", RF, ALGOS, WD ? "true" : "false", prod,
@@ -674,8 +689,14 @@ static hipError_t launch3_f32(const ginsim_mc_params& p, const float* truth32, h
             }
             hipLaunchKernelGGL(f32::truth_f32_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, p.ref_accel, p.ref_gyro,
                                p.ref_odo, p.n, const_cast<float*>(truth32));
-            if (prod == PROD)
-                return keep ? launch_split_f32<RF, ALGOS, WD, PROD, true>(p, truth32, stream) : launch_split_f32<RF, ALGOS, WD, PROD, false>(p, truth32, stream);
+            if constexpr (MAXP == 3) {
+                if (prod == 3)
+                    return keep ? launch_split_f32<RF, ALGOS, WD, 3, true>(p, truth32, stream) : launch_split_f32<RF, ALGOS, WD, 3, false>(p, truth32, stream);
+            }
+            if constexpr (MAXP >= 2) {
+                if (prod == 2)
+                    return keep ? launch_split_f32<RF, ALGOS, WD, 2, true>(p, truth32, stream) : launch_split_f32<RF, ALGOS, WD, 2, false>(p, truth32, stream);
+            }
             return keep ? launch_split_f32<RF, ALGOS, WD, 1, true>(p, truth32, stream) : launch_split_f32<RF, ALGOS, WD, 1, false>(p, truth32, stream);
         }
     }

@@ -236,6 +236,7 @@ def test_hot_kernels_keep_two_wavefronts_per_simd():
             elif cur is not None and v.strip():
                 cur[k.split('[')[0].strip()] = v.strip()
     checked = 0
+    split_seen = {}
     for name, r in kernels.items():         # Itanium-mangled: ...9mc_kernelILi<rf>ELi<algos>ELb<given>ELb<general>EEEv...
         occ, agpr, scratch = int(r['Occupancy']), int(r['AGPRs']), int(r['ScratchSize'])
         hot = any(t in name for t in ('9mc_kernelI', '15mc_kernel_splitI', '13mc_kernel_f32I', '19mc_kernel_f32_splitI',
@@ -245,11 +246,19 @@ def test_hot_kernels_keep_two_wavefronts_per_simd():
         checked += 1
         two_algos = 'ILi0ELi3E' in name or 'ILi1ELi3E' in name
         assert occ >= 2, '%s: %d wavefront(s) per SIMD' % (name, occ)
-        if ('15mc_kernel_splitI' in name or '19mc_kernel_f32_splitI' in name) and name.split('EEEv')[0].endswith('ELi2'):     # 768 threads: three per SIMD
-            assert occ >= 3, '%s: %d wavefront(s) per SIMD' % (name, occ)
+        if '15mc_kernel_splitI' in name or '19mc_kernel_f32_splitI' in name:
+            # <RF, ALGOS, WD, PROD, KEEP>: 256 consumer + PROD x 256 producer threads, 1 + PROD wavefronts per SIMD
+            m = re.search(r'ELi(\d)ELb[01]EEEv', name)
+            assert m, name
+            prod = int(m.group(1))
+            split_seen[prod] = split_seen.get(prod, 0) + 1
+            assert occ >= 1 + prod, '%s: %d wavefront(s) per SIMD' % (name, occ)
+            if prod == 3:
+                assert scratch == 0, '%s: %d bytes of scratch' % (name, scratch)
         assert agpr == 0, '%s parks %d registers in AGPRs' % (name, agpr)
         assert scratch <= (128 if two_algos else 32), '%s: %d bytes of scratch per lane' % (name, scratch)
     assert checked >= 40, checked
+    assert split_seen.get(2, 0) >= 8 and split_seen.get(3, 0) >= 8, split_seen
 
 
 def test_native_pathgen_random_profiles_vs_reference():
