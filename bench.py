@@ -611,8 +611,8 @@ def main():
             'prewarm_ms': prewarm_ms,
             'roofline': roofline(alg_bytes, kern_avg_ms, kname, (traffic or {}).get(kname, {}).get('hbm_bytes_per_launch'),
                                  traffic_source=traffic_source,
-                                 note='writes exactly its algorithmic bytes; limited by fp64/integer VALU issue at the power-capped clock, '
-                                      'see DESIGN.md section 4.1'),
+                                 note='writes exactly its algorithmic bytes; store-bound: a pure non-temporal fill of the same 15-plane '
+                                      'pattern takes ~1.15 ms, see DESIGN.md section 4.1'),
             'result': {'att_std_deg': (merged.std[:3] * r2d).tolist(), 'vel_std_mps': merged.std[6:9].tolist(),
                        'runs': merged.count},
         }

@@ -21,7 +21,8 @@ d = json.load(open("$OUT/bench.json"))
 print("bench: %.4g %s, %.3f ms/step, kernel %.3f ms, frac %.3f, traffic %s" % (d["value"], d["unit"], d["ms_per_step"],
       d["roofline"]["kernel_ms_avg"], d["roofline"]["frac"], d["roofline"]["traffic"]))
 for l in d.get("configs", []):
-    print("  leg %-22s kernel %.3f ms  frac %.3f" % (l["name"], l["roofline"]["kernel_ms_avg"], l["roofline"]["frac"]))
+    if "roofline" in l:
+        print("  leg %-22s kernel %.3f ms  frac %.3f" % (l["name"], l["roofline"]["kernel_ms_avg"], l["roofline"]["frac"]))
 PY
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py --pmc-child"

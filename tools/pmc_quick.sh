@@ -10,6 +10,6 @@ dbs = [os.path.join(r, f) for r, _, fs in os.walk("$OUT") for f in fs if f.endsw
 con = sqlite3.connect(dbs[0])
 rows = con.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name").fetchall()
 for k, c, n, v in rows:
-    if 'mc_kernel' in k:
+    if 'mc_kernel' in k or 'allan' in k:
         print('%-60s %-24s n=%d avg=%.4g' % (k.replace('void ginsim::', '').split('(')[0][:60], c, n, v))
 PY
