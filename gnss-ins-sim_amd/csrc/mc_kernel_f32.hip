@@ -586,8 +586,9 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const gi
             const uint32_t j0 = (i - 1) * kSplitTileF;
             const uint32_t left = j0 < n_steps ? n_steps - j0 : 0u;
             const int cnt = (int)(left < (uint32_t)kSplitTileF ? left : (uint32_t)kSplitTileF);
-#pragma unroll 1
-            for (int t = 0; t < cnt; ++t) {
+            // two steps per trip: the loop-carried state of the second step lands where the first step of the next trip expects
+            // it, which the allocator did not manage with one step per trip (sixteen v_mov at the back edge)
+            auto one_step = [&](int t) {
                 const uint32_t j = j0 + t;
                 V3 acc, gyr;
                 float odo;
@@ -602,6 +603,18 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const gi
                     nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot, resync);
                     if (KEEP) o_od.store<RF>(voff, pl, od);
                 }
+            };
+            int t = 0;
+            if constexpr (!(FREE && ODO)) {         // with both algorithms the doubled body would spill
+#pragma unroll 1
+                for (; t + 1 < cnt; t += 2) {
+                    one_step(t);
+                    one_step(t + 1);
+                }
+                if (t < cnt) one_step(t);
+            } else {
+#pragma unroll 1
+                for (; t < cnt; ++t) one_step(t);
             }
         }
         __syncthreads();
@@ -677,8 +690,8 @@ static hipError_t launch3_f32(const ginsim_mc_params& p, const float* truth32, h
     if constexpr ((ALGOS & GINSIM_ALGO_FREE) != 0) {
         if (mc_variant_f32(p)) {
             // producer groups: three (four wavefronts per SIMD, <= 128 registers) with one algorithm, two (<= 168) with both --
-            // one where both algorithms and the per-sample drift model together would spill at that bound
-            constexpr int MAXP = ALGOS == GINSIM_ALGO_FREE ? 3 : (WD ? 1 : 2);
+            // one group fewer with the per-sample drift model, which would spill at that bound
+            constexpr int MAXP = ALGOS == GINSIM_ALGO_FREE ? (WD ? 2 : 3) : (WD ? 1 : 2);
             const int want = split_prod_f32();
             const int prod = want == 0 || want > MAXP ? MAXP : want;
             const bool keep = keep_mode_f32(p) == 1;
