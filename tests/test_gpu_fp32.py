@@ -101,6 +101,49 @@ def test_fp32_kernel_equals_float_oracle_and_reference_t3(ctx, name, plain):
     job.release()
 
 
+@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_high_odo_rf0'])
+def test_fp32_short_series_every_tile_boundary(ctx, name):
+    """The wave-specialised kernel takes the steps in tiles of six, two per loop trip, and the last sample -- sensor output
+    only -- after its loops from the ring: series of 2 .. 20 samples put the end of the series on every position of a tile
+    (n - 1 a multiple of six, an odd and an even number of steps in the last tile, a single step, a single tile), kept and
+    not kept, against the float oracle bit for bit."""
+    import ginsim
+    from oracle import c_oracle
+    g = load_golden(name)
+    fs, rf, seed = float(g['fs']), int(g['ref_frame']), int(g['seed'])
+    acc_err, gyr_err = _errs(g)
+    algos = [a for a, tag in (('free', 'fi'), ('odo', 'odo')) if tag + '_att' in g]
+    odo_err = {'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])} if 'odo' in g else None
+    RR = 70
+    ids = np.arange(RR)
+    for n in (2, 3, 4, 6, 7, 8, 12, 13, 14, 19, 20):
+        truth = {k: np.ascontiguousarray(g[k][:n]) for k in ('ref_accel', 'ref_gyro', 'ref_att', 'ref_pos', 'ref_vel')}
+        if odo_err is not None:
+            truth['ref_odo'] = np.ascontiguousarray(g['ref_odo'][:n])
+        for keep in (True, False):
+            job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc_err, gyr_err, g['ini'], runs=RR, algos=tuple(algos), odo_err=odo_err,
+                                       seed=seed, keep_sensors=keep, keep_traj=keep, precision='f32')
+            job.run()
+            assert 'split' in job.kernel_name(), job.kernel_name()
+            for a in algos:
+                end, traj, sens, odo = c_oracle.mc_run_f32(seed, 0, RR, fs, rf, truth, acc_err, gyr_err, g['ini'], algo=a, odo_err=odo_err, keep=RR)
+                tag = '%s n=%d keep=%d %s' % (name, n, keep, a)
+                if keep:
+                    _bits_equal(job.sensors('accel', ids), sens[:, :, 0:3], tag + ' accel')
+                    _bits_equal(job.sensors('gyro', ids), sens[:, :, 3:6], tag + ' gyro')
+                    if odo is not None:
+                        _bits_equal(job.sensors('odo', ids), odo, tag + ' odo')
+                    att, dpos, vel = job.trajectories(a, ids, displacement=True)
+                    _bits_equal(att, traj[:, :, 0:3], tag + ' att')
+                    _bits_equal(dpos, traj[:, :, 3:6], tag + ' displacement')
+                    _bits_equal(vel, traj[:, :, 6:9], tag + ' vel')
+                dev_end = job.end_errors(a)
+                assert ang_close(dev_end[:, :3], end[:, :3], 1e-12), tag
+                np.testing.assert_allclose(dev_end[:, 3:6], end[:, 3:6], rtol=0, atol=2e-8, err_msg=tag)
+                np.testing.assert_allclose(dev_end[:, 6:9], end[:, 6:9], rtol=0, atol=1e-12, err_msg=tag)
+            job.release()
+
+
 @pytest.mark.parametrize('name', ['bosch', 'nxp', 'tumble'])
 def test_fp32_given_data_fixtures(ctx, name):
     """The plugin boundary in fp32: logged fp64 IMU series on the device, rounded to float as the kernel reads them."""
