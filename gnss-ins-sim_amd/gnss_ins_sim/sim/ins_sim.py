@@ -497,20 +497,24 @@ class Sim(object):
             s += '\n-----------statistics for ' + d.get_data_all(data_name).description + \
                  ' (in units of ' + st['units'] + ')\n'
             if hasattr(st['max'], 'keys'):
-                keys = sorted(st['max'].keys())          # the reference's (lexicographic) order
                 limit = 2048 if max_summary_runs is None else int(max_summary_runs)
-                if len(keys) > limit:                    # truncating: first runs of every algorithm by run NUMBER
+                total = len(st['max'])
+                if total <= limit:
+                    keys = sorted(st['max'].keys())      # the reference's (lexicographic) order
+                elif hasattr(st['max'], 'first_keys'):   # truncating: first runs of every algorithm by run NUMBER,
+                    keys = st['max'].first_keys(limit)   # made directly (10^5 keys are not built to print 2048 of them)
+                else:
                     def run_order(k):
                         name, _, num = str(k).rpartition('_')
                         return (name, int(num)) if num.isdigit() else (str(k), -1)
-                    keys = sorted(keys, key=run_order)
-                for k in keys[:limit]:
+                    keys = sorted(st['max'].keys(), key=run_order)[:limit]
+                for k in keys:
                     s += '\tSimulation run ' + str(k) + ':\n'
                     s += '\t\t--Max error: ' + str(st['max'][k]) + '\n'
                     s += '\t\t--Avg error: ' + str(st['avg'][k]) + '\n'
                     s += '\t\t--Std of error: ' + str(st['std'][k]) + '\n'
-                if len(keys) > limit:
-                    s += '\t... %d more runs: sim.err_stats[%r]\n' % (len(keys) - limit, data_name)
+                if total > limit:
+                    s += '\t... %d more runs: sim.err_stats[%r]\n' % (total - limit, data_name)
             else:
                 s += '\t--Max error: ' + str(st['max']) + '\n'
                 s += '\t--Avg error: ' + str(st['avg']) + '\n'

@@ -127,6 +127,16 @@ class RunStats(Mapping):
                     return a[int(r) - first]
         raise KeyError(key)
 
+    def first_keys(self, limit):
+        """The first `limit` keys in (algorithm name, run number) order, without making the others."""
+        out = []
+        for name, first, a in sorted(self.parts, key=lambda p: (p[0], p[1])):
+            take = min(a.shape[0], limit - len(out))
+            out.extend(name + '_' + str(first + i) for i in range(take))
+            if len(out) >= limit:
+                break
+        return out
+
     def scaled(self, scale):
         return RunStats([(name, first, a * scale[:a.shape[1]]) for name, first, a in self.parts])
 
