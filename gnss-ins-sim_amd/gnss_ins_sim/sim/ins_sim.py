@@ -38,6 +38,7 @@ import numpy as np
 
 from .ins_data_manager import InsDataMgr
 from .ins_algo_manager import InsAlgoMgr
+from . import sim_data
 from .sim_data import McSeries, ChainSeries
 from ..attitude import attitude
 
@@ -508,11 +509,14 @@ class Sim(object):
                         name, _, num = str(k).rpartition('_')
                         return (name, int(num)) if num.isdigit() else (str(k), -1)
                     keys = sorted(st['max'].keys(), key=run_order)[:limit]
+                fast = sim_data.default_print_options()
+                rows = []
                 for k in keys:
-                    s += '\tSimulation run ' + str(k) + ':\n'
-                    s += '\t\t--Max error: ' + str(st['max'][k]) + '\n'
-                    s += '\t\t--Avg error: ' + str(st['avg'][k]) + '\n'
-                    s += '\t\t--Std of error: ' + str(st['std'][k]) + '\n'
+                    rows.append('\tSimulation run ' + str(k) + ':\n'
+                                '\t\t--Max error: ' + sim_data.vec_str(st['max'][k], fast) + '\n'
+                                '\t\t--Avg error: ' + sim_data.vec_str(st['avg'][k], fast) + '\n'
+                                '\t\t--Std of error: ' + sim_data.vec_str(st['std'][k], fast) + '\n')
+                s += ''.join(rows)
                 if total > limit:
                     s += '\t... %d more runs: sim.err_stats[%r]\n' % (total - limit, data_name)
             else:

@@ -305,3 +305,35 @@ def test_nine_axis_hook_uses_the_references_own_wmm(monkeypatch):
     r = mod.GeoMag('WMM.COF').GeoMag(lat / (math.pi / 180), lon / (math.pi / 180), alt, when)
     np.testing.assert_array_equal(got, np.array([r.bx, r.by, r.bz]) / 1000.0)
     assert 20.0 < np.linalg.norm(got) < 70.0                                       # uT
+
+
+def test_summary_vector_text_equals_numpy_str():
+    """The summary writes str(statistic vector) tens of thousands of times for a large batch; sim_data.vec_str reproduces
+    numpy's array printer (positional / exponent form, common widths) without its per-call set-up.  Same text on 40 000 vectors
+    of every magnitude, with zeros, negative zeros, rounded values, the thresholds of the exponent form; anything it does not
+    cover goes to str()."""
+    from gnss_ins_sim.sim import sim_data
+    rng = np.random.default_rng(7)
+    cases = []
+    for scale in (1e-12, 1e-7, 1e-5, 1e-4, 1e-3, 1e-2, 1, 10, 1e3, 1e5, 1e7, 1e8, 1e9, 1e12):
+        for _ in range(2800):
+            a = rng.normal(size=3) * scale * 10 ** rng.uniform(-2, 2, size=3)
+            if rng.random() < 0.2:
+                a[rng.integers(3)] = 0.0
+            if rng.random() < 0.2:
+                a = np.round(a, int(rng.integers(0, 6)))
+            if rng.random() < 0.1:
+                a = np.abs(a)
+            cases.append(a)
+    cases += [np.zeros(3), np.array([1., 2., 3.]), np.array([0.5, -0.25, 100.]), np.array([1e-4, 1e-4, 1e-4]),
+              np.array([9.99999999e7, 1, 1]), np.array([1e8, 1, 1]), np.array([-0.0, 1.0, 2.0]), np.array([1e-5, 0, 0]),
+              np.array([123456789.123, 0, 0]), np.array([0.1, 100.0, 0.1]), np.array([0.1, 100.1, 0.1]),
+              np.array([1.0, 1000.0, 1.0]), np.array([1.0, 1000.1, 1.0]), np.array([2.5]), np.array([1.0, -2.0]),
+              np.array([np.nan, 1.0, 2.0]), np.array([np.inf, 1.0, -2.0]), np.arange(6.0), np.array([1, 2, 3])]
+    assert sim_data.default_print_options()
+    for a in cases:
+        assert sim_data.vec_str(a) == str(a), repr(a)
+    with np.printoptions(precision=3):
+        assert not sim_data.default_print_options()
+        a = np.array([1.23456789, 2.0, 3.0])
+        assert sim_data.vec_str(a, sim_data.default_print_options()) == str(a)
