@@ -337,3 +337,17 @@ def test_summary_vector_text_equals_numpy_str():
         assert not sim_data.default_print_options()
         a = np.array([1.23456789, 2.0, 3.0])
         assert sim_data.vec_str(a, sim_data.default_print_options()) == str(a)
+
+
+def test_run_stats_first_keys_are_the_first_runs_of_every_algorithm():
+    """What a truncated summary lists: keys in (algorithm, run number) order, made without building the rest; the mapping
+    itself still answers every key."""
+    from gnss_ins_sim.sim import sim_data
+    a = np.arange(30.0).reshape(10, 3)
+    rs = sim_data.RunStats([('odo', 0, a[:4]), ('free', 0, a[:6]), ('free', 6, a[6:])])
+    assert len(rs) == 14
+    assert rs.first_keys(8) == ['free_0', 'free_1', 'free_2', 'free_3', 'free_4', 'free_5', 'free_6', 'free_7']
+    assert rs.first_keys(12) == ['free_%d' % i for i in range(10)] + ['odo_0', 'odo_1']
+    assert rs.first_keys(100) == ['free_%d' % i for i in range(10)] + ['odo_%d' % i for i in range(4)]
+    assert np.array_equal(rs['free_7'], a[7]) and np.array_equal(rs['odo_3'], a[3])
+    assert sorted(rs.keys()) == sorted(rs.first_keys(100))
