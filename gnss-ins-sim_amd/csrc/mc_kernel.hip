@@ -944,24 +944,30 @@ hipError_t launch_normal_transform(const uint32_t* words, int64_t count, double*
     return hipGetLastError();
 }
 
-// [C][n][R] -> [R][C][n]: per component a (n x R) -> (R x n) transpose through a padded 64 x 64 LDS tile; both the
-// reads (64 runs contiguous) and the writes (64 samples contiguous) are 512-byte rows.
+// [C][n][R] -> [R][C][n]: per component a (n x R) -> (R x n) transpose through a padded LDS tile of 64 samples x up to 64 runs.
+// The tile's source rows are read as ONE flat range when the tile spans whole rows (R <= 64: 64 x R contiguous doubles, every
+// lane busy whatever R is -- with a lane per run, 32 runs left half of every wavefront idle and the re-layout of config 5's
+// 2 x 1.1 GB ran at 2.6 TB/s; now 4.6); the writes are 512-byte rows of 64 samples, one per run of the tile.  (Tiles of 128
+// samples for few runs -- 1 KiB rows on the write side -- measured no faster.)
 __global__ void __launch_bounds__(256) runs_to_series_kernel(const double* __restrict__ in, double* __restrict__ out, int C,
                                                             int64_t n, int64_t R) {
     __shared__ double tile[64][65];
     const int c = blockIdx.z;
     const int64_t j0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const double* src = in + (int64_t)c * n * R;
-    for (int k = ty; k < 64; k += 4) {
-        const int64_t j = j0 + k, r = r0 + tx;
-        tile[k][tx] = (j < n && r < R) ? src[j * R + r] : 0.0;
+    const int rt = (int)(R - r0 < 64 ? R - r0 : 64);            // runs in this tile
+    const int jt = (int)(n - j0 < 64 ? n - j0 : 64);            // samples in this tile
+    const double* src = in + (int64_t)c * n * R + j0 * R + r0;
+    const bool pow2 = (rt & (rt - 1)) == 0;
+    const int sh = 31 - __builtin_clz(rt);
+    for (int e = threadIdx.x; e < jt * rt; e += 256) {
+        const int j = pow2 ? (e >> sh) : e / rt;
+        const int r = e - j * rt;
+        tile[j][r] = __builtin_nontemporal_load(&src[(int64_t)j * R + r]);
     }
     __syncthreads();
-    for (int k = ty; k < 64; k += 4) {
-        const int64_t r = r0 + k, j = j0 + tx;
-        if (r < R && j < n) out[(r * C + c) * n + j] = tile[tx][k];
-    }
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (tx < jt)
+        for (int k = ty; k < rt; k += 4) __builtin_nontemporal_store(tile[tx][k], &out[((r0 + k) * C + c) * n + j0 + tx]);
 }
 
 hipError_t launch_runs_to_series(const double* in, double* out, int C, int64_t n, int64_t R, hipStream_t s) {

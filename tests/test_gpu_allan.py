@@ -197,3 +197,20 @@ def test_sim_allan_flow_stays_on_the_device_and_matches_the_host_plugin(ctx, run
     k = int(np.argmin(np.abs(tau['algo0_0'] - 1.0)))
     assert abs(ad_g['algo0_0'][k, 0] / (0.25 / 60 * np.pi / 180) - 1.0) < 0.25
     os.remove(short)
+
+
+@pytest.mark.parametrize('C,n,R', [(3, 1000, 32), (3, 1, 1), (1, 63, 5), (2, 64, 64), (3, 65, 70), (1, 130, 130), (3, 4097, 33), (2, 129, 1)])
+def test_runs_to_series_relayout_every_tile_shape(ctx, C, n, R):
+    """[C][n][R] -> [R][C][n] on the device (what the Allan flow does with the kept sensor series of many runs): full and ragged
+    tiles in both directions, runs that are and are not a power of two, fewer runs than a wavefront has lanes."""
+    import ginsim
+    from ginsim._lib import check
+    rng = np.random.default_rng(C * 1000003 + n * 131 + R)
+    x = rng.normal(size=(C, n, R))
+    src = ctx.upload(x)
+    dst = ctx.malloc(8 * x.size)
+    check(ginsim.lib.ginsim_runs_to_series(ctx.handle, src.ptr, C, n, R, dst.ptr))
+    got = ctx.download(dst, (R, C, n))
+    assert np.array_equal(got, np.ascontiguousarray(x.transpose(2, 0, 1)))
+    src.free()
+    dst.free()
