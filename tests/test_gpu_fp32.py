@@ -3,7 +3,7 @@
   1. BIT-EXACT against the float restatement in oracle/c/ginsim_oracle.c (oracle_mc_run_f32): every kept sensor sample
      and every trajectory sample of the compared runs, for the reference-executed T3 cases (standard / custom / white-drift
      IMUs, odometer, both frames, 100 and 200 Hz), for the given-data T1 fixtures, and for sampled runs of the REAL launches
-     (65 536 and 262 144 runs, wave-specialised kernel with two producer groups, and the plain kernel).  That oracle is
+     (65 536 and 262 144 runs, wave-specialised kernel with three producer groups, and the plain kernel).  That oracle is
      pinned to the executed reference at the stated fp32 tolerances by the CPU tests (tests/test_oracle_c.py).
   2. Against the fp64 kernel ON IDENTICAL SEEDS (the two precisions consume the same normals): per sample within the
      STATED fp32 TOLERANCES for 10 s / 1000 steps: attitude 2e-6 rad, velocity 5e-5 m/s, position 1e-4 m, accel 2e-6 m/s^2,
