@@ -15,7 +15,7 @@ __global__ void fill(double* x, int64_t count) {
     x[i] = -9.79 + 5e-3 * ((double)(h & 0xFFFFF) / 524288.0 - 1.0);
 }
 
-template <int D>
+template <int D, bool MACHINES>
 __global__ void __launch_bounds__(64) allan_rm(const double* __restrict__ x, double* __restrict__ out, double* __restrict__ partial, const Lv lv) {
     const int lane = threadIdx.x;
     const int sigma = blockIdx.y * 64 + lane;
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(64) allan_rm(const double* __restrict__ x, dou
                 P += buf[i] - x0;
 #pragma unroll
                 for (int j = 1; j <= 10; ++j) {
-                    if (--cnt[j - 1] == 0) {            // wave-uniform
+                    if (MACHINES && --cnt[j - 1] == 0) {            // wave-uniform
                         cnt[j - 1] = j;
                         if (!started[j - 1]) { started[j - 1] = true; Q[j - 1] = P; }
                         else {
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(64) allan_rm(const double* __restrict__ x, dou
     }
     if (active)
 #pragma unroll
-        for (int j = 0; j < 9; ++j) partial[((int64_t)blockIdx.x * 9 + j) * S + sigma] = acc[j];
+        for (int j = 0; j < 9; ++j) partial[((int64_t)blockIdx.x * 9 + j) * S + sigma] = acc[j] + P;
 }
 
 int main() {
@@ -99,12 +99,12 @@ int main() {
             for (int rep = 0; rep < 30; ++rep) {
                 hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
                 hipEventRecord(a);
-                if (d == 16) hipLaunchKernelGGL(allan_rm<16>, dim3(ranges, (S + 63) / 64), dim3(64), 0, 0, x, out, partial, lv);
-                else hipLaunchKernelGGL(allan_rm<32>, dim3(ranges, (S + 63) / 64), dim3(64), 0, 0, x, out, partial, lv);
+                if (d == 16) hipLaunchKernelGGL((allan_rm<16, true>), dim3(ranges, (S + 63) / 64), dim3(64), 0, 0, x, out, partial, lv);
+                else hipLaunchKernelGGL((allan_rm<16, false>), dim3(ranges, (S + 63) / 64), dim3(64), 0, 0, x, out, partial, lv);
                 hipEventRecord(b); hipEventSynchronize(b);
                 float ms; hipEventElapsedTime(&ms, a, b); if (rep >= 10) { sum += ms; if (ms < best) best = ms; }
             }
-            printf("L %5lld  D %2d  waves %6d : min %.3f avg %.3f ms  %.0f GB/s\n", (long long)L, d, ranges * 3, best, sum / 20, 8.0 * n * S / (sum / 20) / 1e6);
+            printf("L %5lld  mode %2d (16: machines, 32: loads + prefix only)  waves %6d : min %.3f avg %.3f ms  %.0f GB/s\n", (long long)L, d, ranges * 3, best, sum / 20, 8.0 * n * S / (sum / 20) / 1e6);
         }
         hipFree(partial);
     }
