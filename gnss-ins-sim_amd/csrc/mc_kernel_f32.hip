@@ -576,9 +576,8 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const gi
         }
     };
     // samples 0 .. n-2 have a mechanisation step behind them: a COUNTED inner loop without a way out in the middle of its
-    // body (with the old `if (j == n - 1) break` after the sensors the loop's merge block took the un-stepped state from
-    // one side and the stepped state from the other, and the register allocator settled that with fourteen v_mov on the
-    // hot side).  The last sample, sensor output only, follows the loops: its normals are still in the ring.
+    // body (the old `if (j == n - 1) break` after the sensors gave the loop a second merge block fed by the un-stepped
+    // state).  The last sample, sensor output only, follows the loops: its normals are still in the ring.
     const uint32_t n_steps = n - 1;
     for (uint32_t i = 0; i <= ntiles; ++i) {
         if (i >= 1 && active && !(exp_flags & 2)) {
