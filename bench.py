@@ -166,45 +166,98 @@ def reference_python_baseline(budget_s):
                           '1 core; the reference is single-threaded); /root/reference does not exist on this host, so it is not timed here'}
 
 
-# --------------------------------------------------------------------------------------------- PMC traffic
-def pmc_traffic_live(kernels, timeout_s=90):
-    """HBM bytes per launch of `kernels` (names as rocprofv3 reports them, without arguments) from two rocprofv3 --pmc
-    passes of this script's --pmc-child mode (same build, same workload, 3 launches each): WRITE_SIZE and FETCH_SIZE in
-    KiB; FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section).  Returns {kernel: {...}} or None."""
+# --------------------------------------------------------------------------------------------- PMC passes
+SIMDS, XCDS, SPEC_CLOCK_HZ = 1024, 8, 2.4e9       # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 8 XCDs, 2400 MHz
+PMC_PASSES = (('WRITE_SIZE',), ('FETCH_SIZE',),
+              ('SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_INST_ANY',
+               'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'GRBM_GUI_ACTIVE'))
+
+
+def short_name(kernel_name):
+    k = kernel_name[5:] if kernel_name.startswith('void ') else kernel_name
+    return k[:k.index('(')] if '(' in k else k
+
+
+def pmc_live(timeout_s=150):
+    """Counters of every kernel of this script's --pmc-child workload (same build; the headline, the given-sensors and the
+    fp32 launch, a C3-shaped launch cut to 8192 samples with and without the online statistics, config 5's sensor generation
+    and three Allan calls) from one rocprofv3 --pmc pass per counter group, each in a run of its own with --kernel-trace only
+    (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ has 8 slots, GRBM its own).
+    Returns {kernel (as rocprofv3 names it, without 'void' and arguments): {counter: {'avg', 'sum', 'n'}, 'dur_ns': avg}} or None."""
     import sqlite3
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(exe):
         return None
-    vals = {}
+    out = {}
     work = tempfile.mkdtemp(prefix='ginsim_pmc_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
     try:
-        for counter in ('WRITE_SIZE', 'FETCH_SIZE'):
-            d = os.path.join(work, counter)
-            cmd = [exe, '--pmc', counter, '--kernel-trace', '-d', d, '-o', 'pmc', '--', sys.executable,
-                   os.path.abspath(__file__), '--pmc-child']
+        for i, group in enumerate(PMC_PASSES):
+            d = os.path.join(work, 'pass%d' % i)
+            cmd = [exe, '--pmc'] + list(group) + ['--kernel-trace', '-d', d, '-o', 'pmc', '--', sys.executable,
+                                                   os.path.abspath(__file__), '--pmc-child']
             subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith('.db')]
             if not dbs:
                 return None
             con = sqlite3.connect(dbs[0])
-            for name, cnt, avg in con.execute("select kernel_name, count(*), avg(value) from counters_collection "
-                                              "where counter_name = ? group by kernel_name", (counter,)):
-                for k in kernels:
-                    if name.startswith('void ' + k + '(') or name.startswith(k + '('):
-                        vals.setdefault(k, {})[counter] = (avg, cnt)
+            for name, counter, cnt, avg, tot in con.execute("select kernel_name, counter_name, count(*), avg(value), sum(value) "
+                                                            "from counters_collection group by kernel_name, counter_name"):
+                out.setdefault(short_name(name), {})[counter] = {'avg': avg, 'sum': tot, 'n': cnt}
+            if i == len(PMC_PASSES) - 1:
+                for name, dur in con.execute("select name, avg(end - start) from kernels group by name"):
+                    out.setdefault(short_name(name), {})['dur_ns'] = dur
             con.close()
-        out = {}
-        for k, c in vals.items():
-            if 'WRITE_SIZE' in c and 'FETCH_SIZE' in c:
-                w, f = c['WRITE_SIZE'][0] * 1024.0, 2.0 * c['FETCH_SIZE'][0] * 1024.0
-                out[k] = {'hbm_bytes_per_launch': w + f, 'write_bytes': w, 'fetch_bytes_corrected': f,
-                          'dispatches': int(c['WRITE_SIZE'][1])}
         return out or None
     except Exception:                                              # noqa: BLE001 -- profiling is evidence, not the product
         return None
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def pmc_traffic(pmc, kernels):
+    """HBM bytes per launch of `kernels`: WRITE_SIZE and FETCH_SIZE are in KiB; FETCH_SIZE x 2 on gfx950
+    (MI355X_MICROARCH.md, HBM section: a wide coalesced read is tallied at half its bytes)."""
+    out = {}
+    for k in kernels:
+        c = (pmc or {}).get(k, {})
+        if 'WRITE_SIZE' in c and 'FETCH_SIZE' in c:
+            w, f = c['WRITE_SIZE']['avg'] * 1024.0, 2.0 * c['FETCH_SIZE']['avg'] * 1024.0
+            out[k] = {'hbm_bytes_per_launch': w + f, 'write_bytes': w, 'fetch_bytes_corrected': f, 'dispatches': int(c['WRITE_SIZE']['n'])}
+    return out or None
+
+
+def pmc_traffic_of_call(pmc, prefix, calls_kernel):
+    """HBM bytes per CALL of a multi-kernel entry point (ginsim_allan): the counters of every kernel whose name starts with
+    `prefix`, summed over all their dispatches, divided by the number of calls (= dispatches of `calls_kernel`)."""
+    if not pmc or calls_kernel not in pmc or 'WRITE_SIZE' not in pmc[calls_kernel]:
+        return None
+    calls = pmc[calls_kernel]['WRITE_SIZE']['n']
+    w = sum(c['WRITE_SIZE']['sum'] for k, c in pmc.items() if k.startswith(prefix) and 'WRITE_SIZE' in c) * 1024.0 / calls
+    f = sum(c['FETCH_SIZE']['sum'] for k, c in pmc.items() if k.startswith(prefix) and 'FETCH_SIZE' in c) * 2048.0 / calls
+    return {'hbm_bytes_per_call': w + f, 'write_bytes': w, 'fetch_bytes_corrected': f, 'calls': int(calls)}
+
+
+def valu_roofline(pmc, kernel, kernel_ms, scale, note):
+    """The roofline of a COMPUTE-bound launch ("report VALU utilisation"): SIMD cycles spent issuing VALU
+    instructions per second against SIMDs x spec clock.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip (it equals
+    SQ_INSTS_VALU within 1 % on these kernels: a wave64 fp64-class instruction occupies its SIMD for four cycles), GRBM_GUI_ACTIVE
+    cycles summed over the 8 XCDs; both come from a launch of the same kernel cut to 8192 samples (`scale` = full / cut steps),
+    `kernel_ms` is the HIP-event time of the FULL launch in this process."""
+    c = (pmc or {}).get(kernel, {})
+    if 'SQ_ACTIVE_INST_VALU' not in c or 'GRBM_GUI_ACTIVE' not in c:
+        return None
+    busy = 4.0 * c['SQ_ACTIVE_INST_VALU']['avg']                   # SIMD cycles, cut launch
+    cyc = c['GRBM_GUI_ACTIVE']['avg'] / XCDS                       # shader cycles the cut launch took
+    ach = busy * scale / (kernel_ms * 1e-3)
+    out = {'bound': 'valu', 'achieved': ach, 'peak': SIMDS * SPEC_CLOCK_HZ, 'unit': 'VALU-busy SIMD-cycles/s',
+           'frac': ach / (SIMDS * SPEC_CLOCK_HZ), 'traffic': None, 'kernel': kernel, 'kernel_ms_avg': kernel_ms,
+           'valu_busy_at_the_clock_it_ran': busy / (SIMDS * cyc),
+           'effective_clock_ghz_profiled': (cyc / (c['dur_ns'] * 1e-9) / 1e9) if c.get('dur_ns') else None,
+           'counters_per_cut_launch': {k: v['avg'] for k, v in c.items() if isinstance(v, dict)}, 'note': note}
+    if 'SQ_LDS_BANK_CONFLICT' in c and c.get('SQ_LDS_IDX_ACTIVE', {}).get('avg'):
+        out['lds_bank_conflict_frac'] = c['SQ_LDS_BANK_CONFLICT']['avg'] / c['SQ_LDS_IDX_ACTIVE']['avg']
+    return out
 
 
 def pmc_traffic_file(build):
@@ -236,8 +289,18 @@ def leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, reps=
             'bit_identical_to_fused_kernel': same}
 
 
-def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precision, reps, gps=False, **job_kw):
+PMC_CUT_SAMPLES = 8192      # the C3-shaped launches of the --pmc-child workload are cut to this many samples
+
+
+def cut_truth(truth, n):
+    return {k: (v[:n] if hasattr(v, 'shape') and getattr(v, 'ndim', 0) >= 1 and v.shape[0] > n else v) for k, v in truth.items()}
+
+
+def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precision, reps, gps=False, pmc=None, traffic=None,
+           cut=None, **job_kw):
     ini, truth, _ = workloads.truth_from_profile(profile, fs, rf, fs_gps=10.0 if gps else 0.0, gps=gps)
+    if cut:
+        truth = cut_truth(truth, cut)
     acc, gyr = workloads.imu_grade('mid-accuracy')
     n = truth['ref_accel'].shape[0]
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, seed=SEED, keep_sensors=keep, keep_traj=keep,
@@ -247,16 +310,27 @@ def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precisi
     st = job.stats('free')
     unit = (BYTES_PER_SAMPLE_MC if precision == 'f64' else BYTES_PER_SAMPLE_MC // 2) if keep else 0
     alg = unit * R * n + 72 * R
+    kname = job.kernel_name()
+    if keep:
+        roof = roofline(alg, avg, kname, (traffic or {}).get(kname, {}).get('hbm_bytes_per_launch'))
+    else:
+        # nothing is written per sample (72 B per RUN): compute-bound by construction -> the VALU roofline
+        roof = valu_roofline(pmc, kname, avg, (n - 1.0) / (PMC_CUT_SAMPLES - 1.0),
+                             'stats-only launch: 72 B per RUN reach HBM, the launch is bound by VALU issue; counters from a launch of '
+                             'this kernel cut to %d samples (rocprofv3 --pmc pass of `bench.py --pmc-child`)' % PMC_CUT_SAMPLES)
+        if roof is None:
+            roof = {'bound': 'valu', 'achieved': None, 'peak': SIMDS * SPEC_CLOCK_HZ, 'unit': 'VALU-busy SIMD-cycles/s', 'frac': None,
+                    'traffic': None, 'kernel': kname, 'kernel_ms_avg': avg, 'note': 'no PMC pass available in this run (--pmc off or '
+                    'rocprofv3 missing): see profiles/*_pmc_counters.csv for this kernel'}
     out = {'name': name, 'workload': desc, 'dtype': precision, 'runs': R, 'samples_per_run': n, 'materialised': keep,
            'sample_MC_per_s': R * n / avg * 1e3, 'kernel_ms_min': mn,
-           'roofline': roofline(alg, avg, job.kernel_name(), None, **({} if keep else {
-               'note': 'stats-only: nothing is written per sample (72 B per RUN), the kernel is fp64-VALU-bound by construction'})),
+           'roofline': roof,
            'result': {'att_std_deg': (st.std[:3] * 57.29577951308232).tolist(), 'vel_std_mps': st.std[6:9].tolist(), 'runs': st.count}}
     job.release()
     return out
 
 
-def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0):
+def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0, pmc=None, calls=30, warm=40):
     """BASELINE config 5, second half, END TO END on the device: static truth for 3600 s @ 400 Hz (n = 1 440 000) ->
     accel + gyro series of `runs` runs generated by the time-parallel sensor kernels -> re-layout -> ONE Allan call over all
     6 x runs series (46 averaging factors).  Algorithmic bytes of the Allan call: 8 B per sample (one read of the series)."""
@@ -273,34 +347,44 @@ def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0):
     job = ginsim.MonteCarloJob(ctx, fs, 1, truth, acc, gyr, None, runs=runs, algos=(), seed=SEED, keep_sensors=True)
     job.run()
     tau, ad = job.allan(fs)                                        # warm-up (scratch allocation)
-    ctx.timer_begin()
-    job.launch()
-    gen_ms = ctx.timer_end()
+    gen_ms, gen_min = time_launches(ctx, job.launch, 10)
     t0 = time.perf_counter()
     tau, ad = job.allan(fs)
     e2e_wall_ms = (time.perf_counter() - t0) * 1e3
     S = 6 * runs
-    tmp = ctx.malloc(8 * S * n)
-    for i, nm in enumerate(('accel', 'gyro')):
-        check(ginsim.lib.ginsim_runs_to_series(ctx.handle, job.buffer(nm).ptr, 3, n, runs, tmp.at(i * 24 * n * runs)))
-    for _ in range(40):         # warm-up: the call settles after ~30 of them (WARM_MS)
-        ginsim.allan_var(ctx, tmp, n, S, n, fs)
+    if job.sensor_layout == 'series' or runs == 1:       # the job's own buffer IS [sensor][run][axis][n]
+        tmp, x = None, job.buffer('accel')
+    else:
+        tmp = x = ctx.malloc(8 * S * n)
+        for i, nm in enumerate(('accel', 'gyro')):
+            check(ginsim.lib.ginsim_runs_to_series(ctx.handle, job.buffer(nm).ptr, 3, n, runs, tmp.at(i * 24 * n * runs)))
+    for _ in range(warm):       # warm-up: the call settles after ~30 of them (WARM_MS)
+        ginsim.allan_var(ctx, x, n, S, n, fs)
     ms = []
-    for _ in range(30):         # every call ends with a synchronisation (the sums are on the host): the calls cannot overlap
+    for _ in range(calls):      # every call ends with a synchronisation (the sums are on the host): the calls cannot overlap
         ctx.timer_begin()
-        ginsim.allan_var(ctx, tmp, n, S, n, fs)
+        ginsim.allan_var(ctx, x, n, S, n, fs)
         ms.append(ctx.timer_end())
-    tmp.free()
+    if tmp is not None:
+        tmp.free()
     avg = sum(ms) / len(ms)
+    # per call: the level kernels + the finishing launch; the sensor generation's own kernels are named series_*
+    call_traffic = pmc_traffic_of_call(pmc, 'ginsim::allan_', 'ginsim::allan_tail_kernel')
     # white-noise known answer: AD(tau) = ARW / sqrt(tau) at tau = 1 s
     k1 = int(np.argmin(np.abs(tau - 1.0)))
     arw = float(np.asarray(gyr['arw'])[0])
     out = {'name': 'C5_allan_end_to_end', 'dtype': 'f64',
            'workload': 'static %g s @ %g Hz (n = %d), mid-accuracy IMU, %d runs: sensor generation -> re-layout -> Allan variance '
                        'of %d series, %d averaging factors' % (seconds, fs, n, runs, S, tau.size),
-           'sensor_generation_ms': gen_ms, 'relayout_plus_allan_wall_ms': e2e_wall_ms, 'allan_call_ms_min': min(ms),
+           'sensor_generation_ms': gen_ms, 'sensor_generation_ms_min': gen_min, 'sensor_kernel': job.kernel_name(),
+           'sensor_layout': job.sensor_layout,
+           'sensor_generation_roofline': roofline(48.0 * runs * n, gen_ms, 'series_kernel<0> + series_scan_kernel + series_kernel<1>', None,
+                                                  note='48 B written per sample of a run (accel3 + gyro3 doubles); the three launches of the time-parallel path'),
+           'relayout_plus_allan_wall_ms': e2e_wall_ms, 'allan_call_ms_min': min(ms),
            'samples_per_s_allan_call': S * n / avg * 1e3,
-           'roofline': roofline(8.0 * S * n, avg, 'ginsim_allan (allan_pair_kernel x3 + allan_tail_kernel: the whole call, up to the synchronisation that returns the sums)', None),
+           'roofline': roofline(8.0 * S * n, avg, 'ginsim_allan (every kernel of the call, up to the synchronisation that returns the sums)',
+                                (call_traffic or {}).get('hbm_bytes_per_call'), traffic_detail=call_traffic,
+                                traffic_over_algorithmic=(call_traffic['hbm_bytes_per_call'] / (8.0 * S * n)) if call_traffic else None),
            'result': {'ad_gyro_x_at_1s_over_arw': float(ad['gyro'][:, k1, 0].mean() / arw * np.sqrt(tau[k1]))}}
     job.release()
     return out
@@ -560,7 +644,7 @@ def main():
     kern_avg_ms = float(np.mean(kern_ms))
     assert merged.count == world * R, (merged.count, world * R)
 
-    if args.pmc_child:                                      # the given-sensors and the fp32 kernel are profiled in the same pass
+    if args.pmc_child:      # every kernel a roofline object of the line is about, in the same passes
         if keep and args.precision == 'f64':
             leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, None, reps=3)
             job.release()
@@ -569,7 +653,15 @@ def main():
             for _ in range(4):
                 job.launch()
             ctx.sync()
-        job.release()
+            job.release()
+            job = None
+            # C3's kernels (compute-bound: VALU counters), cut to PMC_CUT_SAMPLES samples
+            leg_mc(ginsim, workloads, ctx, 'c3', '', 'long_drive', 200.0, 0, 262144, False, 'f64', 2, gps=True, cut=PMC_CUT_SAMPLES,
+                   proc_first=0, end_ned=True)
+            leg_mc(ginsim, workloads, ctx, 'c3e', '', 'long_drive', 200.0, 0, 262144, False, 'f64', 2, gps=True, cut=PMC_CUT_SAMPLES)
+            leg_allan(ginsim, workloads, ctx, calls=3, warm=1)       # config 5: sensor generation + three Allan calls
+        if job is not None:
+            job.release()
         ctx.close()
         return
 
@@ -580,10 +672,12 @@ def main():
         build = lib_hash()
         kname = job.kernel_name()
         given_name = 'ginsim::mc_kernel<%d, 1, true, false, 0>' % rf
-        traffic, traffic_source = None, None
+        traffic, traffic_source, pmc = None, None, None
         if world == 1 and args.precision == 'f64' and keep:
             if args.pmc == 'live':
-                traffic, traffic_source = pmc_traffic_live([kname, given_name]), 'live: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of `bench.py --pmc-child` on this build'
+                pmc = pmc_live()
+                traffic = pmc_traffic(pmc, [k for k in (pmc or {}) if 'mc_kernel' in k])
+                traffic_source = 'live: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of `bench.py --pmc-child` on this build'
             if traffic is None and args.pmc in ('live', 'file'):
                 traffic, traffic_source = pmc_traffic_file(build), 'profiles/pmc_traffic.json (same libginsim.so hash)'
             if traffic is None:
@@ -627,18 +721,19 @@ def main():
             job = None
             legs.append(leg_mc(ginsim, workloads, ctx, 'C4_per_gpu_share', 'BASELINE configs[3] per-GPU share: turn_90deg @100 Hz, '
                                '131 072 runs, fp64, materialised', 'turn_90deg', 100.0, 1, 131072, True, 'f64', 10))
+            c3 = dict(pmc=pmc)
             legs.append(leg_mc(ginsim, workloads, ctx, 'C3', 'BASELINE configs[2]: long_drive @200 Hz (n = 193 036), ref_frame 0, 262 144 '
                                'runs, fp64; trajectories would be 6 TB, so the kernel accumulates the per-run process-error statistics '
                                '(what Sim.results() prints by default) and both end-point records online; GPS / magnetometer series '
                                'are generated for the kept subset only (Sim keep_runs), they do not enter the integration',
-                               'long_drive', 200.0, 0, 262144, False, 'f64', 2, gps=True, proc_first=0, end_ned=True))
+                               'long_drive', 200.0, 0, 262144, False, 'f64', 2, gps=True, proc_first=0, end_ned=True, **c3))
             legs.append(leg_mc(ginsim, workloads, ctx, 'C3_end_point_only', 'the same launch with end-point statistics only (r01 form)',
-                               'long_drive', 200.0, 0, 262144, False, 'f64', 2, gps=True))
+                               'long_drive', 200.0, 0, 262144, False, 'f64', 2, gps=True, **c3))
             legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32', 'BASELINE configs[4]: fp32 kernel on the C2 workload, 65 536 runs, '
-                               'materialised (60 B/sample*MC)', 'turn_90deg', 100.0, 1, 65536, True, 'f32', 20))
+                               'materialised (60 B/sample*MC)', 'turn_90deg', 100.0, 1, 65536, True, 'f32', 20, traffic=traffic))
             legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32_262144', 'fp32 kernel, 262 144 runs, materialised', 'turn_90deg', 100.0, 1,
                                262144, True, 'f32', 10))
-            legs.append(leg_allan(ginsim, workloads, ctx))
+            legs.append(leg_allan(ginsim, workloads, ctx, pmc=pmc))
             legs.append(leg_sim_e2e(workloads))
             out['configs'] = legs
         if world == 1 and args.cpu_baseline_seconds > 0:

@@ -44,6 +44,7 @@ hipError_t launch_runs_to_series(const double* in, double* out, int C, int64_t n
 hipError_t launch_normal_transform(const uint32_t* words, int64_t count, double* z0, double* z1, hipStream_t s);
 hipError_t launch_gather_runs(const double* series, int C, int64_t n, int64_t runs, const int64_t* ids, int nsel,
                               double* out, hipStream_t s);
+hipError_t launch_gather_series(const double* series, int C, int64_t n, const int64_t* ids, int nsel, double* out, hipStream_t s);
 size_t stats_scratch_bytes(int64_t runs);
 int stats_blocks(int64_t runs);
 hipError_t launch_end_stats(const double* end_err, int64_t runs, void* scratch, hipStream_t s);
@@ -299,7 +300,7 @@ static int check_sensor(const ginsim_sensor_model& m, const char* what) {
 
 int ginsim_mc_variant(const ginsim_mc_params* p, int32_t* variant) {
     REQUIRE(p && variant, "mc_variant: NULL argument");
-    *variant = p->precision == 1 ? mc_variant_f32(*p) : mc_variant(*p);
+    *variant = p->precision == 1 ? mc_variant_f32(*p) : (series_path_applies(*p) ? 2 : mc_variant(*p));
     return GINSIM_OK;
 }
 
@@ -311,7 +312,7 @@ int ginsim_mc_kernel_name(const ginsim_mc_params* p, char* buf, size_t cap) {
     if (rc) return rc;
     buf[0] = 0;
     if (p->precision == 1) (void)launch_mc_f32(*p, nullptr, nullptr, buf, cap);
-    else if (series_path_applies(*p)) snprintf(buf, cap, "ginsim::series_kernel<1>");
+    else if (series_path_applies(*p)) snprintf(buf, cap, "ginsim::series_kernel<1>");   // the dominant one of series_kernel<0>, series_scan_kernel, series_kernel<1>
     else (void)launch_mc(*p, nullptr, buf, cap);
     REQUIRE(buf[0], "mc_kernel_name: no kernel serves these parameters");
     return GINSIM_OK;
@@ -368,6 +369,9 @@ static int check_mc_params(const ginsim_mc_params* p) {
         if (rc) return rc;
     }
     REQUIRE(p->precision == 0 || p->precision == 1, "mc_run: precision must be 0 (fp64) or 1 (fp32)");
+    REQUIRE(p->sensor_layout == 0 || p->sensor_layout == 1, "mc_run: sensor_layout must be 0 ([axis][sample][run]) or 1 ([run][axis][sample])");
+    REQUIRE(p->sensor_layout == 0 || series_path_applies(*p),
+            "mc_run: sensor_layout 1 is written by the time-parallel series kernels only (sensors only, fp64, <= 1024 runs, >= 2048 samples)");
     if (p->out_proc[0] || p->out_proc[1]) {
         REQUIRE(!p->given_sensors && p->precision == 0, "mc_run: online process statistics need generate mode and fp64");
         REQUIRE((p->algo_mask == GINSIM_ALGO_FREE && p->out_proc[0] && !p->out_proc[1]) ||
@@ -553,6 +557,24 @@ int ginsim_gather_runs(ginsim_ctx* c, const double* series, int32_t ncomp, int64
     HIP_TRY(out.alloc(out_bytes));
     HIP_TRY(hipMemcpyAsync(ids.p, run_ids, sizeof(int64_t) * nsel, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_gather_runs(series, ncomp, n, runs, ids.as<int64_t>(), nsel, out.as<double>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(host_out, out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_gather_series(ginsim_ctx* c, const double* series, int32_t ncomp, int64_t n, int64_t runs, const int64_t* run_ids,
+                         int32_t nsel, double* host_out) {
+    REQUIRE(c && series && run_ids && host_out, "gather_series: NULL argument");
+    REQUIRE(ncomp >= 1 && n >= 1 && runs >= 1 && nsel >= 1, "gather_series: bad sizes");
+    for (int i = 0; i < nsel; ++i)
+        REQUIRE(run_ids[i] >= 0 && run_ids[i] < runs, "gather_series: run id %lld out of range", (long long)run_ids[i]);
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf ids, out;
+    const size_t out_bytes = sizeof(double) * (size_t)nsel * n * ncomp;
+    HIP_TRY(ids.alloc(sizeof(int64_t) * nsel));
+    HIP_TRY(out.alloc(out_bytes));
+    HIP_TRY(hipMemcpyAsync(ids.p, run_ids, sizeof(int64_t) * nsel, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_gather_series(series, ncomp, n, ids.as<int64_t>(), nsel, out.as<double>(), c->stream));
     HIP_TRY(hipMemcpyAsync(host_out, out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GINSIM_OK;

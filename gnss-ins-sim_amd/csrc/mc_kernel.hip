@@ -705,100 +705,244 @@ hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream, char* name, 
 
 // ---------------------------------------------------------------------------------------------------
 // Sensor series for FEW runs (Sim.run(1) as a data generator, the Allan flow of BASELINE config 5): with one lane per
-// run the time loop of mc_kernel is a single sequential chain (n = 1 440 000 samples -> 2.8 s on one lane).  Noise
-// generation is parallel along time except for the Gauss-Markov recurrence d[j+1] = a d[j] + b w[j], which is linear:
-//   pass A  every thread takes a chunk of L samples of one run and integrates the drift from zero -> chunk-end value
-//   pass S  one thread per (run, axis) turns the chunk-end values into chunk-START values:
-//           start[k+1] = a^L start[k] + end[k]
-//   pass B  every thread regenerates the normals of its chunk (counter-based RNG: no state to carry) and emits
-//           truth + bias + drift + white with the recurrence restarted from start[k]
-// Same normals, same recurrence inside a chunk; only the L-step hand-over is evaluated as a^L x + y instead of L
-// fused multiply-adds (a relative 1e-16 on a drift of ~1e-5: far below the 1e-12 / 1e-14 sensor tolerances).
+// run the time loop of mc_kernel is a single sequential chain (n = 1 440 000 samples -> 2.8 s on one lane), and there are
+// no runs to fill the chip with.  Here the TIME axis is the parallel one: a lane is a SAMPLE, a wavefront covers 64
+// consecutive samples of one run per step and walks a chunk of L samples, so
+//   * the Philox counter (sample, block, run) makes the twelve normals of a sample a per-lane computation;
+//   * every store instruction of a wavefront writes 512 contiguous bytes of ONE series -- in the series-major layout
+//     [run][axis][n] (sensor_layout 1), which is what ginsim_allan reads: the Allan flow needs no re-layout;
+//   * the one sequential thing, the Gauss-Markov recurrence d[j+1] = a d[j] + b w[j] (pathgen.py:583-590), is linear:
+//     inside a wavefront it is a weighted inclusive scan over the lanes (Hillis-Steele in DPP: row_shr 1/2/4/8 with the
+//     wave-uniform weights a^1, a^2, a^4, a^8, then row_bcast:15 / :31 with the per-lane weights a^(p+1)), the carry of
+//     the previous 64 samples enters at lane 0, and across chunks it is three launches:
+//       pass A  chunk-end value of every chunk integrated from zero (drift normals only; a lane accumulates its
+//               samples j, j+64, ... with weight a^64, one weighted wave reduction at the end of the chunk)
+//       pass S  chunk-end values -> chunk-START values, start[k+1] = a^L start[k] + end[k]: the same scan, one
+//               wavefront per (run, axis)
+//       pass B  regenerates the normals (counter-based RNG: no state to carry) and emits
+//               truth + bias + drift + white (pathgen.py:500, 562) with the recurrence started from start[k].
+// Same normals and the same recurrence as the lane-per-run kernels; only the association of its sums differs (powers of
+// a instead of repeated multiplication: a relative 1e-16 on a drift of ~1e-5, far below the 1e-12 / 1e-14 sensor
+// tolerances and inside "an ulp of the terms" of the emitted sums, tests/test_gpu_edge_cases.py).
+// Round 3's version gave a THREAD a chunk of up to 4096 samples: 44 workgroups for config 5's 32 x 1 440 000 samples
+// (17 % of the chip), run-fastest stores 256 B apart, 6.0 ms + a 1.0 ms re-layout in front of a 0.5 ms Allan call.
+// wave-uniform weights of the weighted scan with ratio q (ScanWeights below)
+struct ScanQ { double q1, q2, q4, q8, q16; };
+typedef const ScanQ __attribute__((address_space(4))) * scanq_ptr;
+
 struct SeriesPlan {
     double* carry;          // [runs][nchunks][6]: pass A chunk-end values, pass S overwrites them with chunk-start values
     double a_pow[6];        // gm_a ^ L for accel xyz, gyro xyz
     int64_t nchunks;
-    int32_t L;
+    int64_t sr, sc, sj;     // element (run r, axis c, sample j) of a 3-axis sensor lives at r sr + c sc + j sj
+    int64_t odo_sr, odo_sj; // and of the odometer at r odo_sr + j odo_sj
+    int32_t L;              // samples per chunk, a multiple of 64
+    int32_t pad;
+    ScanQ   qa[6];          // powers of gm_a (the scans inside a chunk)
+    ScanQ   qL[6];          // powers of gm_a ^ L (pass S)
+    double  a64[6];         // gm_a ^ 64 (pass A)
+};
+typedef const SeriesPlan __attribute__((address_space(4))) * plan_ptr;
+// the plan is the second kernel argument: it follows the parameter block in the kernarg segment
+__device__ __forceinline__ plan_ptr kernarg_plan(size_t offset) {
+    auto p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (plan_ptr)(p + offset);
+}
+
+// Lanes the control cannot serve (the first lanes of a row for row_shr, row 0 for row_bcast) read 0.0 (bound_ctrl); every
+// row is written (row_mask 0xf), so the instruction needs no defined previous value of its destination -- with a row mask
+// the compiler had to zero the destination first: 84 v_mov per step.  The rows a broadcast must not reach get weight 0.
+template <int CTRL>
+__device__ __forceinline__ double dpp_or_zero(double x) {
+    const int xl = __double2loint(x), xh = __double2hiint(x);
+    const int lo = __builtin_amdgcn_update_dpp(xl, xl, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(xh, xh, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// lane l <- lane l-1, lane 0 <- first
+__device__ __forceinline__ double wave_shift_up(double x, double first) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(first), __double2loint(x), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(first), __double2hiint(x), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_lane63(double x) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// Weights of the weighted scan with ratio q: wave-uniform q, q^2, q^4, q^8, q^16 (host-computed, read from the kernarg
+// segment where they are used: SGPR pairs, re-loaded per use instead of 48 VGPRs) and, per lane, q^((l & 15) + 1),
+// q^((l & 31) + 1) -- zero in the rows that broadcast does not feed.
+
+struct ScanWeights {
+    double w15, w31;
+    __device__ __forceinline__ void init(scanq_ptr q, int lane) {
+        const int p = (lane & 15) + 1;                  // 1 .. 16
+        double w = (p & 1) ? q->q1 : 1.0;
+        w = (p & 2) ? w * q->q2 : w;
+        w = (p & 4) ? w * q->q4 : w;
+        w = (p & 8) ? w * q->q8 : w;
+        w = (p & 16) ? q->q16 : w;
+        w15 = (lane & 16) ? w : 0.0;                                    // rows 1 and 3 take the row before them
+        w31 = (lane & 32) ? ((lane & 16) ? w * q->q16 : w) : 0.0;       // rows 2 and 3 take lane 31
+    }
+    // e[l] = sum_{i <= l} q^(l - i) u[i]
+    __device__ __forceinline__ double inclusive(double e, scanq_ptr q) const {
+        e = __builtin_fma(q->q1, dpp_or_zero<0x111>(e), e);        // row_shr:1
+        e = __builtin_fma(q->q2, dpp_or_zero<0x112>(e), e);        // row_shr:2
+        e = __builtin_fma(q->q4, dpp_or_zero<0x114>(e), e);        // row_shr:4
+        e = __builtin_fma(q->q8, dpp_or_zero<0x118>(e), e);        // row_shr:8   -> scans of the four rows of 16
+        e = __builtin_fma(w15, dpp_or_zero<0x142>(e), e);          // row_bcast:15: lane 15 of a row to the next row
+        e = __builtin_fma(w31, dpp_or_zero<0x143>(e), e);          // row_bcast:31: lane 31 to rows 2 and 3
+        return e;
+    }
 };
 
+static void scanq_host(double q, ScanQ* out) {
+    out->q1 = q; out->q2 = q * q; out->q4 = out->q2 * out->q2; out->q8 = out->q4 * out->q4; out->q16 = out->q8 * out->q8;
+}
+
+constexpr int kSeriesBlock = 256;       // four wavefronts = four chunks per workgroup
+
 template <int PASS>
-__global__ void __launch_bounds__(256) series_kernel(const ginsim_mc_params a, const SeriesPlan pl) {
+__global__ void __launch_bounds__(kSeriesBlock) series_kernel(const ginsim_mc_params a, const SeriesPlan pl) {
     __shared__ uint32_t ntab[kNormalTableWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
 
-    MathConsts mk;
-    mk.init<true>();
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= pl.nchunks * a.runs) return;
-    const int64_t r = id % a.runs, c = id / a.runs;        // run fastest: coalesced when there are >= 64 runs
+    const int lane = threadIdx.x & 63;
+    // grid: x = groups of four chunks, y = run; everything below is wave-uniform (SGPRs) except `lane`
+    const int64_t c = (int64_t)blockIdx.x * (kSeriesBlock / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t r = blockIdx.y;
+    if (c >= pl.nchunks) return;
     const int64_t j0 = c * pl.L, j1 = (j0 + pl.L < a.n) ? j0 + pl.L : a.n;
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     double* cb = pl.carry + (r * pl.nchunks + c) * 6;
     const params_ptr kp = kernarg_params();
+    double ga[6], gb[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ga[k] = kp->accel.gm_a[k]; gb[k] = kp->accel.gm_b[k];
+        ga[3 + k] = kp->gyro.gm_a[k]; gb[3 + k] = kp->gyro.gm_b[k];
+    }
+    const plan_ptr kq = kernarg_plan(sizeof(ginsim_mc_params));
+    ScanWeights sw[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sw[k].init(&kq->qa[k], lane);
+
     if (PASS == 0) {
-        Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
-        for (int64_t j = j0; j < j1; ++j) {
+        // chunk-end value from zero: lane l folds its samples j0 + l, j0 + 64 + l, ... with weight a^64, then one scan
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int64_t jb = j0; jb < j1; jb += 64) {
+            const int64_t j = jb + lane;
+            const bool on = j < j1;
             double z0[6], z1[6];
-            normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)j, z0, z1, tab);
-            da.x = __builtin_fma(kp->accel.gm_a[0], da.x, kp->accel.gm_b[0] * z0[0]);
-            da.y = __builtin_fma(kp->accel.gm_a[1], da.y, kp->accel.gm_b[1] * z1[0]);
-            da.z = __builtin_fma(kp->accel.gm_a[2], da.z, kp->accel.gm_b[2] * z0[1]);
-            dg.x = __builtin_fma(kp->gyro.gm_a[0], dg.x, kp->gyro.gm_b[0] * z0[3]);
-            dg.y = __builtin_fma(kp->gyro.gm_a[1], dg.y, kp->gyro.gm_b[1] * z1[3]);
-            dg.z = __builtin_fma(kp->gyro.gm_a[2], dg.z, kp->gyro.gm_b[2] * z0[4]);
+            normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)(on ? j : j1 - 1), z0, z1, tab);
+            const double zd[6] = {z0[0], z1[0], z0[1], z0[3], z1[3], z0[4]};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] = __builtin_fma(kernarg_plan(sizeof(ginsim_mc_params))->a64[k], acc[k], on ? gb[k] * zd[k] : 0.0);
         }
-        cb[0] = da.x; cb[1] = da.y; cb[2] = da.z; cb[3] = dg.x; cb[4] = dg.y; cb[5] = dg.z;
-    } else {
-        Vec3 da{cb[0], cb[1], cb[2]}, dg{cb[3], cb[4], cb[5]};
-        const int64_t plane = a.n * a.runs;
-        for (int64_t j = j0; j < j1; ++j) {
-            const int64_t off = j * a.runs + r;
-            double z0[6], z1[6];
-            normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)j, z0, z1, tab);
-            const Vec3 ta{a.ref_accel[3 * j], a.ref_accel[3 * j + 1], a.ref_accel[3 * j + 2]};
-            const Vec3 tg{a.ref_gyro[3 * j], a.ref_gyro[3 * j + 1], a.ref_gyro[3 * j + 2]};
-            const Vec3 acc = sense3(ta, &kp->accel, da, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
-            const Vec3 gyr = sense3(tg, &kp->gyro, dg, Vec3{z0[3], z1[3], z0[4]}, Vec3{z1[4], z0[5], z1[5]});
-            if (a.out_accel) store3(a.out_accel, plane, off, acc);
-            if (a.out_gyro) store3(a.out_gyro, plane, off, gyr);
-            if (a.out_odo) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double e = sw[k].inclusive(acc[k], &kq->qa[k]);
+            if (lane == 63) cb[k] = e;
+        }
+        return;
+    }
+
+    // ---- pass B
+    const model_ptr ma = &kp->accel, mg = &kp->gyro;
+    double carry[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) carry[k] = as_uniform(cb)[k];
+    double* const oa = a.out_accel ? a.out_accel + r * pl.sr : nullptr;
+    double* const og = a.out_gyro ? a.out_gyro + r * pl.sr : nullptr;
+    double* const oo = a.out_odo ? a.out_odo + r * pl.odo_sr : nullptr;
+    for (int64_t jb = j0; jb < j1; jb += 64) {
+        const int64_t j = jb + lane;
+        const bool on = j < j1;
+        const int64_t jc = on ? j : j1 - 1;
+        const Vec3 ta{a.ref_accel[3 * jc], a.ref_accel[3 * jc + 1], a.ref_accel[3 * jc + 2]};
+        const Vec3 tg{a.ref_gyro[3 * jc], a.ref_gyro[3 * jc + 1], a.ref_gyro[3 * jc + 2]};
+        double z0[6], z1[6];
+        normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)jc, z0, z1, tab);
+        const double zd[6] = {z0[0], z1[0], z0[1], z0[3], z1[3], z0[4]};
+        const double zw[6] = {z1[1], z0[2], z1[2], z1[4], z0[5], z1[5]};
+        double bx[6], d[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            bx[k] = gb[k] * zd[k];
+            double u = on ? bx[k] : 0.0;
+            u = lane == 0 ? __builtin_fma(ga[k], carry[k], bx[k]) : u;     // the drift at the step's first sample enters here
+            const double e = sw[k].inclusive(u, &kernarg_plan(sizeof(ginsim_mc_params))->qa[k]);     // e[l] = drift at sample j + 1
+            d[k] = wave_shift_up(e, carry[k]);                             // drift at sample j
+            carry[k] = wave_lane63(e);
+        }
+        if (on) {
+            // the sums of sense3 (pathgen.py:500, 562), same order of operations
+            double o[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double ua = ma->white_drift[k] ? bx[k] : d[k], ug = mg->white_drift[k] ? bx[3 + k] : d[3 + k];
+                const double tak = k == 0 ? ta.x : (k == 1 ? ta.y : ta.z), tgk = k == 0 ? tg.x : (k == 1 ? tg.y : tg.z);
+                o[k] = tak + ma->bias[k] + ua + ma->white[k] * zw[k];
+                o[3 + k] = tgk + mg->bias[k] + ug + mg->white[k] * zw[3 + k];
+            }
+            if (oa) { st(oa + j * pl.sj, o[0]); st(oa + pl.sc + j * pl.sj, o[1]); st(oa + 2 * pl.sc + j * pl.sj, o[2]); }
+            if (og) { st(og + j * pl.sj, o[3]); st(og + pl.sc + j * pl.sj, o[4]); st(og + 2 * pl.sc + j * pl.sj, o[5]); }
+            if (oo) {
                 double y0, y1;
                 normal_pair(key, S_ODO, (uint32_t)j, y0, y1, tab);
-                a.out_odo[off] = kp->odo_scale * a.ref_odo[j] + kp->odo_stdv * y0;
+                st(oo + j * pl.odo_sj, kp->odo_scale * a.ref_odo[j] + kp->odo_stdv * y0);     // pathgen.py:639-640
             }
         }
     }
 }
 
-// chunk-end values -> chunk-start values, one thread per (run, axis); the loads do not depend on the recurrence
-__global__ void series_scan_kernel(const SeriesPlan pl, int64_t runs) {
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// chunk-end values -> chunk-start values, one wavefront per (run, axis): start[0] = 0, start[k+1] = a^L start[k] + end[k]
+// is the weighted scan again (ratio a^L), 64 chunks per step
+__global__ void __launch_bounds__(64) series_scan_kernel(const SeriesPlan pl, int64_t runs) {
+    const int lane = threadIdx.x;
+    const int64_t id = blockIdx.x;
     if (id >= runs * 6) return;
     const int64_t r = id / 6;
     const int k = (int)(id % 6);
     double* cb = pl.carry + r * pl.nchunks * 6 + k;
-    const double ap = pl.a_pow[k];
-    double start = 0.0;
-    for (int64_t c = 0; c < pl.nchunks; ++c) {
-        const double end = cb[c * 6];
-        cb[c * 6] = start;
-        start = __builtin_fma(ap, start, end);
+    const scanq_ptr q = &kernarg_plan(0)->qL[k];
+    ScanWeights sw;
+    sw.init(q, lane);
+    double carry = 0.0;                                  // start value of chunk cbase
+    for (int64_t cbase = 0; cbase < pl.nchunks; cbase += 64) {
+        const int64_t c = cbase + lane;
+        const bool on = c < pl.nchunks;
+        double u = on ? cb[c * 6] : 0.0;
+        u = lane == 0 ? __builtin_fma(pl.a_pow[k], carry, u) : u;
+        const double e = sw.inclusive(u, q);             // start of chunk c + 1
+        const double s = wave_shift_up(e, carry);        // start of chunk c
+        carry = wave_lane63(e);
+        if (on) cb[c * 6] = s;
     }
 }
 
 // sensors only, few runs, long series
 bool series_path_applies(const ginsim_mc_params& p) {
     return p.algo_mask == 0 && !p.given_sensors && p.precision == 0 && !p.wave_trace && p.block_threads == 0 &&
-           p.runs <= 1024 && p.n >= 2048;
+           p.runs <= 1024 && p.n >= 2048 && (p.sensor_layout == 1 || p.runs == 1);
 }
 
 int64_t series_chunks(const ginsim_mc_params& p, int32_t* L_out) {
-    // ~8192 threads over the chip, chunks of at least 64 samples
-    int64_t L = (p.n * p.runs + 8191) / 8192;
-    if (L < 64) L = 64;
-    if (L > 4096) L = 4096;
+    // ~16 384 wavefronts over the chip (1024 SIMDs, several rounds of a few wavefronts each), chunks of 256 .. 8192 samples in
+    // whole wave-steps, and at most 1024 chunks per run (pass S walks them 64 at a time)
+    int64_t L = (p.n * p.runs + 16383) / 16384;
+    const int64_t lmin = (p.n + 1023) / 1024;
+    if (L < lmin) L = lmin;
+    if (L < 256) L = 256;
+    if (L > 8192) L = 8192;
+    L = (L + 63) / 64 * 64;
     *L_out = (int32_t)L;
     return (p.n + L - 1) / L;
 }
@@ -812,11 +956,16 @@ hipError_t launch_series(const ginsim_mc_params& p, double* carry, hipStream_t s
         double v = 1.0;
         for (int i = 0; i < pl.L; ++i) v *= aa;
         pl.a_pow[k] = v;
+        scanq_host(aa, &pl.qa[k]);
+        scanq_host(v, &pl.qL[k]);
+        pl.a64[k] = pl.qa[k].q16 * pl.qa[k].q16 * pl.qa[k].q16 * pl.qa[k].q16;
     }
-    const int64_t threads = pl.nchunks * p.runs;
-    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    pl.pad = 0;
+    if (p.sensor_layout == 1) { pl.sr = 3 * p.n; pl.sc = p.n; pl.sj = 1; pl.odo_sr = p.n; pl.odo_sj = 1; }
+    else { pl.sr = 1; pl.sc = p.n * p.runs; pl.sj = p.runs; pl.odo_sr = 1; pl.odo_sj = p.runs; }     // runs == 1: the same thing
+    const dim3 grid((unsigned)((pl.nchunks + kSeriesBlock / 64 - 1) / (kSeriesBlock / 64)), (unsigned)p.runs), block(kSeriesBlock);
     hipLaunchKernelGGL((series_kernel<0>), grid, block, 0, stream, p, pl);
-    hipLaunchKernelGGL(series_scan_kernel, dim3((unsigned)((p.runs * 6 + 63) / 64)), dim3(64), 0, stream, pl, p.runs);
+    hipLaunchKernelGGL(series_scan_kernel, dim3((unsigned)(p.runs * 6)), dim3(64), 0, stream, pl, p.runs);
     hipLaunchKernelGGL((series_kernel<1>), grid, block, 0, stream, p, pl);
     return hipGetLastError();
 }
@@ -921,6 +1070,25 @@ __global__ void gather_runs_kernel(const double* __restrict__ series, int C, int
     const int64_t j = (idx / C) % n;
     const int64_t k = idx / (C * n);
     out[idx] = series[((int64_t)c * n + j) * runs + ids[k]];
+}
+
+// the same from a series-major buffer [runs][C][n] (sensor_layout 1): out [nsel][n][C]
+__global__ void gather_series_kernel(const double* __restrict__ series, int C, int64_t n, const int64_t* __restrict__ ids, int nsel,
+                                     double* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over nsel*C*n, sample fastest (the reads coalesce)
+    const int64_t total = (int64_t)nsel * n * C;
+    if (idx >= total) return;
+    const int64_t j = idx % n;
+    const int c = (int)((idx / n) % C);
+    const int64_t k = idx / (n * C);
+    out[(k * n + j) * C + c] = series[(ids[k] * C + c) * n + j];
+}
+
+hipError_t launch_gather_series(const double* series, int C, int64_t n, const int64_t* ids, int nsel, double* out, hipStream_t s) {
+    const int tb = 256;
+    const int64_t total = (int64_t)nsel * n * C;
+    hipLaunchKernelGGL(gather_series_kernel, dim3((unsigned)((total + tb - 1) / tb)), dim3(tb), 0, s, series, C, n, ids, nsel, out);
+    return hipGetLastError();
 }
 
 // The normal transform on given words (test hook): words 0-1 are taken as one half block -- z0 from word 0, z1 from

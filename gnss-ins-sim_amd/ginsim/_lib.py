@@ -42,7 +42,7 @@ class McParams(C.Structure):
                 ('wave_trace', C.c_void_p), ('block_threads', C.c_int32), ('end_pos_ned', C.c_int32),
                 ('precision', C.c_int32), ('proc_pos_ned', C.c_int32),
                 ('ref_nav', C.c_void_p), ('proc_first', C.c_int64), ('out_proc', C.c_void_p * 2),
-                ('out_end_ned', C.c_void_p * 2)]
+                ('out_end_ned', C.c_void_p * 2), ('sensor_layout', C.c_int32), ('reserved4', C.c_int32)]
 
 
 class PathgenParams(C.Structure):
@@ -104,6 +104,8 @@ _SIGS = {
     'ginsim_stats_merge': (C.c_int, [C.POINTER(Stats), C.c_int32, C.POINTER(Stats)]),
     'ginsim_gather_runs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
                                      C.POINTER(C.c_int64), C.c_int32, _PD]),
+    'ginsim_gather_series': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
+                                       C.POINTER(C.c_int64), C.c_int32, _PD]),
     'ginsim_gather_runs_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
                                          C.POINTER(C.c_int64), C.c_int32, _PD]),
     'ginsim_free_integration': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, _PD, _PD, _PD,

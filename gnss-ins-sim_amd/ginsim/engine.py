@@ -50,8 +50,9 @@ class DeviceBuffer(object):
 class DeviceView(object):
     """A sub-range of a DeviceBuffer (not owning)."""
 
-    def __init__(self, parent, byte_offset, nbytes):
+    def __init__(self, parent, byte_offset, nbytes, layout='runs'):
         self.parent, self.ptr, self.nbytes = parent, parent.ptr + int(byte_offset), int(nbytes)
+        self.layout = layout        # 'runs': [axis][sample][run] (run fastest); 'series': [run][axis][sample]
 
     def at(self, byte_offset):
         return self.ptr + int(byte_offset)
@@ -281,6 +282,10 @@ class MonteCarloJob(object):
     that are already on the device in the engine's [component][sample][run] fp64 layout -- e.g. the 'gyro'/'accel'
     buffers another job materialised -- which are then integrated as they are (the plugin's run(set_of_input)
     boundary for a whole batch; accel_err / gyro_err may be None).  precision='f32' rounds them to float as it reads them.
+
+    Sensors-only jobs (algos=()) of few runs and long series (<= 1024 runs, >= 2048 samples) run on the time-parallel series
+    kernels and keep their series SERIES-major, [run][axis][sample] (``sensor_layout == 'series'``; ginsim_mc_params.sensor_layout
+    1): that is the layout ginsim_allan reads, so ``allan()`` needs no re-layout.  ``sensors()`` hides the difference.
     """
 
     def __init__(self, ctx, fs, ref_frame, truth, accel_err, gyro_err, ini, runs, algos=('free',),
@@ -304,6 +309,9 @@ class MonteCarloJob(object):
                 size = (1 if k == 'odo' else 3) * self.n * self.runs * 8
                 if k not in given or given[k].nbytes < size:
                     raise ValueError('given sensors: %r missing or smaller than %d bytes' % (k, size))
+                if getattr(given[k], 'layout', 'runs') != 'runs':
+                    raise ValueError('given sensors: %r is series-major ([run][axis][sample]); the mechanisation reads '
+                                     '[axis][sample][run]' % (k,))
             self.want_odo = False
         p = self.params = _lib.McParams()
         p.n, p.runs, p.run_offset, p.seed = self.n, self.runs, int(run_offset), int(seed) & (2 ** 64 - 1)
@@ -352,14 +360,26 @@ class MonteCarloJob(object):
         self._ini_table, self._ini_first, self._ref_frame = table, int(ini_first), int(ref_frame)
         # outputs
         plane = self.n * self.runs * self._esize
+        self.sensor_layout = 'runs'
         if self.keep_sensors:
-            # one allocation, accel then gyro: for a single run that IS the [sensor][axis][n] layout ginsim_allan reads
+            if not self.algos and given is None and precision == 'f64':
+                # few runs, long series: the time-parallel series kernels, series-major output (the library decides)
+                p.sensor_layout = 1
+                v = C.c_int32(0)
+                check(lib.ginsim_mc_variant(C.byref(p), C.byref(v)))
+                if v.value == 2:
+                    self.sensor_layout = 'series'
+                else:
+                    p.sensor_layout = 0
+            lay = self.sensor_layout
+            # one allocation, accel then gyro: series-major (or one run) that IS the [sensor][run][axis][n] layout ginsim_allan reads
             self._bufs['imu'] = ctx.malloc(6 * plane)
-            self._bufs['accel'] = DeviceView(self._bufs['imu'], 0, 3 * plane)
-            self._bufs['gyro'] = DeviceView(self._bufs['imu'], 3 * plane, 3 * plane)
+            self._bufs['accel'] = DeviceView(self._bufs['imu'], 0, 3 * plane, lay)
+            self._bufs['gyro'] = DeviceView(self._bufs['imu'], 3 * plane, 3 * plane, lay)
             p.out_accel, p.out_gyro = self._bufs['accel'].ptr, self._bufs['gyro'].ptr
             if self.want_odo:
                 self._bufs['odo'] = ctx.malloc(plane)
+                self._bufs['odo'].layout = lay
                 p.out_odo = self._bufs['odo'].ptr
         self.proc_first, self.proc_ned, self.end_ned = proc_first, bool(proc_ned), bool(end_ned)
         if proc_first is not None:
@@ -398,9 +418,9 @@ class MonteCarloJob(object):
         fs = float(self.params.fs if fs is None else fs)
         names = tuple(names)
         per = 3 * self.n * self.runs * 8
-        contiguous = self.runs == 1 and all(self._bufs[names[i + 1]].ptr == self._bufs[names[i]].ptr + per
-                                            for i in range(len(names) - 1))
-        if contiguous:
+        contiguous = (self.runs == 1 or self.sensor_layout == 'series') and \
+            all(self._bufs[names[i + 1]].ptr == self._bufs[names[i]].ptr + per for i in range(len(names) - 1))
+        if contiguous:              # already [sensor][run][axis][n]: the Allan kernels read the job's own buffer
             ptr = self._bufs[names[0]].ptr
         else:
             # the re-laid-out copy lives with the job (released with it): a 2 GB hipMalloc + hipFree per call cost 0.4 ms,
@@ -411,7 +431,10 @@ class MonteCarloJob(object):
                     tmp.free()
                 tmp = self._bufs['_allan_layout'] = self.ctx.malloc(per * len(names))
             for i, nm in enumerate(names):      # one run: C = 3, R = 1 makes the re-layout a plain copy
-                check(lib.ginsim_runs_to_series(self.ctx.handle, self._bufs[nm].ptr, 3, self.n, self.runs, tmp.at(i * per)))
+                if self.sensor_layout == 'series':
+                    check(lib.ginsim_runs_to_series(self.ctx.handle, self._bufs[nm].ptr, 1, 3 * self.n * self.runs, 1, tmp.at(i * per)))
+                else:
+                    check(lib.ginsim_runs_to_series(self.ctx.handle, self._bufs[nm].ptr, 3, self.n, self.runs, tmp.at(i * per)))
             ptr = tmp.ptr
         avar, tau = allan_var(self.ctx, ptr, self.n, 3 * self.runs * len(names), self.n, fs)
         ad = np.sqrt(avar).reshape(len(names), self.runs, 3, -1)
@@ -509,10 +532,10 @@ class MonteCarloJob(object):
         """(runs, 9) end-point errors [att3 wrapped, pos3, vel3]; ned=True: the NED record (end_ned=True)."""
         return self.ctx.download(self._bufs[('endned_' if ned else 'end_') + algo], (9, self.runs)).T.copy()
 
-    def _gather(self, ptr, ncomp, run_ids):
+    def _gather(self, ptr, ncomp, run_ids, series_major=False):
         ids = np.ascontiguousarray(np.asarray(run_ids, dtype=np.int64).reshape(-1))
         out = np.empty((ids.size, self.n, ncomp))
-        fn = lib.ginsim_gather_runs_f32 if self.precision == 'f32' else lib.ginsim_gather_runs
+        fn = lib.ginsim_gather_runs_f32 if self.precision == 'f32' else (lib.ginsim_gather_series if series_major else lib.ginsim_gather_runs)
         check(fn(self.ctx.handle, ptr, ncomp, self.n, self.runs, ids.ctypes.data_as(C.POINTER(C.c_int64)), ids.size,
                  dptr(out)))
         return out
@@ -521,9 +544,10 @@ class MonteCarloJob(object):
         """Sensor series of selected runs: 'accel'/'gyro' -> (k,n,3); 'odo' -> (k,n)."""
         if not self.keep_sensors:
             raise ValueError('sensor series were not kept (keep_sensors=False)')
+        sm = self.sensor_layout == 'series'
         if name == 'odo':
-            return self._gather(self._bufs['odo'].ptr, 1, run_ids)[:, :, 0]
-        return self._gather(self._bufs[name].ptr, 3, run_ids)
+            return self._gather(self._bufs['odo'].ptr, 1, run_ids, sm)[:, :, 0]
+        return self._gather(self._bufs[name].ptr, 3, run_ids, sm)
 
     def trajectories(self, algo, run_ids, displacement=False):
         """(att, pos, vel) of selected runs, each (k,n,3).  displacement=True (fp32 jobs): the position series as the kernel

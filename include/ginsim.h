@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define GINSIM_ABI_VERSION 3
+#define GINSIM_ABI_VERSION 4
 
 /* status codes */
 #define GINSIM_OK          0
@@ -145,14 +145,24 @@ typedef struct {
                                * generate mode, fp64. */
     double*   out_end_ned[2]; /* per algorithm bit: [9][runs] end-point error with the position error in local NED metres
                                * (extra_opt='ned', ins_data_manager.py:542-552) next to out_end, or NULL (ref_frame 0 only) */
+    /* ---- ABI 4 ---- */
+    int32_t   sensor_layout;  /* layout of out_accel / out_gyro / out_odo.  0 (default): [axis][sample][run], run fastest -- what
+                               * the lane-per-run kernels write.  1: SERIES-major [run][axis][sample] ([run][sample] for the
+                               * odometer) -- every series contiguous, the input layout of ginsim_allan (series_stride = n) and of
+                               * the reference's own per-run arrays dmgr.accel.data[i] (ins_sim.py:491-496).  Only sensors-only
+                               * launches (algo_mask 0) take it; with <= 1024 runs and >= 2048 samples they run on the
+                               * time-parallel series kernels (ginsim_mc_variant reports 2), otherwise layout 1 is refused. */
+    int32_t   reserved4;
 } ginsim_mc_params;
 
 int ginsim_mc_run(ginsim_ctx* ctx, const ginsim_mc_params* p);
 
-/* Which kernel ginsim_mc_run would launch for these parameters (telemetry for profiles; results are bit-identical):
- * 0 = one wavefront per 64 runs does noise + mechanisation (mc_kernel / mc_kernel_f32), 1 = wave-specialised
+/* Which kernel ginsim_mc_run would launch for these parameters (telemetry for profiles; results are bit-identical between
+ * 0 and 1): 0 = one wavefront per 64 runs does noise + mechanisation (mc_kernel / mc_kernel_f32), 1 = wave-specialised
  * producer/consumer workgroups (mc_kernel_split / mc_kernel_f32_split), chosen for batches of <= 1024 wavefronts and,
- * for one algorithm in ref_frame 1 (two producer groups: three wavefronts per SIMD), at every size. */
+ * for one algorithm in ref_frame 1 (two producer groups: three wavefronts per SIMD), at every size; 2 (ABI 4) = the
+ * time-parallel series kernels (sensors only, <= 1024 runs, >= 2048 samples, sensor_layout 1 or one run): a lane is a
+ * SAMPLE, the Gauss-Markov recurrence a weighted scan -- same normals, sums associated differently (an ulp of the terms). */
 int ginsim_mc_variant(const ginsim_mc_params* p, int32_t* variant);
 /* ABI 3: the NAME of that kernel as rocprofv3 reports it, without arguments (e.g. "ginsim::mc_kernel_split<1, 1, false, 2,
  * true>"), written by the same dispatch code that launches it -- profiles and bench.py attribute to what really runs. */
@@ -228,6 +238,9 @@ int ginsim_stats_merge(const ginsim_stats* parts, int32_t nparts, ginsim_stats* 
 /* ---- data access: pull selected runs out of a [ncomp][n][runs] device series into host [nsel][n][ncomp] */
 int ginsim_gather_runs(ginsim_ctx* ctx, const double* series, int32_t ncomp, int64_t n, int64_t runs,
                        const int64_t* run_ids /*host*/, int32_t nsel, double* host_out);
+/* same for a SERIES-major sensor buffer (sensor_layout 1): series [runs][ncomp][n] -> host [nsel][n][ncomp] */
+int ginsim_gather_series(ginsim_ctx* ctx, const double* series, int32_t ncomp, int64_t n, int64_t runs,
+                         const int64_t* run_ids /*host*/, int32_t nsel, double* host_out);
 /* same for a float series written by the fp32 kernel (values widened to double on the way out) */
 int ginsim_gather_runs_f32(ginsim_ctx* ctx, const float* series, int32_t ncomp, int64_t n, int64_t runs,
                            const int64_t* run_ids /*host*/, int32_t nsel, double* host_out);
