@@ -119,47 +119,29 @@ def cpu_baseline(fs, rf, ini, truth, acc, gyr, budget_s):
 
 
 def reference_python_baseline(budget_s):
-    """The reference's own CPU path (Sim.run on config 1, it is single-threaded): timed here when the reference is
-    importable (the build container), otherwise the figure BASELINE.md measured, labelled as quoted."""
+    """The reference's own CPU path on config 1: one core (it is single-threaded; split into noise generation / plugin / rest
+    as BASELINE.md section 2 does) AND all host cores (multiprocessing over Sim.run(R / P)).  Timed here by
+    tools/time_reference.py when the reference is importable (the build container), otherwise the committed, host-stamped
+    record of that tool (profiles/reference_cpu.json), labelled as quoted."""
     ref = '/root/reference'
     if os.path.isdir(os.path.join(ref, 'gnss_ins_sim')):
-        code = (
-            "import sys, time, os, io, contextlib\n"
-            "sys.dont_write_bytecode = True\n"
-            "os.environ.setdefault('MPLBACKEND', 'Agg')\n"
-            "sys.path.insert(0, %r)\n"
-            "import numpy as np\n"
-            "from gnss_ins_sim.sim import imu_model, ins_sim\n"
-            "from demo_algorithms import free_integration\n"
-            "csv = %r + '/demo_motion_def_files/motion_def-90deg_turn.csv'\n"
-            "ini = np.genfromtxt(csv, delimiter=',', skip_header=1, max_rows=1)\n"
-            "ini[0:2] *= np.pi / 180; ini[6:9] *= np.pi / 180\n"
-            "R = %d\n"
-            "np.random.seed(2024)\n"
-            "imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False)\n"
-            "sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, algorithm=free_integration.FreeIntegration(ini))\n"
-            "t0 = time.perf_counter()\n"
-            "with contextlib.redirect_stdout(io.StringIO()):\n"
-            "    sim.run(R)\n"
-            "print(R, 1000, time.perf_counter() - t0)\n")
-        runs = max(10, int(budget_s * 4.76e4 / 1000))
+        runs = max(20, int(budget_s * 4.5e4 / 1000))
         try:
-            out = subprocess.run([sys.executable, '-c', code % (ref, ref, runs)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                 timeout=20 * budget_s + 60, universal_newlines=True, cwd=tempfile.gettempdir())
-            r, n, dt = out.stdout.split()[-3:]
-            return {'value': int(r) * int(n) / float(dt), 'unit': 'sample*MC/s', 'cores': 1, 'kind': 'reference',
-                    'sample': 'unmodified reference Sim.run(%s) on config 1 (90-degree turn @100 Hz, mid-accuracy, ref_frame 1), '
-                              '%.1f s, single-threaded by construction' % (r, float(dt))}
+            out = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'time_reference.py'), '--runs', str(runs), '--json',
+                                  '--no-write'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=40 * budget_s + 120,
+                                 universal_newlines=True, cwd=tempfile.gettempdir(), env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+            rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+            rec['kind'] = 'reference'
+            return rec
         except Exception as e:                                     # noqa: BLE001 -- a baseline must not fail the bench
             return {'value': None, 'kind': 'reference', 'error': repr(e)[:200]}
-    # not importable here (the GPU box): the committed, host-stamped timing of the unmodified reference made by
-    # tools/time_reference.py in the build container (profiles/reference_cpu.json), else the BASELINE.md figure
     try:
         with open(os.path.join(REPO, 'profiles', 'reference_cpu.json')) as f:
             rec = json.load(f)
-        return {'value': rec['value'], 'unit': 'sample*MC/s', 'cores': 1, 'kind': 'quoted',
-                'sample': 'profiles/reference_cpu.json: %s (host %s, %s); /root/reference does not exist on this host, so it is '
-                          'not timed here' % (rec['sample'], rec.get('host', '?'), rec.get('date', '?'))}
+        rec['kind'] = 'quoted'
+        rec['quoted_from'] = ('profiles/reference_cpu.json (host %s, %s): /root/reference does not exist on this host, so the '
+                              'reference is not timed here' % (rec.get('host', '?'), rec.get('date', '?')))
+        return rec
     except (OSError, ValueError, KeyError):
         return {'value': 4.76e4, 'unit': 'sample*MC/s', 'cores': 1, 'kind': 'quoted',
                 'sample': 'BASELINE.md section 2: unmodified reference Sim.run(1000) on config 1 in the survey container (Xeon 2.1 GHz, '
@@ -589,25 +571,36 @@ def main():
         prewarm_ms += ctx.timer_end()
         done += 1
 
-    # N > 1: the same per-GPU load on ONE GPU while the other ranks wait -- the reference point scaling efficiency needs
+    # N > 1: the same per-GPU load on ONE GPU at a time while the other ranks wait -- the reference point scaling efficiency
+    # needs, from EVERY rank (a slow GPU shows up here before it shows up as the step time of the whole job)
     single = None
     if use_dist and world > 1:
+        mine = None
+        for turn in range(world):
+            fence()
+            if rank == turn:
+                k = max(2, min(args.steps, 20))
+                ctx.sync()
+                t0 = time.perf_counter()
+                for s in range(k):
+                    job.params.run_offset = s * R
+                    job.launch()
+                    job.stats_begin('free', s & 1)
+                    job.stats_finish(s & 1)
+                ctx.sync()
+                dt = time.perf_counter() - t0
+                mine = {'rank': rank, 'value': R * n * k / dt, 'ms_per_step': dt / k * 1e3, 'steps': k}
         fence()
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
         if rank == 0:
-            k = max(2, min(args.steps, 20))
-            ctx.sync()
-            t0 = time.perf_counter()
-            for s in range(k):
-                job.params.run_offset = s * R
-                job.launch()
-                job.stats_begin('free', s & 1)
-                job.stats_finish(s & 1)
-            ctx.sync()
-            dt = time.perf_counter() - t0
-            single = {'value': R * n * k / dt, 'unit': 'sample*MC/s', 'ms_per_step': dt / k * 1e3, 'steps': k, 'runs': R,
-                      'note': 'rank 0 alone (the other ranks idle at a barrier), same runs per GPU, launch + device reduction per '
-                              'step, no exchange: efficiency(N) = value / (N x this)'}
-        fence()
+            vals = [e['value'] for e in everyone]
+            single = {'value': everyone[0]['value'], 'unit': 'sample*MC/s', 'ms_per_step': everyone[0]['ms_per_step'],
+                      'steps': everyone[0]['steps'], 'runs': R,
+                      'every_rank': {'value': vals, 'min': min(vals), 'max': max(vals), 'argmin': int(np.argmin(vals))},
+                      'note': 'each rank alone in turn (the other ranks idle at a barrier), same runs per GPU, launch + device '
+                              'reduction per step, no exchange: efficiency(N) = value / (N x this); `value` is rank 0, `every_rank` '
+                              'lists all of them'}
 
     if exchange == 'abi':
         # one batch through BOTH exchanges before anything is timed: the library's all-gather must give the record the
@@ -642,6 +635,14 @@ def main():
 
     kern_ms = [ctx.event_elapsed(2 * (s // stride), 2 * (s // stride) + 1) for s in range(args.warmup, nsteps) if s % stride == 0]
     kern_avg_ms = float(np.mean(kern_ms))
+    per_rank = None
+    if use_dist and world > 1:          # the slowest GPU sets the step time: make it visible in the line
+        rows = [None] * world
+        dist.all_gather_object(rows, {'rank': rank, 'kernel_ms_avg': kern_avg_ms, 'kernel_ms_max': float(np.max(kern_ms)),
+                                      'device': ctx.name()})
+        ks = [r['kernel_ms_avg'] for r in rows]
+        per_rank = {'kernel_ms_avg': ks, 'min': min(ks), 'max': max(ks), 'argmax': int(np.argmax(ks)),
+                    'kernel_ms_max': [r['kernel_ms_max'] for r in rows]}
     assert merged.count == world * R, (merged.count, world * R)
 
     if args.pmc_child:      # every kernel a roofline object of the line is about, in the same passes
@@ -712,6 +713,8 @@ def main():
         }
         if single is not None:
             out['per_gpu_single'] = single
+        if per_rank is not None:
+            out['per_rank'] = per_rank
         if world == 1 and not args.no_legs:
             legs = []
             if keep and args.precision == 'f64':

@@ -71,6 +71,11 @@ struct Comm {
     int nranks = 0, rank = 0;
 };
 
+const char* comm_probe() {
+    Api& a = api();
+    return a.ok ? nullptr : a.err;
+}
+
 const char* comm_unique_id(unsigned char* id128) {
     Api& a = api();
     if (!a.ok) return a.err;

@@ -8,6 +8,7 @@ namespace ginsim {
 struct Comm;     // one RCCL communicator (one rank) bound to a context's device
 
 // nullptr + message on failure; the library is dlopen()ed on first use, so single-GPU users never load RCCL
+const char* comm_probe();        // can librccl be reached at all? (dlopen + dlsym only: no bootstrap socket, no thread)
 const char* comm_unique_id(unsigned char* id128);
 const char* comm_create(int nranks, int rank, const unsigned char* id128, Comm** out);
 void comm_destroy(Comm* c);

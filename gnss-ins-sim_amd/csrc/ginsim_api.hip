@@ -51,6 +51,8 @@ hipError_t launch_end_stats(const double* end_err, int64_t runs, void* scratch, 
 void stats_merge_host(const ginsim_stats* parts, int nparts, ginsim_stats* out);
 hipError_t launch_process_stats(const double* traj, const double* ref, int64_t n, int64_t runs, int64_t j0, int pos_ned,
                                 int run_major, double* out, hipStream_t s);
+hipError_t launch_process_stats_f32(const float* traj, const double* ref, int64_t n, int64_t runs, int64_t j0, int pos_ned,
+                                    int run_major, double* out, const double* origin, int64_t n_ini, uint64_t ini_first, hipStream_t s);
 
 
 }  // namespace ginsim
@@ -455,10 +457,26 @@ int ginsim_comm_init(ginsim_ctx* c, int32_t nranks, int32_t rank, const unsigned
     REQUIRE(c && id && nranks >= 1 && rank >= 0 && rank < nranks, "comm_init: bad arguments");
     REQUIRE(!c->comm, "comm_init: this context already has a communicator");
     HIP_TRY(hipSetDevice(c->device));
-    const char* err = comm_create(nranks, rank, id, &c->comm);
-    if (err) { set_error("comm_init: %s", err); return GINSIM_ERR_HIP; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->comm_recv), sizeof(ginsim_stats) * 8 * (size_t)nranks));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->comm_host), sizeof(ginsim_stats) * 8 * (size_t)nranks, hipHostMallocDefault));
+    // the buffers first: a failure here must not leave a communicator behind (the other ranks would already be inside the
+    // collective ncclCommInitRank, and a retry on this context would be refused)
+    const size_t bytes = sizeof(ginsim_stats) * 8 * (size_t)nranks;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->comm_recv), bytes);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->comm_host), bytes, hipHostMallocDefault);
+    const char* err = e == hipSuccess ? comm_create(nranks, rank, id, &c->comm) : nullptr;
+    if (e != hipSuccess || err) {
+        if (c->comm_recv) { (void)hipFree(c->comm_recv); c->comm_recv = nullptr; }
+        if (c->comm_host) { (void)hipHostFree(c->comm_host); c->comm_host = nullptr; }
+        c->comm = nullptr;
+        if (err) set_error("comm_init: %s", err);
+        else set_error("comm_init: %s", hipGetErrorString(e));
+        return GINSIM_ERR_HIP;
+    }
+    return GINSIM_OK;
+}
+
+int ginsim_comm_probe(void) {
+    const char* err = comm_probe();
+    if (err) { set_error("comm_probe: %s", err); return GINSIM_ERR_HIP; }
     return GINSIM_OK;
 }
 
@@ -477,7 +495,7 @@ int ginsim_comm_destroy(ginsim_ctx* c) {
 
 int ginsim_end_stats_all_begin(ginsim_ctx* c, const double* end_err, int64_t runs, int32_t slot) {
     REQUIRE(c && runs >= 0 && (runs == 0 || end_err) && slot >= 0 && slot < 8, "end_stats_all_begin: bad arguments");
-    REQUIRE(c->comm, "end_stats_all_begin: no communicator (ginsim_comm_init)");
+    REQUIRE(c->comm && c->comm_recv && c->comm_host, "end_stats_all_begin: no communicator (ginsim_comm_init)");
     REQUIRE(!c->comm_pending[slot], "end_stats_all_begin: slot %d is still pending (call ginsim_end_stats_all_finish first)", slot);
     HIP_TRY(hipSetDevice(c->device));
     if (!c->comm_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&c->comm_ev[slot], hipEventDisableTiming));
@@ -535,6 +553,32 @@ int ginsim_end_stats_from_traj(ginsim_ctx* c, const double* traj, const double* 
     HIP_TRY(scratch(c, 2, sizeof(double) * 27 * (size_t)runs, &ws));
     // a one-sample window: the "mean" plane [9][runs] of the process kernel IS the end-point error
     HIP_TRY(launch_process_stats(traj, ref, n, runs, n - 1, pos_ned, 0, reinterpret_cast<double*>(ws), c->stream));
+    return ginsim_end_stats(c, reinterpret_cast<double*>(ws) + (size_t)9 * runs, runs, host_out);
+}
+
+int ginsim_process_stats_f32(ginsim_ctx* c, const float* traj, const double* ref, int64_t n, int64_t runs, int64_t first_sample,
+                             int32_t pos_ned, const double* origin, int32_t n_ini, uint64_t ini_first, double* host_out) {
+    REQUIRE(c && traj && ref && origin && host_out, "process_stats_f32: NULL argument");
+    REQUIRE(n >= 1 && runs >= 1 && first_sample >= 0 && first_sample < n && n_ini >= 1, "process_stats_f32: bad sizes");
+    HIP_TRY(hipSetDevice(c->device));
+    void* ws = nullptr;
+    const size_t bytes = sizeof(double) * 27 * (size_t)runs;
+    HIP_TRY(scratch(c, 2, bytes, &ws));
+    HIP_TRY(launch_process_stats_f32(traj, ref, n, runs, first_sample, pos_ned, 1, reinterpret_cast<double*>(ws), origin, n_ini,
+                                     ini_first, c->stream));
+    HIP_TRY(hipMemcpyAsync(host_out, ws, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GINSIM_OK;
+}
+
+int ginsim_end_stats_from_traj_f32(ginsim_ctx* c, const float* traj, const double* ref, int64_t n, int64_t runs, int32_t pos_ned,
+                                   const double* origin, int32_t n_ini, uint64_t ini_first, ginsim_stats* host_out) {
+    REQUIRE(c && traj && ref && origin && host_out && n >= 1 && runs >= 1 && n_ini >= 1, "end_stats_from_traj_f32: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    void* ws = nullptr;
+    HIP_TRY(scratch(c, 2, sizeof(double) * 27 * (size_t)runs, &ws));
+    HIP_TRY(launch_process_stats_f32(traj, ref, n, runs, n - 1, pos_ned, 0, reinterpret_cast<double*>(ws), origin, n_ini, ini_first,
+                                     c->stream));
     return ginsim_end_stats(c, reinterpret_cast<double*>(ws) + (size_t)9 * runs, runs, host_out);
 }
 

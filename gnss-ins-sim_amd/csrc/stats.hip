@@ -92,9 +92,19 @@ __device__ __forceinline__ double angle_range_pi_mul(double x) {
     return m > kPi ? m - kTwoPi : m;
 }
 
-__global__ void __launch_bounds__(64 * kSeg) process_stats_kernel(const double* __restrict__ traj, const double* __restrict__ ref,
+// T = float: the series of the fp32 kernel -- the position planes hold the DISPLACEMENT from the run's initial position
+// (ginsim_mc_params.precision), so the position of a sample is origin[run's initial state] + displacement, formed in fp64;
+// everything after that (errors, moments) is the fp64 arithmetic of the double version.
+struct ProcOrigin {
+    const double* table;    // device [n_ini][3]: ECEF (ref_frame 1) or LLA (ref_frame 0) of every initial state, or nullptr (T = double)
+    int64_t n_ini;
+    uint64_t ini_first;     // the run's initial state is row (ini_first + run < n_ini ? ini_first + run : 0), as in the MC kernels
+};
+
+template <typename T>
+__global__ void __launch_bounds__(64 * kSeg) process_stats_kernel(const T* __restrict__ traj, const double* __restrict__ ref,
                                                                  int64_t n, int64_t runs, int64_t j0, int pos_ned,
-                                                                 int run_major, double* __restrict__ out) {
+                                                                 int run_major, double* __restrict__ out, const ProcOrigin org) {
     __shared__ Mom part[kSeg][9][64];
     const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * 64 + lane;
@@ -107,11 +117,18 @@ __global__ void __launch_bounds__(64 * kSeg) process_stats_kernel(const double* 
 #pragma unroll
     for (int c = 0; c < 9; ++c) { mean[c] = 0.0; m2[c] = 0.0; mx[c] = 0.0; }
     double cnt = 0.0;
+    double o3[3] = {0.0, 0.0, 0.0};
+    if (org.table && active) {
+        const uint64_t call = org.ini_first + (uint64_t)r;
+        const double* row = org.table + 3 * (call < (uint64_t)org.n_ini ? call : 0);
+        o3[0] = row[0]; o3[1] = row[1]; o3[2] = row[2];
+    }
     if (active) {
         for (int64_t j = jb; j < je; ++j) {
             double x[9], t[9], e[9];
 #pragma unroll
-            for (int c = 0; c < 9; ++c) { x[c] = traj[c * plane + j * runs + r]; t[c] = truth[9 * j + c]; }
+            for (int c = 0; c < 9; ++c) { x[c] = (double)traj[c * plane + j * runs + r]; t[c] = truth[9 * j + c]; }
+            x[3] += o3[0]; x[4] += o3[1]; x[5] += o3[2];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {       // wrapped only when outside [-pi, pi], exactly as the online accumulator does (mc_kernel.hip wrap_pi3)
                 const double d = x[c] - t[c];
@@ -163,8 +180,15 @@ __global__ void __launch_bounds__(64 * kSeg) process_stats_kernel(const double* 
 
 hipError_t launch_process_stats(const double* traj, const double* ref, int64_t n, int64_t runs, int64_t j0, int pos_ned,
                                 int run_major, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(process_stats_kernel, dim3((unsigned)((runs + 63) / 64)), dim3(64 * kSeg), 0, s, traj, ref, n, runs, j0,
-                       pos_ned, run_major, out);
+    hipLaunchKernelGGL((process_stats_kernel<double>), dim3((unsigned)((runs + 63) / 64)), dim3(64 * kSeg), 0, s, traj, ref, n, runs, j0,
+                       pos_ned, run_major, out, ProcOrigin{nullptr, 0, 0});
+    return hipGetLastError();
+}
+
+hipError_t launch_process_stats_f32(const float* traj, const double* ref, int64_t n, int64_t runs, int64_t j0, int pos_ned,
+                                    int run_major, double* out, const double* origin, int64_t n_ini, uint64_t ini_first, hipStream_t s) {
+    hipLaunchKernelGGL((process_stats_kernel<float>), dim3((unsigned)((runs + 63) / 64)), dim3(64 * kSeg), 0, s, traj, ref, n, runs, j0,
+                       pos_ned, run_major, out, ProcOrigin{origin, n_ini, ini_first});
     return hipGetLastError();
 }
 

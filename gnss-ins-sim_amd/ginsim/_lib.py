@@ -93,6 +93,7 @@ _SIGS = {
     'ginsim_end_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Stats)]),
     'ginsim_end_stats_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     'ginsim_end_stats_finish': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
+    'ginsim_comm_probe': (C.c_int, []),
     'ginsim_comm_unique_id': (C.c_int, [C.c_char_p]),
     'ginsim_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
     'ginsim_comm_destroy': (C.c_int, [C.c_void_p]),
@@ -101,6 +102,10 @@ _SIGS = {
     'ginsim_process_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _PD]),
     'ginsim_end_stats_from_traj': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                              C.POINTER(Stats)]),
+    'ginsim_process_stats_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                           C.c_void_p, C.c_int32, C.c_uint64, _PD]),
+    'ginsim_end_stats_from_traj_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                                 C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(Stats)]),
     'ginsim_stats_merge': (C.c_int, [C.POINTER(Stats), C.c_int32, C.POINTER(Stats)]),
     'ginsim_gather_runs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
                                      C.POINTER(C.c_int64), C.c_int32, _PD]),

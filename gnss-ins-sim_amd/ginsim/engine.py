@@ -24,20 +24,31 @@ def device_count():
 
 
 class DeviceBuffer(object):
-    """A hipMalloc'ed region owned by a Context."""
+    """A hipMalloc'ed region owned by a Context.  Large regions go back to the context's pool when they are freed and are
+    handed out again for the next request of the same size: a hipMalloc of the 3-5 GB series buffers of a 65 536-run Sim
+    takes anything between 1 and 280 ms on MI355X (measured: 226 / 3 / 124 / 284 ms in four consecutive Sim.run calls), the
+    kernel that fills them 1.3 ms.  Everything of a context runs on its one stream, so a region that is reused is only
+    touched after the work that last used it."""
 
     def __init__(self, ctx, nbytes):
         self.ctx, self.nbytes = ctx, int(nbytes)
-        p = C.c_void_p()
-        check(lib.ginsim_malloc(ctx.handle, self.nbytes, C.byref(p)))
-        self.ptr = p.value
+        self.ptr = ctx._pool_take(self.nbytes)
+        if self.ptr is None:
+            p = C.c_void_p()
+            rc = lib.ginsim_malloc(ctx.handle, self.nbytes, C.byref(p))
+            if rc != 0 and ctx._pool_bytes:          # out of memory with regions parked in the pool: give them back and retry
+                ctx.release_pool()
+                rc = lib.ginsim_malloc(ctx.handle, self.nbytes, C.byref(p))
+            check(rc)
+            self.ptr = p.value
 
     def at(self, byte_offset):
         return self.ptr + int(byte_offset)
 
     def free(self):
         if self.ptr and self.ctx.handle:
-            lib.ginsim_free(self.ctx.handle, self.ptr)
+            if not self.ctx._pool_give(self.nbytes, self.ptr):
+                lib.ginsim_free(self.ctx.handle, self.ptr)
         self.ptr = None
 
     def __del__(self):
@@ -70,14 +81,41 @@ class Context(object):
         check(lib.ginsim_create(int(device), C.byref(h)))
         self.handle = h.value
         self.device = int(device)
+        self.comm_ranks = 0
+        # freed device regions by size (DeviceBuffer): regions of at least POOL_MIN bytes, POOL_LIMIT bytes in total
+        self._pool, self._pool_bytes = {}, 0
+        self.pool_limit = int(os.environ.get('GINSIM_POOL_BYTES', 96 * 2 ** 30))
 
     def name(self):
         buf = C.create_string_buffer(256)
         check(lib.ginsim_device_name(self.handle, buf, 256))
         return buf.value.decode()
 
+    POOL_MIN = 1 << 20
+
     def malloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def _pool_take(self, nbytes):
+        lst = self._pool.get(nbytes)
+        if not lst:
+            return None
+        self._pool_bytes -= nbytes
+        return lst.pop()
+
+    def _pool_give(self, nbytes, ptr):
+        if nbytes < self.POOL_MIN or self._pool_bytes + nbytes > self.pool_limit:
+            return False
+        self._pool.setdefault(nbytes, []).append(ptr)
+        self._pool_bytes += nbytes
+        return True
+
+    def release_pool(self):
+        """hipFree everything parked in the pool (also done by close())."""
+        for lst in self._pool.values():
+            for ptr in lst:
+                lib.ginsim_free(self.handle, ptr)
+        self._pool, self._pool_bytes = {}, 0
 
     def upload(self, array):
         a = np.ascontiguousarray(array)
@@ -112,6 +150,11 @@ class Context(object):
 
     # ---- multi-GPU exchange behind the C ABI (RCCL on this context's stream)
     @staticmethod
+    def comm_probe():
+        """Raises unless librccl can be reached from this process (dlopen + dlsym only)."""
+        check(lib.ginsim_comm_probe())
+
+    @staticmethod
     def comm_unique_id():
         """128 bytes rank 0 hands to the other ranks (ncclGetUniqueId)."""
         buf = C.create_string_buffer(128)
@@ -129,6 +172,7 @@ class Context(object):
 
     def close(self):
         if self.handle:
+            self.release_pool()
             lib.ginsim_destroy(self.handle)
             self.handle = None
 
@@ -508,22 +552,41 @@ class MonteCarloJob(object):
     def process_stats(self, algo, first_sample=0, pos_ned=False):
         """Per-run statistics of the error over time (samples >= first_sample): (runs, 3, 9) = max|e|, mean, std.
         Needs the trajectories (keep_traj=True) and truth['ref_att'/'ref_pos'/'ref_vel']."""
-        if not self.keep_traj or self.precision != 'f64':
-            raise ValueError('process-error statistics need fp64 trajectories (keep_traj=True, precision="f64")')
+        if not self.keep_traj:
+            raise ValueError('process-error statistics need the trajectories (keep_traj=True)')
         if 'ref_nav' not in self._bufs:
             self._bufs['ref_nav'] = self.ctx.upload(self._ref_nav)
         out = np.empty((self.runs, 3, 9))
+        if self.precision == 'f32':     # float series, positions as displacement from the run's initial position
+            check(lib.ginsim_process_stats_f32(self.ctx.handle, self._bufs['traj_' + algo].ptr, self._bufs['ref_nav'].ptr, self.n,
+                                               self.runs, int(first_sample), int(bool(pos_ned)), self._origin().ptr,
+                                               self._ini_table.shape[0], self._ini_first, dptr(out)))
+            return out
         check(lib.ginsim_process_stats(self.ctx.handle, self._bufs['traj_' + algo].ptr, self._bufs['ref_nav'].ptr,
                                        self.n, self.runs, int(first_sample), int(bool(pos_ned)), dptr(out)))
         return out
 
+    def _origin(self):
+        """Device table of the initial positions the fp32 displacement series are relative to ([n_ini][3]: ECEF for ref_frame 1,
+        LLA for ref_frame 0; free_integration.py:96-98 / :127-128)."""
+        if '_origin' not in self._bufs:
+            from gnss_ins_sim.geoparams import geoparams
+            lla = self._ini_table[:, 0:3]
+            self._bufs['_origin'] = self.ctx.upload(np.ascontiguousarray(geoparams.lla2ecef(lla) if self._ref_frame == 1 else lla))
+        return self._bufs['_origin']
+
     def stats_from_traj(self, algo, pos_ned=False):
         """End-point statistics recomputed on the device from the kept trajectories (used for extra_opt='ned')."""
-        if not self.keep_traj or self.precision != 'f64':
-            raise ValueError('needs fp64 trajectories (keep_traj=True, precision="f64")')
+        if not self.keep_traj:
+            raise ValueError('needs the trajectories (keep_traj=True)')
         if 'ref_nav' not in self._bufs:
             self._bufs['ref_nav'] = self.ctx.upload(self._ref_nav)
         s = _lib.Stats()
+        if self.precision == 'f32':
+            check(lib.ginsim_end_stats_from_traj_f32(self.ctx.handle, self._bufs['traj_' + algo].ptr, self._bufs['ref_nav'].ptr, self.n,
+                                                     self.runs, int(bool(pos_ned)), self._origin().ptr, self._ini_table.shape[0],
+                                                     self._ini_first, C.byref(s)))
+            return StatsResult(s)
         check(lib.ginsim_end_stats_from_traj(self.ctx.handle, self._bufs['traj_' + algo].ptr, self._bufs['ref_nav'].ptr,
                                              self.n, self.runs, int(bool(pos_ned)), C.byref(s)))
         return StatsResult(s)

@@ -36,32 +36,40 @@ def lla2ecef(lla):
 lla2ecef_batch = lla2ecef
 
 
-def reference_geomag_n(lat, lon, alt, when=None):
+def reference_geomag_n(lat, lon, alt, when=None, root=None):
     """The geomagnetic field [uT] in the N frame at (lat, lon [rad], alt [m]) exactly as pathgen.path_gen obtains it
     (pathgen.py:164-168): ``geomag.GeoMag("WMM.COF").GeoMag(lat_deg, lon_deg, alt)`` -> (bx, by, bz) / 1000.  The World Magnetic
     Model itself is outside the accelerated path (SURVEY #14: "reuse on host"), so this only LOCATES the reference's own
-    ``gnss_ins_sim/geoparams/geomag.py`` (+ WMM.COF) -- in $GNSS_INS_SIM_REFERENCE or in a directory on sys.path, i.e. a
-    reference checkout next to this package -- and loads that one file under a private module name (the package name itself is
-    taken by this drop-in).  Returns None when no checkout is found.  `when`: a datetime.date (default: today, the reference's
-    import-time default argument, geomag.py:23)."""
+    ``gnss_ins_sim/geoparams/geomag.py`` (+ WMM.COF) and loads that one file under a private module name (the package name
+    itself is taken by this drop-in), without writing bytecode next to it.  Where it looks: `root`, else $GNSS_INS_SIM_REFERENCE
+    -- an explicit statement by the caller, nothing is picked up from sys.path or the current directory.  Returns None when
+    there is no such checkout.
+    `when`: a datetime.date; the default is today -- the reference's own import-time default (geomag.py:23), which makes 9-axis
+    outputs differ from one day to the next; the date used is printed once so that a run can be repeated (geo_mag_date=...)."""
     import datetime
     import importlib.util
     import os
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    roots = [os.environ.get('GNSS_INS_SIM_REFERENCE')] + list(sys.path)
-    for root in roots:
-        if not root:
-            continue
-        d = os.path.join(root, 'gnss_ins_sim', 'geoparams')
-        f = os.path.join(d, 'geomag.py')
-        if os.path.abspath(d) == here or not (os.path.isfile(f) and os.path.isfile(os.path.join(d, 'WMM.COF'))):
-            continue
+    root = root or os.environ.get('GNSS_INS_SIM_REFERENCE')
+    if not root:
+        return None
+    d = os.path.join(root, 'gnss_ins_sim', 'geoparams')
+    f = os.path.join(d, 'geomag.py')
+    if os.path.abspath(d) == here or not (os.path.isfile(f) and os.path.isfile(os.path.join(d, 'WMM.COF'))):
+        return None
+    keep = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True              # the checkout may be read-only and is not ours to write into
+    try:
         spec = importlib.util.spec_from_file_location('_ginsim_reference_geomag', f)
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        gm = mod.GeoMag('WMM.COF')
-        d2r = math.pi / 180                      # pos_n[0] / D2R, pathgen.py:166
-        r = gm.GeoMag(lat / d2r, lon / d2r, alt, when or datetime.date.today())
-        return np.array([r.bx, r.by, r.bz]) / 1000.0
-    return None
+    finally:
+        sys.dont_write_bytecode = keep
+    gm = mod.GeoMag('WMM.COF')
+    d2r = math.pi / 180                          # pos_n[0] / D2R, pathgen.py:166
+    if when is None:
+        when = datetime.date.today()
+        print('geomagnetic field evaluated by %s for %s (pass geo_mag_date to repeat this run another day)' % (f, when.isoformat()))
+    r = gm.GeoMag(lat / d2r, lon / d2r, alt, when)
+    return np.array([r.bx, r.by, r.bz]) / 1000.0

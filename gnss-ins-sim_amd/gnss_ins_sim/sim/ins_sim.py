@@ -27,7 +27,7 @@ Keyword-only extras (defaults keep the reference behaviour):
     geo_mag_n          geomagnetic field [uT] in the N frame at the initial position, needed for a 9-axis IMU.  The
                        reference evaluates the WMM model once per run for this vector (pathgen.py:164-168,
                        date = today); that model is outside the accelerated path: either the caller supplies the vector, or
-                       a checkout of the reference is reachable (sys.path / $GNSS_INS_SIM_REFERENCE) and ITS geomag.py is
+                       a checkout of the reference is named in $GNSS_INS_SIM_REFERENCE and ITS geomag.py is
                        evaluated once on the host (geoparams.reference_geomag_n; geo_mag_date pins the date).
 """
 import os
@@ -54,11 +54,14 @@ class _McResults(object):
     materialised (the same object when everything is kept, a job over the first ``keep_runs`` runs otherwise, or None).
     """
 
-    def __init__(self, jobs, kept, names, kinds, first_run, runs_local, total_runs, group, device, make_ps_job=None):
+    def __init__(self, jobs, kept, names, kinds, first_run, runs_local, total_runs, group, device, make_ps_job=None, ctx=None,
+                 make_kept_job=None, block_runs=0):
         self.jobs, self.kept, self.algo_names, self.kinds = jobs, kept, names, kinds
         self.first_run, self.runs_local, self.total_runs = first_run, runs_local, total_runs
         self._group, self._device, self._stats = group, device, {}
-        self._make_ps_job = make_ps_job
+        self._make_ps_job, self._ctx = make_ps_job, ctx
+        self._make_kept_job, self._block_runs = make_kept_job, int(block_runs)
+        self.exchange = None                # which exchange merged the records: 'abi', 'torch (...)', None = one process
 
     def job_of(self, name):
         return self.jobs[self.algo_names.index(name)]
@@ -69,28 +72,51 @@ class _McResults(object):
             import ginsim
             from ginsim import distributed
             job, kind = self.job_of(name), self.kinds[self.algo_names.index(name)]
-            if job is None:                         # this rank holds no runs (world > sim_count): an empty record
-                part = ginsim.StatsResult.zero()
-            elif not ned:
-                part = job.stats(kind)
-            elif job.end_ned:                       # second end-point record written by the kernel (no trajectories needed)
-                part = job.stats(kind, ned=True)
-            elif job.keep_traj and job.precision == 'f64':
-                part = job.stats_from_traj(kind, pos_ned=True)
+            # every rank takes the same branch (same Sim configuration); a rank without runs (world > sim_count) has job None
+            # and contributes the empty record
+            probe = next((j for j in self.jobs if j is not None), None)
+            from_traj = ned and probe is not None and not probe.end_ned
+            if from_traj:                           # NED record recomputed from trajectories (kept, or re-integrated block by block)
+                part = ginsim.StatsResult.zero() if job is None else self._ned_from_traj(self.algo_names.index(name))
+                self._stats[key] = part if self._group is None else distributed.allreduce_stats(part, self._group, self._device)
+            elif self._group is None:
+                self._stats[key] = job.stats(kind, ned=ned)
             else:
-                raise NotImplementedError("extra_opt='ned' is available in fp64 only")
-            self._stats[key] = distributed.allreduce_stats(part, self._group, self._device)
+                # the record is on the device: the library's own RCCL all-gather behind the C ABI when the backend is nccl
+                # (the exchange bench.py times), the torch.distributed all-reduce otherwise
+                ex = distributed.StatsExchange.of(self._ctx, self._group, self._device)
+                self._stats[key] = ex.merge(job, kind, ned=ned)
+                self.exchange = ex.kind if ex.note is None else '%s (%s)' % (ex.kind, ex.note)
         return self._stats[key]
+
+    def _blocks(self, idx):
+        """Statistics that need trajectories a stats-only launch did not keep (the fp32 kernel has no online accumulator): the
+        runs are integrated again in blocks that fit the device budget, trajectories kept, and each block is reduced on the
+        device before the next one is launched -- the counter RNG reproduces exactly the same runs."""
+        step = max(self._block_runs, 1)
+        for off in range(0, self.runs_local, step):
+            blk = self._make_kept_job(idx, off, min(step, self.runs_local - off))
+            blk.run()
+            try:
+                yield blk
+            finally:
+                blk.release()
+
+    def _ned_from_traj(self, idx):
+        import ginsim
+        job, kind = self.jobs[idx], self.kinds[idx]
+        if job.keep_traj:
+            return job.stats_from_traj(kind, pos_ned=True)
+        return ginsim.StatsResult.merge([b.stats_from_traj(kind, pos_ned=True).pack() for b in self._blocks(idx)])
 
     def _process_array(self, idx, start_sample, ned):
         """(runs, 3, 9) process statistics of fused algorithm idx over this rank's runs."""
         job, kind = self.jobs[idx], self.kinds[idx]
         key = ('proc', idx, int(start_sample), bool(ned))
         if key not in self._stats:
-            if job.precision != 'f64':
-                raise NotImplementedError("process-error statistics (err_stats_start >= 0) are computed in fp64: use "
-                                          "results(err_stats_start=-1) with precision='f32'")
-            if job.keep_traj:
+            if job.precision != 'f64' and not job.keep_traj:       # fp32, statistics only: re-integrate block by block
+                self._stats[key] = np.concatenate([b.process_stats(kind, start_sample, pos_ned=ned) for b in self._blocks(idx)])
+            elif job.keep_traj:
                 self._stats[key] = job.process_stats(kind, start_sample, pos_ned=ned)
             elif job.proc_first == int(start_sample) and job.proc_ned == bool(ned):
                 self._stats[key] = job.process_stats_online(kind)
@@ -199,8 +225,8 @@ class Sim(object):
             self.geo_mag_n = geoparams.reference_geomag_n(ini_pva[0], ini_pva[1], ini_pva[2], self.geo_mag_date)
             if self.geo_mag_n is None:
                 raise NotImplementedError('a 9-axis IMU needs the local geomagnetic field: pass Sim(..., geo_mag_n=[bx,by,bz] uT), or '
-                                          'put a checkout of the reference (its gnss_ins_sim/geoparams/geomag.py + WMM.COF) on sys.path '
-                                          'or in $GNSS_INS_SIM_REFERENCE (the WMM evaluation of pathgen.py:164-168 is outside the '
+                                          'name a checkout of the reference (its gnss_ins_sim/geoparams/geomag.py + WMM.COF) '
+                                          'in $GNSS_INS_SIM_REFERENCE (the WMM evaluation of pathgen.py:164-168 is outside the '
                                           'accelerated path)')
         raw = ginsim.pathgen(ini_pva, motion_def, fs_imu, self.fs[1] if self.imu.gps else 0.0, mobility,
                              self.ref_frame, gps=self.imu.gps,
@@ -357,8 +383,18 @@ class Sim(object):
                 i = fused[idx]
                 return make_job(group_of[i], [kinds[i]], count, False, False, proc_first=start_sample,
                                 proc_ned=ned, end_ned=False)
+            def make_kept_job(idx, off, runs_):      # a block of this rank's runs, trajectories kept (fp32 statistics)
+                i = fused[idx]
+                g = group_of[i]
+                return ginsim.MonteCarloJob(ctx, fs_imu, self.ref_frame, truth, self.imu.accel_err, self.imu.gyro_err, g['ini'],
+                                            runs=runs_, algos=(kinds[i],), odo_err=self.imu.odo_err, earth_rot=g['earth_rot'],
+                                            seed=seed, run_offset=first + off, ini_first=g['first'] + first + off,
+                                            keep_sensors=False, keep_traj=True, precision=self.precision)
+            esize = 4 if self.precision == 'f32' else 8
+            block_runs = max(256, int(self.max_device_bytes // (9 * esize * n)) // 256 * 256)
             self.mc = _McResults([stats_jobs.get(i) for i in fused], [kept_jobs.get(i) for i in fused], names,
-                                 [kinds[i] for i in fused], first, count, self.sim_count, group, xdev, make_ps_job)
+                                 [kinds[i] for i in fused], first, count, self.sim_count, group, xdev, make_ps_job, ctx=ctx,
+                                 make_kept_job=make_kept_job, block_runs=block_runs)
             d.set_mc_results(self.mc)
         # plugins outside the fused kernel: the reference's per-run loop over host copies (user code)
         if hosted:
@@ -461,10 +497,6 @@ class Sim(object):
             data_saved = self.dmgr.save_data(data_dir, max_runs=max_saved_runs)
         if gen_kml is True:
             self.dmgr.save_kml_files(data_dir)
-        if self.mc is not None and self.precision == 'f32' and err_stats_start != -1:
-            print("precision='f32': process-error statistics are an fp64 product; reporting end-point statistics "
-                  "(err_stats_start=-1) instead.")
-            err_stats_start = -1
         self._summary(data_dir, data_saved, err_stats_start, extra_opt, max_summary_runs)
         self.sim_results = True
         return self.dmgr.available

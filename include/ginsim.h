@@ -214,7 +214,14 @@ int ginsim_end_stats_finish(ginsim_ctx* ctx, int32_t slot, ginsim_stats* host_ou
  *      Bootstrap: rank 0 calls ginsim_comm_unique_id and hands the 128 bytes to the other ranks through whatever launcher the
  *      caller uses (an environment variable, a file, torch.distributed's store ...); every rank then calls ginsim_comm_init. */
 #define GINSIM_COMM_ID_BYTES 128
+/* ABI 4: can librccl be reached from this process (dlopen + dlsym, nothing else)?  Every rank calls it and the verdicts are
+ * reduced BEFORE anyone enters the collective ginsim_comm_init: a rank that failed alone would leave the others waiting there. */
+int ginsim_comm_probe(void);
+/* rank 0 only (it starts RCCL's bootstrap listener for this id) */
 int ginsim_comm_unique_id(unsigned char* id /*[GINSIM_COMM_ID_BYTES]*/);
+/* Collective over the nranks ranks (ncclCommInitRank): returns an error on every rank or on none once all have entered; a rank
+ * that never enters (it failed earlier) leaves the others blocked inside RCCL -- hence ginsim_comm_probe.  On failure the
+ * context is left without a communicator and may retry. */
 int ginsim_comm_init(ginsim_ctx* ctx, int32_t nranks, int32_t rank, const unsigned char* id);
 int ginsim_comm_destroy(ginsim_ctx* ctx);
 /* ginsim_end_stats_begin / _finish over ALL ranks: reduction of this rank's end errors (runs may be 0: an empty record) ->
@@ -233,6 +240,14 @@ int ginsim_process_stats(ginsim_ctx* ctx, const double* traj, const double* ref,
  * every run on the device, then the same reduction as ginsim_end_stats. */
 int ginsim_end_stats_from_traj(ginsim_ctx* ctx, const double* traj, const double* ref, int64_t n, int64_t runs,
                                int32_t pos_ned, ginsim_stats* host_out);
+/* ABI 4: the same two statistics over the FLOAT trajectories of the fp32 kernel (precision 1), whose position planes hold the
+ * displacement from the run's initial position: origin = device [n_ini][3], the initial positions (ECEF metres for ref_frame
+ * 1, LLA for ref_frame 0) of the initial-state table the launch used, ini_first as in ginsim_mc_params.  The position of a sample
+ * is formed as origin + displacement in fp64 and everything after it is the fp64 arithmetic of the calls above. */
+int ginsim_process_stats_f32(ginsim_ctx* ctx, const float* traj, const double* ref, int64_t n, int64_t runs, int64_t first_sample,
+                             int32_t pos_ned, const double* origin, int32_t n_ini, uint64_t ini_first, double* host_out);
+int ginsim_end_stats_from_traj_f32(ginsim_ctx* ctx, const float* traj, const double* ref, int64_t n, int64_t runs, int32_t pos_ned,
+                                   const double* origin, int32_t n_ini, uint64_t ini_first, ginsim_stats* host_out);
 int ginsim_stats_merge(const ginsim_stats* parts, int32_t nparts, ginsim_stats* out);
 
 /* ---- data access: pull selected runs out of a [ncomp][n][runs] device series into host [nsel][n][ncomp] */

@@ -4,6 +4,10 @@ import sys
 import numpy as np
 import pytest
 
+# tests may load single files of the read-only reference checkout (geomag.py): never drop bytecode next to them
+sys.dont_write_bytecode = True
+os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(REPO, 'gnss-ins-sim_amd')
 GOLDEN = os.path.join(REPO, 'tests', 'golden')

@@ -60,8 +60,23 @@ def test_bench_starts_itself_for_n_gt_1():
     s = two['per_gpu_single']
     assert s['runs'] == 8192 and s['value'] > 0 and s['unit'] == 'sample*MC/s'
     assert two['prewarm_ms'] >= 30.0 and 'gloo' in two['config']['parallelism']
+    # every rank is in the line: its kernel time in the timed region and its own single-GPU reference
+    assert len(two['per_rank']['kernel_ms_avg']) == 2 and two['per_rank']['max'] >= two['per_rank']['min'] > 0
+    assert two['per_rank']['argmax'] in (0, 1) and len(s['every_rank']['value']) == 2 and s['every_rank']['min'] > 0
     # two ranks sharing ONE GPU cannot beat one rank by more than the overlap of host work: a sanity bound, not a scaling claim
     assert two['value'] < 2.5 * s['value']
+
+
+def test_bench_eight_ranks_without_a_launcher():
+    """The driver's 8-GPU command as it will be issued -- `python bench.py --gpus 8`, no launcher -- with the eight ranks sharing
+    the one GPU of this box over gloo: self-start under torch.distributed.run, sharding by global run id, the per-rank turns of
+    per_gpu_single, the exchange, the merge and the per-rank fields of the line all execute with world = 8."""
+    d = _bench(8, ['--steps', '2', '--warmup', '1', '--runs-per-gpu', '4096', '--cpu-baseline-seconds', '0', '--no-legs', '--pmc', 'off',
+                   '--backend', 'gloo', '--shared-device'], launcher=False)
+    assert d['n_gpus'] == 8 and d['config']['total_runs_per_step'] == 8 * 4096 and d['result']['runs'] == 8 * 4096
+    assert len(d['per_rank']['kernel_ms_avg']) == 8 and 0 <= d['per_rank']['argmax'] < 8
+    assert len(d['per_gpu_single']['every_rank']['value']) == 8 and d['per_gpu_single']['runs'] == 4096
+    assert d['scaling'] == 'weak' and d['value'] > 0
 
 
 def test_bench_line_contract():
@@ -156,6 +171,62 @@ keys = list(sim.dmgr.accel.data.keys())
 np.save(sys.argv[2], np.concatenate([sim.err_stats['vel']['std'], sim.err_stats['att_euler']['max'], [keys[0], keys[-1], len(keys)]]))
 dist.barrier(); dist.destroy_process_group()
 '''
+
+
+_SIM_NCCL_WORKER = r'''
+import os, sys, json
+sys.path[:0] = [%(pkg)r, %(repo)r]
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%(port)d', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+os.environ['LOCAL_RANK'] = '0'
+from gnss_ins_sim.sim import imu_model, ins_sim
+from demo_algorithms import free_integration
+csv = os.path.join(%(pkg)r, 'motion_profiles', 'turn_90deg.csv')
+ini = np.genfromtxt(csv, delimiter=',', skip_header=1, max_rows=1)
+ini[0:2] *= np.pi / 180; ini[6:9] *= np.pi / 180
+imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False)
+out = {}
+for rep in range(2):            # the second Sim finds the communicator on the process-wide context
+    sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, algorithm=free_integration.FreeIntegration(ini), seed=77)
+    sim.run(777)
+    sim.results(err_stats_start=-1)
+    out['exchange%%d' %% rep] = sim.mc.exchange
+    out['vel_std'] = [float(x) for x in sim.err_stats['vel']['std']]
+    out['att_max'] = [float(x) for x in sim.err_stats['att_euler']['max']]
+print('RESULT ' + json.dumps(out))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_sim_uses_the_abi_exchange_with_backend_nccl(tmp_path):
+    """Sim under torch.distributed with backend nccl (= RCCL): the end-point records are merged by the library's own all-gather
+    behind the C ABI (ginsim_comm_* / ginsim_end_stats_all_*: the exchange bench.py times), after its first result was
+    cross-checked against the torch.distributed all-reduce -- here with the one-rank communicator this box allows; the statistics
+    equal those of the plain single-process Sim."""
+    script = tmp_path / 'n.py'
+    script.write_text(_SIM_NCCL_WORKER % {'pkg': PKG, 'repo': REPO, 'port': _port()})
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
+    text = p.stdout.decode()
+    assert p.returncode == 0, text[-3000:]
+    got = json.loads([l for l in text.splitlines() if l.startswith('RESULT ')][-1][7:])
+    assert got['exchange0'] == 'abi' and got['exchange1'] == 'abi', got
+    sys.path[:0] = [PKG]
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    ini = np.genfromtxt(csv, delimiter=',', skip_header=1, max_rows=1)
+    ini[0:2] *= np.pi / 180
+    ini[6:9] *= np.pi / 180
+    sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False),
+                      algorithm=free_integration.FreeIntegration(ini), seed=77)
+    sim.run(777)
+    sim.results(err_stats_start=-1)
+    np.testing.assert_allclose(got['vel_std'], sim.err_stats['vel']['std'], rtol=1e-12)
+    np.testing.assert_array_equal(got['att_max'], sim.err_stats['att_euler']['max'])
 
 
 def test_sim_shards_runs_across_ranks(tmp_path):

@@ -305,3 +305,43 @@ def test_pinned_host_buffers(ctx):
     assert np.isfinite(view).all()          # a view keeps the pinned block alive
     small = ginsim.pinned_empty(ctx, 0)
     assert small.size == 0
+
+
+def test_pathgen_sensor_generators_under_their_reference_names(ctx):
+    """pathgen.acc_gen / gyro_gen / odo_gen / gps_gen / mag_gen (pathgen.py:441-661) with the reference's signatures, served by the
+    device: one realisation of the error model over given truth, equal to the oracle's for the same key; np.random.seed makes
+    a call repeatable as it does for the reference; vibration is refused."""
+    from gnss_ins_sim.pathgen import pathgen
+    from ginsim import workloads
+    from oracle import ins_np
+    ini, truth, raw = workloads.truth_from_profile('turn_90deg', 100.0, 0, fs_gps=10.0, gps=True)
+    acc, gyr = workloads.imu_grade('low-accuracy')
+    zero = np.zeros_like(truth['ref_accel'])
+    quiet = {'b': np.zeros(3), 'b_drift': np.zeros(3), 'b_corr': np.full(3, np.inf), 'arw': np.zeros(3), 'vrw': np.zeros(3)}
+    a = pathgen.acc_gen(100.0, truth['ref_accel'], acc, seed=91)
+    w = pathgen.gyro_gen(100.0, truth['ref_gyro'], gyr, seed=92)
+    a_ref, _ = ins_np.mc_sensors(91, np.array([0]), 100.0, truth['ref_accel'], zero, acc, quiet)
+    _, w_ref = ins_np.mc_sensors(92, np.array([0]), 100.0, zero, truth['ref_gyro'], quiet, gyr)
+    assert a.shape == truth['ref_accel'].shape and w.shape == truth['ref_gyro'].shape
+    np.testing.assert_allclose(a, a_ref[0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(w, w_ref[0], rtol=0, atol=1e-14)
+    odo_err = {'scale': 0.999, 'stdv': 0.1}
+    o = pathgen.odo_gen(truth['ref_odo'], odo_err, seed=93)
+    np.testing.assert_allclose(o, ins_np.mc_odo(93, np.array([0]), truth['ref_odo'], odo_err)[0], rtol=0, atol=1e-12)
+    np.random.seed(5)
+    a1 = pathgen.acc_gen(100.0, truth['ref_accel'], acc)
+    np.random.seed(5)
+    a2 = pathgen.acc_gen(100.0, truth['ref_accel'], acc)
+    a3 = pathgen.acc_gen(100.0, truth['ref_accel'], acc)
+    assert np.array_equal(a1, a2) and not np.array_equal(a2, a3)
+    gps_err = {'stdp': np.array([5.0, 5.0, 7.0]), 'stdv': np.array([0.05, 0.05, 0.05])}
+    gp = pathgen.gps_gen(truth['ref_gps'], gps_err, 0, seed=94)
+    assert gp.shape == truth['ref_gps'].shape
+    d = gp - truth['ref_gps']
+    assert 1.0 < d[:, 2].std() < 20.0 and 1e-7 < d[:, 0].std() < 1e-5 and 0.01 < d[:, 3:6].std() < 0.2      # m, rad, m/s
+    mag_err = {'si': np.eye(3) + 0.01, 'hi': np.array([1.0, -2.0, 3.0]), 'std': np.array([0.1, 0.1, 0.1])}
+    ref_mag = np.tile(np.array([30.0, 2.0, 40.0]), (500, 1))
+    mg = pathgen.mag_gen(ref_mag, mag_err, seed=95)
+    np.testing.assert_allclose(mg.mean(0), (ref_mag[0] + mag_err['hi']).dot(mag_err['si'].T), atol=0.05)
+    with pytest.raises(NotImplementedError):
+        pathgen.acc_gen(100.0, truth['ref_accel'], acc, vib_def={'type': 'random'})

@@ -326,3 +326,70 @@ def test_fp32_shard_invariance(ctx):
         assert np.array_equal(part.end_errors('free'), ref[first:first + count])
         part.release()
         first += count
+
+
+@pytest.mark.parametrize('name', ['t3_mid_rf0', 't3_demo_rf1', 't3_high_odo_rf0'])
+def test_fp32_process_and_ned_statistics_over_float_trajectories(ctx, name):
+    """process-error statistics (ins_data_manager.py:761-795) and the 'ned' position error (:542-552) of an fp32
+    job.  The statistics kernel reads the float series the fp32 kernel wrote (positions as displacement from the run's initial
+    position, formed back in fp64), so its result must equal the NumPy restatement applied to the host copies of those same
+    series to fp64 rounding; against the reference's fp64 numbers it agrees within the fp32 trajectory tolerances."""
+    import ginsim
+    from oracle import ins_np
+    g = load_golden(name)
+    R, fs, rf = int(g['R']), float(g['fs']), int(g['ref_frame'])
+    acc, gyr = _errs(g)
+    truth = {'ref_accel': g['ref_accel'], 'ref_gyro': g['ref_gyro'], 'ref_pos': g['ref_pos'], 'ref_vel': g['ref_vel'], 'ref_att': g['ref_att']}
+    odo_err = None
+    if 'odo' in g:
+        truth['ref_odo'] = g['ref_odo']
+        odo_err = {'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])}
+    algos = tuple(a for a in ('free', 'odo') if ('fi' if a == 'free' else 'odo') + '_att' in g)
+    job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, g['ini'], runs=R, algos=algos, odo_err=odo_err, seed=int(g['seed']),
+                               keep_traj=True, precision='f32').run()
+    j0 = int(round(float(g['proc_start_s']) * fs))
+    for a in algos:
+        att, pos, vel = job.trajectories(a, np.arange(R))        # host copies: initial position + displacement
+        for ned in ([False, True] if rf == 0 else [False]):
+            want = ins_np.process_error_stats(att, pos, vel, g['ref_att'], g['ref_pos'], g['ref_vel'], j0, pos_ned=ned)
+            got = job.process_stats(a, j0, pos_ned=ned)
+            # NED metres come out of a difference of two ECEF positions (6e6 m): 1e-9 m of rounding on either side, the same
+            # absolute 2e-8 m the fp64 statistics tests allow (tests/test_process_stats.py)
+            np.testing.assert_allclose(got, want, rtol=1e-9, atol=2e-8 if ned else 1e-12, err_msg='%s %s ned=%s' % (name, a, ned))
+        if rf == 0:
+            e = ins_np.lla_error_ned(pos[:, -1], np.broadcast_to(g['ref_pos'][-1], (R, 3)))
+            end = job.stats_from_traj(a, pos_ned=True)
+            np.testing.assert_allclose(end.maxabs[3:6], np.abs(e).max(0), rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(end.std[3:6], e.std(0), rtol=1e-7, atol=1e-9)
+    job.release()
+
+
+def test_sim_fp32_results_with_the_reference_defaults(ctx):
+    """Sim(precision='f32').results() with the reference's defaults (err_stats_start = 0: per-run process statistics) -- kept
+    trajectories and statistics-only (re-integrated block by block) give the same numbers, close to the fp64 Sim's."""
+    import contextlib
+    import io
+    import os
+    from conftest import PKG
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration
+    g = load_golden('t3_mid_rf0')
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    stats = {}
+    for tag, kw in (('f64', dict(precision='f64')), ('kept', dict(precision='f32', keep_trajectories=True)),
+                    ('blocks', dict(precision='f32', keep_trajectories=False, max_device_bytes=9 * 4 * 1000 * 300))):
+        imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False)
+        sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=0, imu=imu, algorithm=free_integration.FreeIntegration(g['ini']),
+                          seed=int(g['seed']), **kw)
+        sim.run(700)
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim.results(extra_opt='ned')
+        st = sim.err_stats
+        assert len(st['vel']['max']) == 700 and st['pos']['units'] == "['m', 'm', 'm']"
+        stats[tag] = {dn: {s: np.stack([st[dn][s]['algo0_%d' % r] for r in (0, 255, 256, 699)]) for s in ('max', 'avg', 'std')}
+                      for dn in ('att_euler', 'pos', 'vel')}
+    for dn in ('att_euler', 'pos', 'vel'):
+        for s in ('max', 'avg', 'std'):
+            np.testing.assert_array_equal(stats['kept'][dn][s], stats['blocks'][dn][s])       # same runs, same kernel, same reduction
+            scale = np.abs(stats['f64'][dn]['max']).max()
+            np.testing.assert_allclose(stats['kept'][dn][s], stats['f64'][dn][s], rtol=0, atol=2e-3 * scale + 1e-7)

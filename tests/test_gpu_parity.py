@@ -173,6 +173,18 @@ def _errs(g):
     return acc, gyr
 
 
+def _golden_algo_order(name):
+    """The algorithm list ('fi' / 'odo', in order) the committed recipe tests/golden/make_golden.py handed to the reference's
+    Sim for golden `name`: the reference names its statistics groups 'algo0', 'algo1' by that order (ins_algo_manager.py:98-114)."""
+    import os
+    import re
+    from conftest import GOLDEN
+    text = open(os.path.join(GOLDEN, 'make_golden.py')).read()
+    m = re.search(r"t3_case\('%s'[^\n]*?(\[(?:'(?:fi|odo)'(?:, )?)+\])" % re.escape(name), text)
+    assert m, 'golden recipe has no t3_case for %s' % name
+    return [x.strip("' ") for x in m.group(1).strip('[]').split(',')]
+
+
 @pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'])
 def test_t3_injected_noise_vs_reference(ctx, name):
     """Unmodified reference Sim.run(R) fed the engine's Philox normals == fused kernel, per sample."""
@@ -204,14 +216,14 @@ def test_t3_injected_noise_vs_reference(ctx, name):
                           rtol=1e-9, what=name + a)
         st = job.stats(a)
         assert st.count == R
-        matched = False
-        for grp in groups:
-            want = {s: np.concatenate([g['stat_%s_%s_%s' % (dn, s, grp)] for dn in ('att_euler', 'pos', 'vel')])
-                    for s in ('max', 'avg', 'std')}
-            matched |= (np.allclose(st.maxabs * scale, want['max'], rtol=1e-7, atol=1e-12)
-                        and np.allclose(st.mean * scale, want['avg'], rtol=1e-7, atol=1e-12)
-                        and np.allclose(st.std * scale, want['std'], rtol=1e-6, atol=1e-12))
-        assert matched, 'device end-point statistics of %s/%s match no reference group' % (name, a)
+        # the NAMED group: 'algo<i>' with i the position of this algorithm in the list the golden recipe gave the reference's Sim
+        grp = 'algo%d' % _golden_algo_order(name).index(tag)
+        assert grp in groups
+        want = {s: np.concatenate([g['stat_%s_%s_%s' % (dn, s, grp)] for dn in ('att_euler', 'pos', 'vel')])
+                for s in ('max', 'avg', 'std')}
+        np.testing.assert_allclose(st.maxabs * scale, want['max'], rtol=1e-7, atol=1e-12, err_msg='%s/%s max vs %s' % (name, a, grp))
+        np.testing.assert_allclose(st.mean * scale, want['avg'], rtol=1e-7, atol=1e-12, err_msg='%s/%s avg vs %s' % (name, a, grp))
+        np.testing.assert_allclose(st.std * scale, want['std'], rtol=1e-6, atol=1e-12, err_msg='%s/%s std vs %s' % (name, a, grp))
     job.release()
 
 

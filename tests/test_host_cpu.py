@@ -171,20 +171,32 @@ assert distributed.allreduce_stats_end(distributed.allreduce_stats_begin(part)) 
 # bootstrap of the library's own communicator: a rank that cannot reach librccl must make EVERY rank raise before any of them
 # enters the collective initialisation (nobody is left waiting); with all ranks fine the id of rank 0 reaches every rank
 class FakeCtx(object):
-    def __init__(self, broken): self.broken, self.got = broken, None
-    def comm_unique_id(self):
+    def __init__(self, broken=False, init_fails=False): self.broken, self.init_fails, self.got, self.ids, self.destroyed = broken, init_fails, None, 0, 0
+    def comm_probe(self):
         if self.broken: raise OSError('librccl not found')
+    def comm_unique_id(self):
+        self.ids += 1
         return bytes([rank]) * 128
-    def comm_init(self, nranks, r, uid): self.got = (nranks, r, uid)
+    def comm_init(self, nranks, r, uid):
+        if self.init_fails: raise OSError('ncclCommInitRank: unhandled system error')
+        self.got = (nranks, r, uid)
+    def comm_destroy(self): self.destroyed += 1
 bad = FakeCtx(broken=(rank == 1))
 try:
     distributed.init_abi_comm(bad, dist.group.WORLD, torch.device('cpu'))
     raise SystemExit('init_abi_comm did not raise on rank %%d' %% rank)
 except RuntimeError as e:
-    assert 'not usable on every rank' in str(e) and bad.got is None
-good = FakeCtx(broken=False)
+    assert 'not usable on every rank' in str(e) and bad.got is None and bad.ids == 0     # nobody drew an id, nobody entered the init
+# the collective initialisation fails on ONE rank: every rank raises, and the rank that did get a communicator drops it again
+half = FakeCtx(init_fails=(rank == 1))
+try:
+    distributed.init_abi_comm(half, dist.group.WORLD, torch.device('cpu'))
+    raise SystemExit('init_abi_comm did not raise on rank %%d' %% rank)
+except RuntimeError as e:
+    assert 'ncclCommInitRank failed' in str(e) and half.destroyed == (1 if rank == 0 else 0)
+good = FakeCtx()
 assert distributed.init_abi_comm(good, dist.group.WORLD, torch.device('cpu')) == (world, rank)
-assert good.got == (world, rank, bytes([0]) * 128)
+assert good.got == (world, rank, bytes([0]) * 128) and good.ids == (1 if rank == 0 else 0)      # the id is drawn on rank 0 only
 dist.barrier()
 dist.destroy_process_group()
 print('rank', rank, 'ok')
@@ -351,3 +363,49 @@ def test_run_stats_first_keys_are_the_first_runs_of_every_algorithm():
     assert rs.first_keys(100) == ['free_%d' % i for i in range(10)] + ['odo_%d' % i for i in range(4)]
     assert np.array_equal(rs['free_7'], a[7]) and np.array_equal(rs['odo_3'], a[3])
     assert sorted(rs.keys()) == sorted(rs.first_keys(100))
+
+
+@pytest.mark.parametrize('rf', [0, 1])
+def test_path_gen_under_its_reference_name(rf):
+    """`from gnss_ins_sim.pathgen import pathgen; pathgen.path_gen(ini, motion_def, output_def, mobility, ref_frame, magnet)`
+    (pathgen.py:26-329) with the drop-in package ahead on the path: the reference's signature, its result dict ('status', 'imu',
+    'nav', 'mag', 'gps', 'odo'; [] for what is switched off) and its exceptions, over ginsim_pathgen -- against the truth the
+    executed reference produced (t2 goldens)."""
+    from gnss_ins_sim.pathgen import pathgen
+    g = load_golden('t2_turn_rf%d' % rf)
+    k = g['rows']
+    md0 = g['motion_def'].copy()
+    out_def = np.array([[1.0, 100.0], [1.0, 10.0], [1.0, 100.0]])
+    r = pathgen.path_gen(g['ini_pva'], md0, out_def, g['mobility'], rf, False)
+    assert sorted(r) == ['gps', 'imu', 'mag', 'nav', 'odo', 'status'] and r['status'] is True and r['mag'] == []
+    assert np.array_equal(md0, g['motion_def']) and out_def[1, 1] == 10.0          # the arguments are left alone
+    assert r['imu'].shape == (int(g['n']), 7) and r['nav'].shape == (int(g['n']), 10) and r['odo'].shape == (int(g['n']), 5)
+    np.testing.assert_allclose(r['imu'][:, 1:4], g['full_ref_accel'], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(r['imu'][:, 4:7], g['full_ref_gyro'], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(r['nav'][k, 1:4], g['ref_pos'], rtol=1e-15, atol=0)
+    np.testing.assert_allclose(r['nav'][k, 4:7], g['ref_vel'], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(r['nav'][k, 7:10], g['ref_att'], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(r['gps'][:, 1:7], g['ref_gps'], rtol=1e-15, atol=1e-13)
+    np.testing.assert_allclose(r['gps'][:, 7], g['gps_vis'])
+    np.testing.assert_allclose(r['odo'][k, 2], g['ref_odo'], rtol=0, atol=1e-13)
+    np.testing.assert_array_equal(r['imu'][:, 0], np.arange(int(g['n'])))           # index column = simulation count (osr 1)
+    # GPS and odometer switched off: empty lists, as pathgen.py:99-104 initialises them
+    off = pathgen.path_gen(g['ini_pva'], md0, np.array([[1.0, 100.0], [0.0, 10.0], [-1.0, 100.0]]), g['mobility'], rf)
+    assert off['gps'] == [] and off['odo'] == [] and off['imu'].shape == r['imu'].shape
+    # magnetometer truth with a supplied field vector (the WMM evaluation itself is an input)
+    m9 = load_golden('t3_mag9_gps_rf%d' % rf)
+    mag = pathgen.path_gen(g['ini_pva'], md0, out_def, g['mobility'], rf, True, geo_mag_n=m9['geo_mag_n'])
+    np.testing.assert_allclose(mag['mag'][:, 1:4], m9['ref_mag'], rtol=0, atol=1e-13)
+    # the reference's own errors (pathgen.py:118-126, 147)
+    bad = md0.copy()
+    bad[1, 7] = -1.0
+    with pytest.raises(ValueError, match='negative time duration'):
+        pathgen.path_gen(g['ini_pva'], bad, out_def, g['mobility'], rf)
+    zero = md0.copy()
+    zero[:, 7] = 0.0
+    with pytest.raises(ValueError, match='must be above 0'):
+        pathgen.path_gen(g['ini_pva'], zero, out_def, g['mobility'], rf)
+    with pytest.raises(ValueError, match='3x2'):
+        pathgen.path_gen(g['ini_pva'], md0, np.array([[1.0, 100.0], [1.0, 10.0]]), g['mobility'], rf)
+    with pytest.raises(NotImplementedError):
+        pathgen.path_gen(g['ini_pva'], md0, np.array([[2.0, 100.0], [1.0, 10.0], [1.0, 100.0]]), g['mobility'], rf)

@@ -1,0 +1,46 @@
+"""Where the wall time of Sim(...).run(65 536); Sim.results() goes (BASELINE config 2, everything kept on the device):
+cProfile of the third construction (allocators and the library are warm).  Development aid."""
+import cProfile
+import contextlib
+import io
+import os
+import pstats
+import sys
+import time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(REPO, 'gnss-ins-sim_amd'), REPO]
+import numpy as np
+from gnss_ins_sim.sim import imu_model, ins_sim
+from demo_algorithms import free_integration
+csv = os.path.join(REPO, 'gnss-ins-sim_amd', 'motion_profiles', 'turn_90deg.csv')
+ini = np.genfromtxt(csv, delimiter=',', skip_header=1, max_rows=1)
+ini[0:2] *= np.pi / 180
+ini[6:9] *= np.pi / 180
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+
+
+def once():
+    imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False)
+    t0 = time.perf_counter()
+    sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, mode=None, env=None,
+                      algorithm=free_integration.FreeIntegration(ini), seed=1)
+    sim.run(R)
+    t1 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim.results(err_stats_start=-1)
+    t2 = time.perf_counter()
+    return sim, t1 - t0, t2 - t1
+
+
+for rep in range(4):
+    sim, a, b = once()
+    print('rep %d: run %.3f ms, results %.3f ms -> %.3g sample*MC/s' % (rep, a * 1e3, b * 1e3, R * 1000 / (a + b)))
+    del sim
+pr = cProfile.Profile()
+pr.enable()
+sim, a, b = once()
+pr.disable()
+print('profiled: run %.3f ms, results %.3f ms' % (a * 1e3, b * 1e3))
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
+print(s.getvalue()[:9000])
