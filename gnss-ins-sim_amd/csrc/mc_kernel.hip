@@ -200,6 +200,11 @@ __device__ __forceinline__ double angle_range_pi_mul(double x) {
 // sum e^2 / n - mean^2 with a relative rounding error of ~ 2^-53 (1 + mean^2 / var) sqrt(n) -- 1e-12 for mean^2 / var up
 // to 1e3 at n = 2e5.  process_stats_kernel (stats.hip), which reads kept trajectories, keeps the Welford / Chan-merge form
 // and is the checker: the two agree to 1e-9 relative (tests/test_process_stats.py), the online form to 1e-7 with the oracle.
+// The floor of the raw form: an error that is (nearly) CONSTANT over the window -- a noise-free or ideal IMU with an initial
+// offset, a deterministic bias -- has var << mean^2, and what sum e^2 / n - mean^2 leaves of a std below ~1.5e-8 |mean| is
+// rounding (clamped at 0 here).  The kept-trajectory path has no such floor; a shift about the first sample's error would
+// remove it at the price of 18 more registers, which the ref_frame 0 variants (251 VGPRs) do not have
+// (tests/test_process_stats.py::test_online_statistics_floor_for_a_constant_error pins the bound).
 // The attitude error is wrapped to [-pi, pi] only when some lane of the wavefront is outside it (wrap_pi3).
 __device__ __forceinline__ double wrap_pi_lane(double x) { return fabs(x) <= kPi ? x : angle_range_pi_mul(x); }
 

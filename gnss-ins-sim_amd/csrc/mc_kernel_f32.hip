@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256, 2) mc_kernel_f32(const ginsim_mc_params a
 // (the steps of a tile alternate between the groups).  Bit-identical to mc_kernel_f32.
 //
 // The consumer is ONE wavefront per SIMD and the step time hangs on it: a lone wavefront issues an instruction every ~5
-// cycles whatever its kind (tools/ubench3.hip: v_fma_f32 5.1, s_mov_b32 8.5, v_cvt_f32_f64 8.0, v_mad_u64_u32 9.1, a
+// cycles whatever its kind (tools/experiments/ubench3.hip: v_fma_f32 5.1, s_mov_b32 8.5, v_cvt_f32_f64 8.0, v_mad_u64_u32 9.1, a
 // transcendental 8.8), so its loop is written for instruction COUNT:
 //   * KEEP is a template parameter (everything kept / nothing kept; other combinations take the plain kernel): no
 //     per-step tests of the output pointers;

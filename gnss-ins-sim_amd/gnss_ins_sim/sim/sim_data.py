@@ -117,10 +117,11 @@ def vec_str(a, fast=True):
     """str(a) for a short 1-D float64 vector -- the text the reference's summary prints for every statistic -- four times
     faster than numpy's array printer: the same two passes over the same dragon4 calls (numpy/_core/arrayprint.py,
     FloatingFormat: exponent form when max >= 1e8, min < 1e-4 or max / min > 1000; common integer and fraction widths),
-    without building a formatter object per vector.  Anything else (non-finite values, other shapes or types, changed
-    print options: pass fast=default_print_options()) goes to str().  tests/test_host_cpu.py compares the two on 40 000
-    vectors."""
-    if not (fast and isinstance(a, np.ndarray) and a.dtype == np.float64 and a.ndim == 1 and 0 < a.size <= 8):
+    without building a formatter object per vector.  Only vectors of up to THREE elements (every statistic of the summary): a
+    longer one can exceed numpy's line width of 75 and is then wrapped, which this writer does not do.  Anything else
+    (non-finite values, other shapes or types, changed print options: pass fast=default_print_options()) goes to str().
+    tests/test_host_cpu.py compares the two on 40 000 vectors of sizes 1-3 and checks that sizes 4-8 take the str() path."""
+    if not (fast and isinstance(a, np.ndarray) and a.dtype == np.float64 and a.ndim == 1 and 0 < a.size <= 3):
         return str(a)
     vals = a.tolist()
     nz = [abs(v) for v in vals if v != 0.0]

@@ -342,9 +342,16 @@ def test_summary_vector_text_equals_numpy_str():
               np.array([123456789.123, 0, 0]), np.array([0.1, 100.0, 0.1]), np.array([0.1, 100.1, 0.1]),
               np.array([1.0, 1000.0, 1.0]), np.array([1.0, 1000.1, 1.0]), np.array([2.5]), np.array([1.0, -2.0]),
               np.array([np.nan, 1.0, 2.0]), np.array([np.inf, 1.0, -2.0]), np.arange(6.0), np.array([1, 2, 3])]
+    # vectors of 4-8 elements can exceed numpy's line width and are wrapped by str(); the fast writer does not
+    # wrap, so they must take the str() path -- long values of every size that would not fit one line
+    for size in range(4, 9):
+        for scale in (1e-7, 1.0, 1e9):
+            for _ in range(60):
+                cases.append(rng.normal(size=size) * scale * 10 ** rng.uniform(-2, 2, size=size))
     assert sim_data.default_print_options()
     for a in cases:
         assert sim_data.vec_str(a) == str(a), repr(a)
+    assert any('\n' in str(a) for a in cases)             # the wrapped form really occurs among them
     with np.printoptions(precision=3):
         assert not sim_data.default_print_options()
         a = np.array([1.23456789, 2.0, 3.0])

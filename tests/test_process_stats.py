@@ -244,9 +244,37 @@ def test_sim_stats_only_results_with_reference_defaults_and_keep_runs(tmp_path):
         lean.results(str(tmp_path), err_stats_start=-1)
     files = set(os.listdir(tmp_path))
     assert {'accel-0.csv', 'gps-2.csv', 'pos-algo1_2.csv', 'ref_gps.csv'} <= files and 'accel-%d.csv' % K not in files
-    # single precision: the default results() falls back to end-point statistics with a notice
+    # single precision, statistics only: the default results() now gives the per-run process statistics too (the runs are
+    # re-integrated block by block with float trajectories kept, tests/test_gpu_fp32.py), no fall-back notice
     f32 = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False),
                       algorithm=free_integration.FreeIntegration(g['ini']), seed=99, precision='f32', keep_trajectories=False)
     f32.run(64)
     st, text = stats(f32)
-    assert 'end-point statistics' in text and st['vel']['std'].shape == (3,)
+    assert 'end-point statistics' not in text and len(st['vel']['std']) == 64 and 'Simulation run algo0_63:' in text
+
+
+@pytest.mark.gpu
+def test_online_statistics_floor_for_a_constant_error():
+    """the online accumulator keeps raw sums (sum e, sum e^2), so for an error that is nearly constant over the
+    window -- here an ideal IMU (no noise at all) started 1e-3 rad / 0.5 m/s away from the truth -- its std carries a rounding
+    floor of ~1.5e-8 |mean|, where the kept-trajectory path (Welford) returns the true small value.  Max and mean are unaffected."""
+    import ginsim
+    g = load_golden('t2_turn_rf1')
+    r = ginsim.pathgen(g['ini_pva'], g['motion_def'], 100.0, 0.0, g['mobility'], 1)
+    truth = {'ref_accel': r['imu'][:, 1:4], 'ref_gyro': r['imu'][:, 4:7], 'ref_pos': r['nav'][:, 1:4], 'ref_vel': r['nav'][:, 4:7],
+             'ref_att': r['nav'][:, 7:10]}
+    ideal = {'b': np.zeros(3), 'b_drift': np.zeros(3), 'b_corr': np.full(3, np.inf), 'arw': np.zeros(3), 'vrw': np.zeros(3)}
+    ini = np.array(g['ini_pva'], dtype=np.float64)
+    ini[6] += 1e-3
+    ini[3] += 0.5
+    ctx = ginsim.default_context()
+    online = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, ideal, ideal, ini, runs=64, seed=1, proc_first=0).run()
+    kept = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, ideal, ideal, ini, runs=64, seed=1, keep_traj=True).run()
+    a, b = online.process_stats_online('free'), kept.process_stats('free', 0)
+    np.testing.assert_allclose(a[:, 0], b[:, 0], rtol=1e-12, atol=1e-15)                        # max |e|
+    np.testing.assert_allclose(a[:, 1], b[:, 1], rtol=1e-11, atol=1e-15)                        # mean
+    floor = 2e-8 * np.abs(b[:, 1]) + 1e-15
+    assert np.all(np.abs(a[:, 2] - b[:, 2]) <= np.maximum(floor, 1e-9 * b[:, 2])), np.abs(a[:, 2] - b[:, 2]).max()
+    assert np.all(b[:, 2, 0] < 1e-6 * np.abs(b[:, 1, 0]))           # the case really is "constant error": yaw std << |yaw mean|
+    online.release()
+    kept.release()
