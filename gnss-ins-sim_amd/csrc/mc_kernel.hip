@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
         trace[2] = __builtin_amdgcn_s_memtime();
     }
     __shared__ uint32_t ntab[GIVEN ? 4 : kNormalTableWords];
-    NormalTables tab{nullptr};
+    NormalTables tab{};
     if (!GIVEN) {
         tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
         __syncthreads();

@@ -336,7 +336,7 @@ F32_FM float odo_normal(const RngKey& key, uint32_t j, const NormalTables& tab) 
 template <int RF, int ALGOS, bool GIVEN, bool WD>
 __global__ void __launch_bounds__(256, 2) mc_kernel_f32(const ginsim_mc_params a) {
     __shared__ uint32_t ntab[GIVEN ? 4 : kNormalTableWords];
-    NormalTables tab{nullptr};
+    NormalTables tab{};
     if (!GIVEN) {
         tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
         __syncthreads();
