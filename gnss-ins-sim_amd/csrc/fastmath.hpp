@@ -50,25 +50,6 @@ constexpr int kNormalTableWords = 4 * kNormalOctaves * kNormalSubs;
 static __device__ const uint32_t kNormalTableBits[kNormalTableWords] = {
 #include "normal_tables.inc"
 };
-#ifdef GINSIM_NTAB_SPLIT
-// EXPERIMENT (DESIGN_EXPERIMENTS.md): the row of a segment as two 8-byte halves in two arrays, {c0, c1}
-// and {c2, c3}.  A ds_read_b64 is served in two groups of 32 lanes over 64 banks, a row is 2 banks wide and row r sits on
-// bank pair r mod 32: the 32 most probable rows (octaves 1-4 of the tail probability, 93.75 % of the draws) never collide with
-// each other, where the 16-byte rows of the one-array layout (ds_read_b128: four groups of 16 lanes, row r on bank quad
-// r mod 16) alias from the third octave on -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 34 % in the fused kernel.
-struct NormalTables {
-    const float2* lo;
-    const float2* hi;
-};
-
-GINSIM_FM NormalTables fill_normal_tables(uint32_t* lds, int tid, int nthreads) {
-    for (int k = tid; k < kNormalTableWords; k += nthreads) {
-        const int row = k >> 2, col = k & 3;
-        lds[(col >> 1) * (kNormalTableWords / 2) + 2 * row + (col & 1)] = kNormalTableBits[k];
-    }
-    return NormalTables{reinterpret_cast<const float2*>(lds), reinterpret_cast<const float2*>(lds + kNormalTableWords / 2)};
-}
-#else
 struct NormalTables {
     const float4* q;
 };
@@ -77,7 +58,6 @@ GINSIM_FM NormalTables fill_normal_tables(uint32_t* lds, int tid, int nthreads) 
     for (int k = tid; k < kNormalTableWords; k += nthreads) lds[k] = kNormalTableBits[k];
     return NormalTables{reinterpret_cast<const float4*>(lds)};
 }
-#endif
 
 // One standard normal from ONE 32-bit word by inversion, DEFINED operation by operation (the oracles repeat it to the bit:
 // oracle/philox.py normal_icdf):
@@ -93,13 +73,7 @@ GINSIM_FM float normal_icdf(uint32_t w, const NormalTables& tab) {
     const uint32_t m = (w & 0x7fffffffu) | 1u;
     const int lz = __builtin_clz(m);                                    // 1 .. 31
     const uint32_t y = m << lz;
-#ifdef GINSIM_NTAB_SPLIT
-    const int seg = (lz - 1) * kNormalSubs + (int)((y >> 28) & 7u);
-    const float2 c01 = tab.lo[seg], c23 = tab.hi[seg];
-    const float4 c{c01.x, c01.y, c23.x, c23.y};
-#else
     const float4 c = tab.q[(lz - 1) * kNormalSubs + (int)((y >> 28) & 7u)];
-#endif
     const float x = __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, y << 4, 9));      // 0x3f800000 | ((y << 4) >> 9)
     const float z = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c.w, x, c.z), x, c.y), x, c.x);
     return __uint_as_float((__float_as_uint(z) & 0x7fffffffu) | (w & 0x80000000u));

@@ -99,8 +99,9 @@ for d in sorted(os.listdir(SRC)):
 with open(os.path.join(DST, tag + '_pmc_counters.csv'), 'w', newline='') as f:
     w = csv.writer(f)
     w.writerow([stamp])
-    w.writerow(['# rocprofv3 --pmc <one group per pass> --kernel-trace -- python bench.py --pmc-child (3 timed + 1 warm-up launches of the C2 '
-                'workload and 4 of the given-sensors kernel); values are per dispatch (avg/min/max over dispatches)'])
+    w.writerow(['# rocprofv3 --pmc <one group per pass> --kernel-trace -- python bench.py --pmc-child (the C2 workload: headline, given-sensors and '
+                'fp32 launch; since round 4 also a C3-shaped launch cut to 8192 samples with and without the online statistics, config 5\'s '
+                'sensor generation and Allan calls); values are per dispatch (avg/min/max over dispatches)'])
     w.writerow(['kernel', 'counter', 'dispatches', 'avg', 'min', 'max'])
     for kn in sorted(pmc):
         for c in sorted(pmc[kn]):
@@ -123,6 +124,31 @@ if '--traffic' in sys.argv:
     with open(os.path.join(DST, 'pmc_traffic.json'), 'w') as f:
         json.dump(summary, f, indent=1)
 print(json.dumps(summary, indent=1))
+# --- round 4: the compute-bound launches (C3) and the multi-kernel Allan call
+XCDS, SIMDS = 8, 1024
+extra = {}
+for kn, c in pmc.items():
+    name = kn[len('void '):kn.index('(')] if kn.startswith('void ') else kn[:kn.index('(')] if '(' in kn else kn
+    if 'mc_kernel<0, 1, false' in kn and 'SQ_ACTIVE_INST_VALU' in c and 'GRBM_GUI_ACTIVE' in c and 'SQ_WAVES' in c:
+        steps = 8191.0                  # bench.PMC_CUT_SAMPLES - 1
+        cyc = c['GRBM_GUI_ACTIVE'][1] / XCDS
+        extra[name] = {'valu_busy': 4.0 * c['SQ_ACTIVE_INST_VALU'][1] / (SIMDS * cyc),
+                       'valu_per_step_and_64_runs': c['SQ_INSTS_VALU'][1] / c['SQ_WAVES'][1] / steps,
+                       'salu_per_step_and_64_runs': c['SQ_INSTS_SALU'][1] / c['SQ_WAVES'][1] / steps if 'SQ_INSTS_SALU' in c else None,
+                       'lds_bank_conflict_over_active': (c['SQ_LDS_BANK_CONFLICT'][1] / c['SQ_LDS_IDX_ACTIVE'][1]) if 'SQ_LDS_IDX_ACTIVE' in c else None,
+                       'wait_inst_any_over_wave_cycles': (c['SQ_WAIT_INST_ANY'][1] / c['SQ_WAVE_CYCLES'][1]) if 'SQ_WAVE_CYCLES' in c and 'SQ_WAIT_INST_ANY' in c else None}
+allan = {k: c for k, c in pmc.items() if 'ginsim::allan_' in k}
+if allan and all('WRITE_SIZE' in c and 'FETCH_SIZE' in c for c in allan.values()):
+    calls = [c['WRITE_SIZE'][0] for k, c in allan.items() if 'allan_tail_kernel' in k]
+    if calls:
+        w_b = sum(c['WRITE_SIZE'][0] * c['WRITE_SIZE'][1] for c in allan.values()) * 1024.0 / calls[0]
+        f_b = sum(c['FETCH_SIZE'][0] * c['FETCH_SIZE'][1] for c in allan.values()) * 2048.0 / calls[0]
+        extra['ginsim_allan (192 x 1 440 000, per call)'] = {'hbm_bytes': w_b + f_b, 'write_bytes': w_b, 'fetch_bytes_corrected': f_b,
+                                                            'over_algorithmic': (w_b + f_b) / (8.0 * 192 * 1440000), 'calls': calls[0]}
+with open(os.path.join(DST, tag + '_compute_bound_and_allan.json'), 'w') as f:
+    json.dump({'raw_run': 'gpurun_out/round_' + tag, 'libginsim_sha256': sha, 'kernels': extra}, f, indent=1)
+print(json.dumps(extra, indent=1))
+
 valu = {}
 for kn, c in pmc.items():
     if ('mc_kernel_split<' in kn or 'mc_kernel_f32_split<' in kn) and 'SQ_INSTS_VALU' in c and 'SQ_WAVES' in c:
