@@ -19,9 +19,35 @@ def profile_path(name):
     return os.path.join(PROFILE_DIR, name + '.csv')
 
 
+_PARSED = {}        # (path, mtime_ns, size) or the CSV text itself -> (ini, seg): np.genfromtxt twice costs 0.2 ms per Sim.run
+
+
 def parse_motion(src):
     """Sim.__parse_motion (gnss_ins_sim/sim/ins_sim.py:578-610): file path or CSV text ->
-    (ini_pva(9) [rad, m, m/s], motion_def(S,9) [rad])."""
+    (ini_pva(9) [rad, m, m/s], motion_def(S,9) [rad]).  The parse of a file is remembered by (path, mtime, size), of a string by
+    its text; callers get copies."""
+    key = None
+    try:
+        if isinstance(src, str):
+            if os.path.isfile(src):
+                st = os.stat(src)
+                key = (os.path.abspath(src), st.st_mtime_ns, st.st_size)
+            else:
+                key = src
+            hit = _PARSED.get(key)
+            if hit is not None:
+                return hit[0].copy(), hit[1].copy()
+    except OSError:
+        key = None
+    ini, seg = _parse_motion(src)
+    if key is not None:
+        if len(_PARSED) > 64:
+            _PARSED.clear()
+        _PARSED[key] = (ini.copy(), seg.copy())
+    return ini, seg
+
+
+def _parse_motion(src):
     try:
         if not os.path.isfile(src):
             src = list(src.split('\n'))

@@ -62,8 +62,9 @@ def path_gen(ini_pos_vel_att, motion_def, output_def, mobility, ref_frame=0, mag
                                       'make a checkout of the reference reachable ($GNSS_INS_SIM_REFERENCE)')
     raw = ginsim.pathgen(ini, motion_def, out_freq, output_def[1, 1] if enable_gps else 0.0, mobility, ref_frame,
                          gps=bool(enable_gps), geo_mag_n=mag_n)
-    return {'status': True, 'imu': raw['imu'], 'nav': raw['nav'], 'mag': raw['mag'] if magnet else [],
-            'gps': raw['gps'] if enable_gps else [], 'odo': raw['odo'] if enable_odo else []}
+    # the engine hands out its remembered truth read-only; the reference's caller owns (and may overwrite) what it gets
+    return {'status': True, 'imu': raw['imu'].copy(), 'nav': raw['nav'].copy(), 'mag': raw['mag'].copy() if magnet else [],
+            'gps': raw['gps'].copy() if enable_gps else [], 'odo': raw['odo'].copy() if enable_odo else []}
 
 
 def _key(seed):
