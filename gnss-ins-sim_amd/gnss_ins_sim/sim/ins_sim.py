@@ -248,7 +248,7 @@ class Sim(object):
             d.add_data(d.ref_mag.name, np.ascontiguousarray(raw['mag'][:, 1:4]))
         if self.imu.odo:
             d.add_data(d.ref_odo.name, np.ascontiguousarray(raw['odo'][:, 2]))
-        d.add_data(d.ref_att_quat.name, attitude.euler2quat(d.ref_att_euler.data))     # ins_sim.py:729-748
+        d.add_data(d.ref_att_quat.name, sim_data.Lazy(lambda e=d.ref_att_euler.data: attitude.euler2quat(e)))    # ins_sim.py:729-748, on first read
         truth = {'ref_accel': d.ref_accel.data, 'ref_gyro': d.ref_gyro.data, 'ref_pos': d.ref_pos.data,
                  'ref_vel': d.ref_vel.data, 'ref_att': d.ref_att_euler.data}
         if self.imu.odo:
@@ -551,10 +551,11 @@ class Sim(object):
                 s += ''.join(rows)
                 if total > limit:
                     s += '\t... %d more runs: sim.err_stats[%r]\n' % (total - limit, data_name)
-            else:
-                s += '\t--Max error: ' + str(st['max']) + '\n'
-                s += '\t--Avg error: ' + str(st['avg']) + '\n'
-                s += '\t--Std of error: ' + str(st['std']) + '\n'
+            else:       # one vector per statistic (end-point mode): the same writer, a quarter of numpy's array printer
+                fast = sim_data.default_print_options()
+                s += '\t--Max error: ' + sim_data.vec_str(st['max'], fast) + '\n'
+                s += '\t--Avg error: ' + sim_data.vec_str(st['avg'], fast) + '\n'
+                s += '\t--Std of error: ' + sim_data.vec_str(st['std'], fast) + '\n'
         self.sum += s
         if self._dist()[0] == 0:
             print(self.sum)

@@ -220,7 +220,25 @@ class ChainSeries(Mapping):
         return self
 
 
+class Lazy(object):
+    """A derived series that is computed when it is first read (``Sim_data.data``): e.g. the quaternion form of the true
+    attitude (ins_sim.py:729-748), which the reference computes eagerly in every run() and no statistic uses."""
+
+    def __init__(self, make):
+        self.make = make
+
+
 class Sim_data(object):
+    @property
+    def data(self):
+        if isinstance(self._data, Lazy):
+            self._data = self._data.make()
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = value
+
     def __init__(self, name, description, units=None, output_units=None, plottable=True, logx=False, logy=False,
                  grid='on', legend=None):
         self.name, self.description = name, description

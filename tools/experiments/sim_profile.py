@@ -7,7 +7,7 @@ import os
 import pstats
 import sys
 import time
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(REPO, 'gnss-ins-sim_amd'), REPO]
 import numpy as np
 from gnss_ins_sim.sim import imu_model, ins_sim
