@@ -7,6 +7,8 @@ all per-device records and folds them with the library's Chan merge -- same resu
 independent of reduction order, and better conditioned than summing raw sum / sum-of-squares.
 Payload: world x 28 doubles (1.8 KB at 8 GPUs) -> latency-bound; link bandwidth is irrelevant.
 """
+import os
+
 import numpy as np
 
 from .engine import StatsResult
@@ -75,7 +77,7 @@ def init_abi_comm(ctx, group=None, device=None):
     No rank may be left alone inside a collective: (1) every rank probes librccl (ginsim_comm_probe: dlopen + dlsym only) and
     the verdicts are reduced, so that either all ranks go on or all raise; (2) ncclCommInitRank is collective -- once every rank
     has entered it fails or succeeds on all of them -- and its outcome is reduced as well, so a context that did get a
-    communicator drops it again when another rank did not.
+    communicator drops it again when another rank did not; (3) that call is bounded in time ($GINSIM_COMM_INIT_TIMEOUT, 90 s).
     `device`: where the small verdict tensors live (cuda:<local_rank> with backend nccl, cpu with gloo)."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -96,10 +98,26 @@ def init_abi_comm(ctx, group=None, device=None):
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     if box[0] is None:                          # rank 0 could not draw an id: every rank sees that and raises
         raise RuntimeError('ncclGetUniqueId failed on rank 0%s' % (': ' + problem if problem else ''))
-    try:
-        ctx.comm_init(world, rank, box[0])
-    except Exception as e:                      # noqa: BLE001
-        problem = repr(e)
+    # (3) bounded in time: ncclCommInitRank has no time-out of its own, and a first run on new hardware cannot be debugged --
+    # the call runs on a helper thread (ctypes releases the GIL) and a rank that is not back after `limit` seconds reports
+    # failure like any other; its thread is abandoned (daemon), the context gets no communicator
+    import threading
+    limit = float(os.environ.get('GINSIM_COMM_INIT_TIMEOUT', '90'))
+    done = {}
+
+    def work():
+        try:
+            ctx.comm_init(world, rank, box[0])
+            done['ok'] = True
+        except Exception as e:                  # noqa: BLE001
+            done['err'] = repr(e)
+    t = threading.Thread(target=work, name='ginsim-comm-init', daemon=True)
+    t.start()
+    t.join(limit)
+    if t.is_alive():
+        problem = 'ncclCommInitRank did not return within %g s' % limit
+    elif 'err' in done:
+        problem = done['err']
     if not _all_agree(problem is None, group, device):
         if problem is None:
             ctx.comm_destroy()
