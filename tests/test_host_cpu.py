@@ -416,3 +416,42 @@ def test_path_gen_under_its_reference_name(rf):
         pathgen.path_gen(g['ini_pva'], md0, np.array([[1.0, 100.0], [1.0, 10.0]]), g['mobility'], rf)
     with pytest.raises(NotImplementedError):
         pathgen.path_gen(g['ini_pva'], md0, np.array([[2.0, 100.0], [1.0, 10.0], [1.0, 100.0]]), g['mobility'], rf)
+
+
+def test_dispatch_queries_and_sensor_layout_rules_without_a_gpu():
+    """ginsim_mc_variant / ginsim_mc_kernel_name are host code (they run the library's own dispatch without launching): which
+    kernel serves a parameter block, and the ABI-4 rule that the series-major sensor layout is written by the time-parallel
+    series kernels only."""
+    import ctypes as C
+    import ginsim
+    from ginsim import _lib
+
+    def params(**kw):
+        p = _lib.McParams()
+        p.n, p.runs, p.fs, p.ref_frame, p.algo_mask, p.n_ini = 1000, 65536, 100.0, 1, 1, 1
+        for k in ('ini', 'ref_accel', 'ref_gyro', 'out_accel', 'out_gyro'):
+            setattr(p, k, 4096)                       # never dereferenced: nothing is launched
+        p.out_traj[0] = 4096
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    def query(p):
+        v = C.c_int32(-1)
+        _lib.check(_lib.lib.ginsim_mc_variant(C.byref(p), C.byref(v)))
+        buf = C.create_string_buffer(256)
+        _lib.check(_lib.lib.ginsim_mc_kernel_name(C.byref(p), buf, 256))
+        return v.value, buf.value.decode()
+
+    assert query(params()) == (1, 'ginsim::mc_kernel_split<1, 1, false, 2, true>')                    # C2: the wave-specialised kernel
+    assert query(params(given_sensors=1, in_gyro=4096, in_accel=4096)) == (0, 'ginsim::mc_kernel<1, 1, true, false, 0>')
+    assert query(params(precision=1))[1].startswith('ginsim::f32::mc_kernel_f32_split<1, 1, false, 3,')
+    # sensors only, few runs, long series: the time-parallel kernels -- with the series-major layout, or with one run (same thing)
+    few = dict(algo_mask=0, runs=32, n=1440000)
+    assert query(params(sensor_layout=1, **few)) == (2, 'ginsim::series_kernel<1>')
+    assert query(params(sensor_layout=0, **dict(few, runs=1))) == (2, 'ginsim::series_kernel<1>')
+    assert query(params(sensor_layout=0, **few))[0] == 0                                               # run-fastest layout: one lane per run
+    for bad in (dict(sensor_layout=1), dict(sensor_layout=1, algo_mask=0, runs=2000, n=1440000), dict(sensor_layout=1, algo_mask=0, runs=32, n=1000),
+                dict(sensor_layout=2, **few)):
+        with pytest.raises(ValueError, match='sensor_layout'):
+            query(params(**bad))
