@@ -68,12 +68,9 @@ __device__ __forceinline__ void read_a(const double* __restrict__ w, int lane, d
 // at each: ten in a row queue up behind the other wavefronts' pieces at the CU's address unit and the wavefront stands still)
 struct NothingBetween { __device__ __forceinline__ void operator()(int) const {} };
 
-// t10 != nullptr: the four sums of 10 of this lane (entries 4 lane .. 4 lane + 3 of the next level, RELATIVE to the chunk's
-// shift, i.e. without the 10 shift) are handed back instead of being stored -- the fused kernel keeps the next level on the chip.
 template <bool CHECK, bool RAW, class Between = NothingBetween>
 __device__ __forceinline__ void compute_a(double (&e)[48], int lane, int64_t c, const AllanLevel& lv, double shift,
-                                          double* __restrict__ out_series, double (&acc)[9], const Between& between = Between(),
-                                          double* __restrict__ t10 = nullptr) {
+                                          double* __restrict__ out_series, double (&acc)[9], const Between& between = Between()) {
     {
         if (RAW) {
 #pragma unroll
@@ -119,10 +116,7 @@ __device__ __forceinline__ void compute_a(double (&e)[48], int lane, int64_t c, 
         const double r4 = pair_sq<8, CHECK>(s5, c * (kChunk / 5) + 8 * lane, lv.nb[4]);
         acc[4] += mine ? r4 : 0.0;
         between(9);
-        if (t10) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) t10[k] = lane < 63 ? s5[2 * k] + s5[2 * k + 1] : 0.0;
-        } else if (lane < 63 && out_series) {                                // level k+1: sums of 10, unshifted
+        if (lane < 63 && out_series) {                                       // level k+1: sums of 10, unshifted
             const int64_t g = c * (kChunk / 10) + 4 * lane;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -133,10 +127,10 @@ __device__ __forceinline__ void compute_a(double (&e)[48], int lane, int64_t c, 
 
 template <bool CHECK, bool RAW = false>
 __device__ __forceinline__ void pass_a(const double* __restrict__ w, int lane, int64_t c, const AllanLevel& lv, double shift,
-                                       double* __restrict__ out_series, double (&acc)[9], double* __restrict__ t10 = nullptr) {
+                                       double* __restrict__ out_series, double (&acc)[9]) {
     double e[48];
     read_a(w, lane, e);
-    compute_a<CHECK, RAW>(e, lane, c, lv, shift, out_series, acc, NothingBetween(), t10);
+    compute_a<CHECK, RAW>(e, lane, c, lv, shift, out_series, acc);
 }
 
 __device__ __forceinline__ void read_b(const double* __restrict__ w, int lane, double (&e)[72]) {
@@ -379,16 +373,6 @@ struct DmaPieceIssue {
     }
 };
 
-// the fused kernel's wavefront 0: pieces 3 .. 9 of its half during the level-0 arithmetic (between(0 .. 6)); pieces 0 .. 2 cover
-// the part of the stage its level-1 pass uses as scratch and follow that pass
-struct DmaPieceIssueUpper {
-    DmaPieceIssue base;
-    __device__ __forceinline__ void operator()(int q) const {
-        if (q < 7) base(q + 3);
-        else { __builtin_amdgcn_sched_barrier(0); }
-    }
-};
-
 // a chunk the DMA cannot take, half per wavefront: unshifted, `shift` beyond the end (RAW passes subtract it again)
 __device__ __forceinline__ void stage_ragged_half(const double* __restrict__ x, double* __restrict__ w, int wave, int lane, int64_t c,
                                                   int64_t n_in, double shift) {
@@ -487,271 +471,6 @@ allan_pair_kernel(const double* __restrict__ in, double* __restrict__ out, doubl
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
         if (lane == 0 && mine) partial[(s * nparts + part) * 9 + j] = a;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Levels 0 AND 1 in one pass (allan_fused_kernel): the wave-pair kernel above, whose wavefront 0 no longer writes the sums
-// of 10 to HBM.  Writing level 1 (0.22 GB next to 2.21 GB of reads for 192 x 1 440 000) cost the level-0 kernel 75 of its
-// 450 us -- three times what those bytes cost as reads -- and reading it back was another launch of 51 us.
-// The LDS is full (4 workgroups x 2 stages x 20 KB = 160 KB), so level 1 cannot be staged like level 0, and its bins of 5
-// and 8 entries do not align with the 252 entries a chunk yields.  It does not have to be: level 1 carries a tenth of the data,
-// so it may use a general, alignment-free formulation at several times the per-entry cost --
-//   * wavefront 0 keeps the 252 level-1 entries of the chunk it has just finished in registers (4 per lane) and, at the START
-//     of the next chunk's arithmetic (the stage it has just read is free until its own LDS-DMA pieces are issued), turns them
-//     into PREFIX SUMS P[g] relative to a per-workgroup origin (one DPP wave scan), drops P for the chunk and the 18 entries
-//     before it into the first 2.2 KB of that stage, and
-//   * evaluates every boundary x = multiple of j whose second bin ends inside this chunk (g0 < x + j <= g0 + 252):
-//     d = (P[x+j] - P[x]) - (P[x] - P[x-j]), sum d^2 -- three 8-byte LDS reads per boundary, 713 boundaries per chunk for
-//     j = 1..9 -- and the level-2 entries P[10m+10] - P[10m] (written to HBM: a hundredth of the input);
-//   * the 18 level-1 entries before a workgroup's first chunk are recomputed from 180 raw entries (0.1 % more reads).
-// Every boundary of the series is evaluated by exactly one workgroup (the one holding entry x + j - 1); prefix sums relative
-// to the workgroup's first entry keep the cancellation in the differences at 1e-12 relative (spans of 8 chunks).
-struct AllanFused {
-    int64_t n2;             // entries of level 2 per series (n1 / 10)
-    int64_t out2_stride;
-    int32_t n1;             // entries of level 1 per series: the boundaries x of factor j are valid for j <= x < floor(n1 / j) j
-    int32_t pad;            // (floor(n / (10 j)) = floor(floor(n / 10) / j); every factor is evaluated at level 1 when it is chunked)
-};
-// NOTHING of this plan may be fetched inside the level-1 pass: a scalar load shares lgkmcnt with the LDS reads and returns out of
-// order, so the wait for it is lgkmcnt(0) -- in the first three variants a limit loaded per factor serialised every round of
-// ring reads behind a scalar-cache round trip (9-14 x ~250 cycles per chunk: the whole loss of those variants, E6.1)
-
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_zero_fill(double x) {     // lanes the control / row mask does not reach read 0.0
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// inclusive prefix sum over the 64 lanes (Hillis-Steele inside the rows of 16, then row_bcast:15 / :31)
-__device__ __forceinline__ double wave_prefix_sum(double x) {
-    x += dpp_zero_fill<0x111, 0xf>(x);
-    x += dpp_zero_fill<0x112, 0xf>(x);
-    x += dpp_zero_fill<0x114, 0xf>(x);
-    x += dpp_zero_fill<0x118, 0xf>(x);
-    x += dpp_zero_fill<0x142, 0xa>(x);
-    x += dpp_zero_fill<0x143, 0xc>(x);
-    return x;
-}
-__device__ __forceinline__ double lane_value(double x, int lane) {      // wave-uniform: x of lane `lane`
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
-}
-
-constexpr int kL1 = kChunk / 10;            // 252 level-1 entries per chunk
-constexpr int kL1Halo = 18;                 // P[x - j] reaches back to g0 - 17
-// what wavefront 0 carries from one chunk to the next
-struct Level1State {
-    double pprev[4];        // P[g0 - 252 + 4 lane + 1 ..] of the chunk before (only lanes 58 .. 62 are read: the 18 values before g0)
-    double pcarry;          // P[g0]
-};
-
-// Level 1 of chunk c, right after its level-0 arithmetic: t[k] = level-1 entry 4 lane + k of the chunk relative to 10 x shift
-// (lane 63: 0).  ring[i] = P[g0 - 18 + i], i = 0 .. 270, in the first 2.2 KB of the stage the chunk was read from -- free until
-// this wavefront's own LDS-DMA pieces 0 .. 2 are issued, which therefore come last; pieces 3 .. 9 (entries 384 .. 1279 of the
-// stage) were issued during the level-0 arithmetic.
-template <class Piece>
-__device__ __forceinline__ void level1_phase(Level1State& st, const double (&t)[4], double shift, int64_t c, double origin,
-                                             double* __restrict__ ring, int lane, int n1, int n2, double* __restrict__ out2_series,
-                                             double (&acc1)[9], const Piece& piece) {
-    const int g0i = (int)(c * kL1);                         // level-1 indices fit 32 bits (n <= 2^32 samples)
-    const double d10 = 10.0 * (shift - origin);
-    const double p1 = t[0] + d10, p2 = p1 + (t[1] + d10), p3 = p2 + (t[2] + d10), p4 = p3 + (t[3] + d10);
-    const double own = lane < 63 ? p4 : 0.0;
-    const double base = (wave_prefix_sum(own) - own) + st.pcarry;        // P[g0 + 4 lane]
-    const double pk[4] = {base + p1, base + p2, base + p3, base + p4};     // P[g0 + 4 lane + 1 .. + 4]
-    if (lane < 63) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ring[kL1Halo + 4 * lane + 1 + k] = pk[k];
-    }
-    if (lane == 0) ring[kL1Halo] = st.pcarry;
-    if (lane >= 58 && lane < 63) {                          // the 18 prefix values before g0 (entries 234 .. 251 of the chunk before)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = 4 * lane + 1 + k - (kL1 - kL1Halo);
-            if (i >= 0 && i < kL1Halo) ring[i] = st.pprev[k];
-        }
-    }
-    st.pcarry = lane_value(pk[3], 62);                      // P[g0 + 252]
-#pragma unroll
-    for (int k = 0; k < 4; ++k) st.pprev[k] = pk[k];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // 14 rounds of 64 boundaries: factor j takes ceil(252 / j / 64) of them.  ALL their reads are issued first (the 48 entries of
-    // the level-0 pass are dead by now: there is room for 84 registers of them), then the arithmetic, with the request's pieces
-    // in between -- with a piece pinned between two factors' reads each factor waited out its own LDS latency: 9 x ~150 cycles per
-    // chunk on the path the other wavefront waits for, and the fused kernel was SLOWER than the two it replaces (512 vs 499 us).
-    constexpr int kRounds = 14;
-    constexpr int kJ[kRounds] = {1, 1, 1, 1, 2, 2, 3, 3, 4, 5, 6, 7, 8, 9};
-    constexpr int kQ[kRounds] = {0, 1, 2, 3, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0};
-    double pm[kRounds], p0[kRounds], pp[kRounds];
-    int xr[kRounds];
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-        const int j = kJ[r];
-        const int xs = (g0i / j) * j;                       // smallest multiple of j above g0 - j
-        xr[r] = xs + (64 * kQ[r] + lane) * j;
-        // the lanes that are off read a clamped, in-range address (one v_med3 instead of a mask and a select per round: the
-        // masks of three compares per round were 250 scalar instructions per chunk in the first variants)
-        const int lo = g0i - j + 1 > j ? g0i - j + 1 : j, hi = g0i + kL1 - j;       // wave-uniform; min(max()) folds into v_med3_i32
-        const int xc = xr[r] < lo ? lo : (xr[r] > hi ? hi : xr[r]);
-        const int i = xc - g0i + kL1Halo;
-        pm[r] = ring[i - j];
-        p0[r] = ring[i];
-        pp[r] = ring[i + j];
-    }
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-        const int j = kJ[r];
-        int hi = (n1 / j) * j;                              // x < hi: both bins exist; x + j <= g0 + 252: the second one ends in this chunk
-        hi = hi < g0i + kL1 - j + 1 ? hi : g0i + kL1 - j + 1;
-        const bool ok = (unsigned)(xr[r] - j) < (unsigned)(hi - j);     // j <= x < hi
-        const double d = (pp[r] - p0[r]) - (p0[r] - pm[r]);
-        acc1[j - 1] = __builtin_fma(ok ? d : 0.0, d, acc1[j - 1]);
-    }
-    if (out2_series) {                                       // level 2: sums of 10 level-1 entries, unshifted
-        const int X = (g0i / 10 + 1 + lane) * 10;            // P[X] - P[X - 10], X = 10 m + 10 in (g0, g0 + 252]
-        if (X <= g0i + kL1 && X / 10 - 1 < n2) {
-            const int i = X - g0i + kL1Halo;
-            out2_series[X / 10 - 1] = __builtin_fma(100.0, origin, ring[i] - ring[i - 10]);
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the ring is read: its part of the stage may be refilled
-    piece(0);
-    piece(1);
-    piece(2);
-}
-
-__global__ void __launch_bounds__(128, 2)
-allan_fused_kernel(const double* __restrict__ in, double* __restrict__ out2, double* __restrict__ partial, double* __restrict__ partial1,
-                   const AllanLevel lv, const AllanFused fu) {
-    __shared__ __attribute__((aligned(1024))) double stage[2][kDmaStage];       // 40 960 B: four workgroups per CU
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t s = blockIdx.y, part = blockIdx.x, nparts = gridDim.x;
-    const double* x = in + s * lv.in_stride;
-    const int n1 = fu.n1, n2 = (int)fu.n2;
-    double* out2_series = fu.n2 > 0 ? out2 + s * fu.out2_stride : nullptr;
-    const int64_t c_begin = part * lv.chunks_per_block;
-    int64_t c_end = c_begin + lv.chunks_per_block;
-    if (c_end > lv.nchunks) c_end = lv.nchunks;
-    const int64_t c_dma = (lv.n_in - kDmaStage) / kChunk;       // chunks 0 .. c_dma lie wholly inside the series
-    if (c_begin < c_end && c_begin <= c_dma) dma_request_half(x + c_begin * kChunk, stage[0], wave, lane);
-    if (c_begin + 1 < c_end && c_begin + 1 <= c_dma) dma_request_half(x + (c_begin + 1) * kChunk, stage[1], wave, lane);
-    // The two wavefronts run the SAME sequence of barriers in two role-specialised loops: what wavefront 0 carries for level 1
-    // (34 registers) is then not live across wavefront 1's 63-entry pass, which alone fills the register file.
-    auto chunk_top = [&](int64_t c, double* w) {
-        if (c > c_dma) {            // staged through registers; nothing else of mine is in flight
-            stage_ragged_half(x, w, wave, lane, c, lv.n_in, x[c * kChunk]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            // what was issued after the request for chunk c: the next request's pieces (and, wavefront 0, at most one
-            // level-2 store, not counted: waiting for one operation more is harmless, for one less is not)
-            wait_all_but((c + 1 < c_end && c + 1 <= c_dma) ? kDmaPieces / 2 : 0);
-        }
-        block_barrier();                                        // chunk c is in its stage, for both wavefronts
-    };
-    // every role has its own accumulators (the factors of the other role would be carried through the loop for nothing)
-    auto write_record = [&](double* rec, const double (&v)[9], bool first_role) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const bool mine = (j == 0 || j == 1 || j == 3 || j == 4 || j == 7) == first_role;
-            if (!mine) continue;
-            double a = v[j];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
-            if (lane == 0) rec[(s * nparts + part) * 9 + j] = a;
-        }
-    };
-    if (wave == 0) {
-        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        double acc1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        Level1State st;
-        st.pcarry = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) st.pprev[k] = 0.0;
-        // the workgroup's origin and the prefix sums of the 18 level-1 entries before its first chunk
-        double origin = 0.0;
-        if (c_begin < c_end) {
-            origin = lane_value(x[c_begin * kChunk], 0);         // wave-uniform: keep it out of the vector registers
-            if (c_begin > 0) {
-                const double* hb = x + (c_begin * kL1 - kL1Halo) * 10;       // level-1 entry g0 - 18 + lane = raw hb[10 lane ..]
-                double h = 0.0;
-                if (lane < kL1Halo) {
-#pragma unroll
-                    for (int q = 0; q < 10; ++q) h += hb[10 * lane + q] - origin;
-                }
-                const double incl = wave_prefix_sum(h);                     // sum of the halo entries 0 .. lane
-                const double total = lane_value(incl, kL1Halo - 1);
-                const double ph = (incl - h) - total;                       // P[g0 - 18 + lane] with P[g0] = 0
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int src = 4 * lane + 1 + k - (kL1 - kL1Halo);     // lanes 58 .. 62 take halo value `src`
-                    st.pprev[k] = __shfl(ph, src < 0 ? 0 : (src > 63 ? 63 : src), 64);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // nothing but the requests may be pending in the loop
-        }
-#pragma unroll 1
-        for (int64_t c = c_begin; c < c_end; ++c) {
-            double* w = stage[(c - c_begin) & 1];
-            chunk_top(c, w);
-            // the lane id made opaque per trip: otherwise the dozen lane-derived addresses and bin indices of the passes are
-            // hoisted out of the loop as invariants, do not fit next to the 48 entries and are SPILLED -- and a reload from
-            // scratch is a vector load: its s_waitcnt vmcnt(0) would wait for every request in flight, once per chunk
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const bool again = c + 2 < c_end && c + 2 <= c_dma;
-            const double shift = w[0];                          // the chunk's origin, from the stage
-            double t10[4];
-            if (chunk_is_interior(c, lv)) {
-                double e[48];
-                read_a(w, ln, e);
-                block_barrier();                                // both wavefronts hold their segments: the stage is free
-                // the request for chunk c + 2: pieces 3 .. 9 between the level-0 arithmetic, as in the wave-pair kernel
-                const DmaPieceIssueUpper upper{DmaPieceIssue{x + (c + 2) * kChunk, w, wave, ln, again}};
-                compute_a<false, true>(e, ln, c, lv, shift, nullptr, acc, upper, t10);
-            } else {                                            // the last chunk or two of a series: checked, straight from the stage
-                pass_a<true, true>(w, ln, c, lv, shift, nullptr, acc, t10);
-                block_barrier();
-                if (again) {
-                    const DmaPieceIssue all{x + (c + 2) * kChunk, w, wave, ln, true};
-                    for (int q = 3; q < 10; ++q) all(q);
-                }
-            }
-            // level 1 of this chunk in the first 2.2 KB of the stage it came from, then pieces 0 .. 2 of the request
-            const DmaPieceIssue piece{x + (c + 2) * kChunk, w, wave, ln, again};
-            level1_phase(st, t10, shift, c, origin, w, ln, n1, n2, out2_series, acc1, piece);
-            asm volatile("" ::: "memory");
-        }
-        write_record(partial, acc, true);
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            double b = acc1[j];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) b += __shfl_xor(b, m, 64);
-            if (lane == 0) partial1[(s * nparts + part) * 9 + j] = b;
-        }
-    } else {
-        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-        for (int64_t c = c_begin; c < c_end; ++c) {
-            double* w = stage[(c - c_begin) & 1];
-            chunk_top(c, w);
-            const bool interior = chunk_is_interior(c, lv);
-            const bool again = c + 2 < c_end && c + 2 <= c_dma;
-            const double shift = w[0];
-            if (!interior) {
-                pass_bc<true, true>(w, lane, c, lv, shift, acc);
-                block_barrier();
-                if (again) dma_request_half(x + (c + 2) * kChunk, w, wave, lane);
-            } else {
-                double e[72];
-                read_b_single(w, lane, e);
-                block_barrier();
-                const DmaPieceIssue piece{x + (c + 2) * kChunk, w, wave, lane, again};
-                compute_b<false, true, true>(e, lane, c, lv, shift, acc, piece);
-            }
-        }
-        write_record(partial, acc, false);
     }
 }
 
@@ -863,18 +582,6 @@ hipError_t launch_allan_finish(const double* in, const double* partial, double* 
                                int64_t nseries, hipStream_t st) {
     const int64_t blocks = (t.nlevels > 0 ? nseries : 0) + nseries * f.nlevels;
     if (blocks > 0) hipLaunchKernelGGL(allan_tail_kernel, dim3((unsigned)blocks), dim3(64 * kTailWaves), 0, st, in, partial, sums, t, f);
-    return hipGetLastError();
-}
-
-hipError_t launch_allan_fused(const double* in, double* out2, double* partial, double* partial1, const AllanLevel& lv,
-                              const AllanLevel& lv1, int64_t nseries, hipStream_t st) {
-    AllanFused fu;
-    fu.n2 = lv1.n_out;
-    fu.out2_stride = lv1.out_stride;
-    fu.n1 = (int32_t)lv1.n_in;
-    fu.pad = 0;
-    hipLaunchKernelGGL(allan_fused_kernel, dim3((unsigned)allan_pair_parts(lv), (unsigned)nseries), dim3(128), 0, st, in, out2, partial,
-                       partial1, lv, fu);
     return hipGetLastError();
 }
 

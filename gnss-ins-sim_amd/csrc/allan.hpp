@@ -38,10 +38,6 @@ hipError_t launch_allan_level(const double* in, double* out, double* partial, co
 bool allan_dma_applies(const double* in, const AllanLevel& lv);
 int allan_pair_parts(const AllanLevel& lv);
 hipError_t launch_allan_pair(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries, hipStream_t st);
-// levels k and k+1 in one pass (lv1 = the plan of level k+1, which is kept on the chip): out2 receives level k+2, partial / partial1
-// one record per workgroup and series for either level (allan_pair_parts(lv) of them)
-hipError_t launch_allan_fused(const double* in, double* out2, double* partial, double* partial1, const AllanLevel& lv,
-                              const AllanLevel& lv1, int64_t nseries, hipStream_t st);
 // ONE launch finishes the call: workgroups 0 .. nseries-1 run the levels that fit a chunk, the others fold the partial records
 // of the levels before (either part may be empty)
 hipError_t launch_allan_finish(const double* in, const double* partial, double* sums, const AllanTail& t, const AllanFold& f,

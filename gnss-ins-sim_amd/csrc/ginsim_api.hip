@@ -728,7 +728,7 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
     AllanFold fold;
     fold.nlevels = 0;
     int64_t records = 0;
-    struct Step { int k; int mode; };      // mode 0: allan_level_kernel, 1: wave-pair LDS-DMA kernel, 2: levels k and k+1 fused
+    struct Step { int k; int mode; };      // mode 0: allan_level_kernel, 1: wave-pair LDS-DMA kernel
     std::vector<Step> steps;
     {
         int64_t n_in = n, stride_in = series_stride, pow10 = 1;
@@ -771,19 +771,6 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
             fold.nparts[k] = parts;
             fold.offset[k] = records;
             records += (int64_t)parts * nseries;
-            // levels 0 and 1 in one pass (allan_fused_kernel): level 1 is never written to HBM nor read back.  Needs the wave-pair
-            // kernel on level 0 and a level 1 that would itself have been chunked; GINSIM_ALLAN_FUSE=0 keeps the two-launch form (A/B)
-            static const bool fuse_ok = [] { const char* e = getenv("GINSIM_ALLAN_FUSE"); return !e || atoi(e) != 0; }();
-            bool all9 = true;      // every factor of level 1 evaluated (its limit is then floor(n1 / j) j): always so for a chunked level 1
-            if (levels >= 2) for (int j = 0; j < 9; ++j) all9 = all9 && lvs[1].nb[j] == lvs[1].n_in / (j + 1);
-            if (fuse_ok && dma && k == 0 && levels >= 2 && all9 && lvs[1].n_in > allan_chunk_entries() && lvs[1].n_in < (int64_t)1 << 30) {
-                fold.nparts[1] = parts;
-                fold.offset[1] = records;
-                records += (int64_t)parts * nseries;
-                steps.push_back(Step{0, 2});
-                k = 2;
-                continue;
-            }
             steps.push_back(Step{k, dma ? 1 : 0});
             ++k;
         }
@@ -804,10 +791,7 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
         // level k+1 (<= n/10 entries per series) goes to ping, k+2 to pong, ...
         double* out = (flip++ % 2 == 0) ? ping.d() : pong.d();
         const int k = st.k;
-        if (st.mode == 2)
-            HIP_TRY(launch_allan_fused(in, out, partial.d() + 9 * fold.offset[k], partial.d() + 9 * fold.offset[k + 1], lvs[k], lvs[k + 1],
-                                       nseries, c->stream));
-        else if (st.mode == 1)
+        if (st.mode == 1)
             HIP_TRY(launch_allan_pair(in, out, partial.d() + 9 * fold.offset[k], lvs[k], nseries, c->stream));
         else
             HIP_TRY(launch_allan_level(in, out, partial.d() + 9 * fold.offset[k], lvs[k], nseries, c->stream));
