@@ -307,6 +307,30 @@ def test_pinned_host_buffers(ctx):
     assert small.size == 0
 
 
+@pytest.mark.parametrize('runs,n', [(2, 2048), (5, 4099), (1024, 2111)])
+def test_time_parallel_series_general_sensor_model_and_ragged_lengths(ctx, runs, n):
+    """The series path with the GENERAL sensor model -- a constant bias on every axis, one accelerometer and one gyro axis with an
+    infinite correlation time (white drift, pathgen.py:593), a short correlation time (a = 0.5: the scan weights a^k underflow
+    towards 0 inside a wavefront) -- at lengths that end inside a 64-sample step and at the smallest / largest sizes the path
+    takes, against the oracle's sequential recurrence."""
+    import ginsim
+    from ginsim import workloads
+    from oracle import ins_np
+    ini, truth, _ = workloads.truth_from_profile('long_drive', 200.0, 0)
+    t = {k: (v[:n] if hasattr(v, 'shape') and v.shape and v.shape[0] > n else v) for k, v in truth.items()}
+    acc = {'b': np.array([0.01, -0.02, 0.03]), 'b_drift': np.array([5e-5, 8e-5, 2e-5]), 'b_corr': np.array([100.0, np.inf, 0.01]),
+           'vrw': np.array([5e-4, 4e-4, 6e-4])}
+    gyr = {'b': np.array([1e-4, 0.0, -2e-4]), 'b_drift': np.array([2e-5, 1e-5, 3e-5]), 'b_corr': np.array([np.inf, 50.0, 200.0]),
+           'arw': np.array([7e-5, 7e-5, 9e-5])}
+    job = ginsim.MonteCarloJob(ctx, 200.0, 0, t, acc, gyr, None, runs=runs, algos=(), seed=4242, keep_sensors=True).run()
+    assert job.sensor_layout == 'series' and job.kernel_name() == 'ginsim::series_kernel<1>'
+    pick = sorted({0, runs // 2, runs - 1})
+    a_ref, g_ref = ins_np.mc_sensors(4242, np.array(pick), 200.0, t['ref_accel'], t['ref_gyro'], acc, gyr)
+    np.testing.assert_allclose(job.sensors('accel', pick), a_ref, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(job.sensors('gyro', pick), g_ref, rtol=0, atol=1e-14)
+    job.release()
+
+
 def test_pathgen_sensor_generators_under_their_reference_names(ctx):
     """pathgen.acc_gen / gyro_gen / odo_gen / gps_gen / mag_gen (pathgen.py:441-661) with the reference's signatures, served by the
     device: one realisation of the error model over given truth, equal to the oracle's for the same key; np.random.seed makes
