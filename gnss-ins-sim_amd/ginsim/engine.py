@@ -783,12 +783,12 @@ def allan_var(ctx, x, n, nseries, series_stride, fs, cap=128):
     """Allan variance of `nseries` device-resident series (DeviceBuffer, DeviceView or raw pointer), allan.py:18-59.
     Returns (avar (nseries, ntau), tau (ntau,))."""
     ptr = getattr(x, 'ptr', x)
-    tau = np.zeros(cap)
-    avar = np.zeros((nseries, cap))
+    tau = np.empty(cap)                 # the library writes every entry it reports (ntau of them per series)
+    avar = np.empty((nseries, cap))
     nt = C.c_int32(0)
     check(lib.ginsim_allan(ctx.handle, ptr, int(n), int(nseries), int(series_stride), float(fs), dptr(tau), dptr(avar),
                            C.byref(nt), cap))
-    return avar[:, :nt.value].copy(), tau[:nt.value].copy()
+    return np.ascontiguousarray(avar[:, :nt.value]), tau[:nt.value].copy()
 
 
 def allan_var_host(ctx, series, fs):
