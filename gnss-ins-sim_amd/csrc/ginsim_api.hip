@@ -370,6 +370,15 @@ static int check_mc_params(const ginsim_mc_params* p) {
         rc = check_sensor(p->gyro, "gyro");
         if (rc) return rc;
     }
+    for (const ginsim_vibration* v : {&p->vib_accel, &p->vib_gyro}) {
+        REQUIRE(v->type == GINSIM_VIB_NONE || v->type == GINSIM_VIB_RANDOM || v->type == GINSIM_VIB_SINUSOIDAL,
+                "mc_run: vibration type must be 0 (none), 1 (random) or 2 (sinusoidal)");
+        if (v->type == GINSIM_VIB_NONE) continue;
+        REQUIRE(!p->given_sensors && p->precision == 0 && p->sensor_layout == 0,
+                "mc_run: a vibration term needs generate mode, fp64 and sensor_layout 0 (it lives in the lane-per-run fp64 kernels)");
+        REQUIRE(std::isfinite(v->amp[0]) && std::isfinite(v->amp[1]) && std::isfinite(v->amp[2]) && std::isfinite(v->omega_dt),
+                "mc_run: vibration amplitudes / frequency must be finite");
+    }
     REQUIRE(p->precision == 0 || p->precision == 1, "mc_run: precision must be 0 (fp64) or 1 (fp32)");
     REQUIRE(p->sensor_layout == 0 || p->sensor_layout == 1, "mc_run: sensor_layout must be 0 ([axis][sample][run]) or 1 ([run][axis][sample])");
     REQUIRE(p->sensor_layout == 0 || series_path_applies(*p),

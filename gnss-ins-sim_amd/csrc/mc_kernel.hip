@@ -293,14 +293,55 @@ __device__ __forceinline__ Vec3 sense3(const Vec3& truth, model_ptr m, Vec3& dri
     return o;
 }
 
+// The vibration term of a sensor sample (ABI 5; pathgen.py:476-492, 538-556), added LAST as the reference's sum does
+// (a_mea = ref + bias + drift + noise + vib).  Everything wave-uniform except the normals and the per-run phases.
+typedef const ginsim_vibration __attribute__((address_space(4))) * vib_ptr;
+
+template <uint32_t PHASE_STREAM>
+__device__ __forceinline__ Vec3 vibration_phase(vib_ptr v, const RngKey& key) {
+    if (v->type != GINSIM_VIB_SINUSOIDAL || !v->random_phase) return Vec3{0.0, 0.0, 0.0};
+    const u32x4 w = philox4x32(0u, PHASE_STREAM >> 1, key.r0, key.r1, key.k0, key.k1);
+    // np.random.rand(1)*2*math.pi (pathgen.py:553-555), u = word 2^-32
+    return Vec3{((double)w.x * 0x1p-32 * 2.0) * kPi, ((double)w.y * 0x1p-32 * 2.0) * kPi, ((double)w.z * 0x1p-32 * 2.0) * kPi};
+}
+
+template <uint32_t STREAM>
+__device__ __forceinline__ Vec3 add_vibration(const Vec3& o, vib_ptr v, const RngKey& key, uint32_t j, const NormalTables& tab,
+                                              const Vec3& phase) {
+    Vec3 r = o;
+    if (v->type == GINSIM_VIB_RANDOM) {
+        double z0[2], z1[2];
+        normal_pairs<STREAM, 2>(key, j, z0, z1, tab);
+        r.x = o.x + v->amp[0] * z0[0];
+        r.y = o.y + v->amp[1] * z1[0];
+        r.z = o.z + v->amp[2] * z0[1];
+    } else if (v->type == GINSIM_VIB_SINUSOIDAL) {
+        const double cj = v->omega_dt * (double)j;          // (2 pi f dt) * arange(n), rounded before the phase is added
+        if (v->random_phase) {
+            const double ax = cj + phase.x, ay = cj + phase.y, az = cj + phase.z;
+            r.x = o.x + v->amp[0] * sin(ax);
+            r.y = o.y + v->amp[1] * sin(ay);
+            r.z = o.z + v->amp[2] * sin(az);
+        } else {
+            const double s = sin(cj);
+            r.x = o.x + v->amp[0] * s;
+            r.y = o.y + v->amp[1] * s;
+            r.z = o.z + v->amp[2] * s;
+        }
+    }
+    return r;
+}
+
 // Two workgroups per CU is what the launch geometry below counts on: tell the register allocator (variants had grown
 // to 256 VGPRs + a few AGPRs = one wavefront per SIMD, 30 % slower at 262 144 runs, with no functional symptom;
 // tests/test_host_cpu.py now reads the compiler's resource report).
 // PS: 0 = no process statistics; 1 = online process-error statistics of the (single) algorithm; 2 = the same with the
 // position error in NED metres (ref_frame 0).
-template <int RF, int ALGOS, bool GIVEN, bool WD, int PS = 0>
+// VIB: the sensors carry a vibration term (vib_accel / vib_gyro; general sensor model, generate mode).
+template <int RF, int ALGOS, bool GIVEN, bool WD, int PS = 0, bool VIB = false>
 __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
     static_assert(PS == 0 || (!GIVEN && (ALGOS == GINSIM_ALGO_FREE || ALGOS == GINSIM_ALGO_ODO)), "process statistics: one algorithm, generate mode");
+    static_assert(!VIB || (!GIVEN && WD), "vibration: generate mode, general sensor model");
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t* trace = nullptr;
     if (a.wave_trace && (threadIdx.x & 63) == 0) {
@@ -333,9 +374,14 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
+    Vec3 vpa{0.0, 0.0, 0.0}, vpg{0.0, 0.0, 0.0};
+    if (VIB) {
+        vpa = vibration_phase<S_ACC_VIB_PHASE>(&kernarg_params()->vib_accel, key);
+        vpg = vibration_phase<S_GYR_VIB_PHASE>(&kernarg_params()->vib_gyro, key);
+    }
     MathConsts mk;
     // constants pinned in VGPRs except where that variant would spill to scratch (measured per variant)
-    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO)) && PS == 0>();
+    mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO)) && PS == 0 && !VIB>();
 
     if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
     if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
@@ -383,6 +429,10 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
                 double z0[3], z1[3];
                 normal_pairs<S_GYR_D_XY, 3>(key, jj, z0, z1, tab);
                 gyr = sense3<WD>(cur_g, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
+            }
+            if (VIB) {
+                if (need_acc) acc = add_vibration<S_ACC_VIB_XY>(acc, &kernarg_params()->vib_accel, key, jj, tab, vpa);
+                if (need_gyr) gyr = add_vibration<S_GYR_VIB_XY>(gyr, &kernarg_params()->vib_gyro, key, jj, tab, vpg);
             }
             if (need_acc && a.out_accel) store3(a.out_accel, plane, off, acc);
             if (need_gyr && a.out_gyro) store3(a.out_gyro, plane, off, gyr);
@@ -584,7 +634,10 @@ static int split_policy() {        // GINSIM_SPLIT=0 / 1 forces the plain / wave
 }
 
 // 1 = wave-specialised kernel (mc_kernel_split), 0 = one wavefront does everything for its 64 runs (mc_kernel)
+static bool any_vibration(const ginsim_mc_params& p) { return p.vib_accel.type != GINSIM_VIB_NONE || p.vib_gyro.type != GINSIM_VIB_NONE; }
+
 int mc_variant(const ginsim_mc_params& p) {
+    if (any_vibration(p)) return 0;                     // the vibration term lives in the plain kernel (general sensor model)
     if (!(p.algo_mask & GINSIM_ALGO_FREE) || p.given_sensors || p.block_threads != 0 || p.wave_trace || p.n < 2) return 0;
     if (p.out_proc[0] || p.out_proc[1]) return 0;      // online process statistics live in the plain kernel
     const int pol = split_policy();
@@ -662,9 +715,22 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
     if constexpr (WD && (ALGOS == GINSIM_ALGO_FREE || ALGOS == GINSIM_ALGO_ODO)) {
         if (p.out_proc[ALGOS == GINSIM_ALGO_FREE ? 0 : 1]) {       // the general sensor model serves all PS launches
             const bool ned = RF == 0 && p.proc_pos_ned;
+            if (any_vibration(p)) {
+                GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d, true>", RF, ALGOS, ned ? 2 : 1)
+                if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1, true>), grid, block, lds, stream, p);
+                else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1, true>), grid, block, lds, stream, p);
+                return hipGetLastError();
+            }
             GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d>", RF, ALGOS, ned ? 2 : 1)
             if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1>), grid, block, lds, stream, p);
             else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1>), grid, block, lds, stream, p);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (WD) {
+        if (any_vibration(p)) {
+            GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, 0, true>", RF, ALGOS)
+            hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 0, true>), grid, block, lds, stream, p);
             return hipGetLastError();
         }
     }
@@ -689,7 +755,7 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream, char* n
     }
     // the simple-model variant of the two-algorithm ref_frame 0 kernels is the one instantiation that spills: use the general one
     constexpr bool kSimpleFits = !(RF == 0 && ALGOS == (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO));
-    if (any_white_drift(p) || !kSimpleFits || p.out_proc[0] || p.out_proc[1]) return launch3<RF, ALGOS, true>(p, stream, name, cap);
+    if (any_white_drift(p) || any_vibration(p) || !kSimpleFits || p.out_proc[0] || p.out_proc[1]) return launch3<RF, ALGOS, true>(p, stream, name, cap);
     if constexpr (kSimpleFits) return launch3<RF, ALGOS, false>(p, stream, name, cap);
     return hipErrorInvalidValue;
 }
@@ -935,7 +1001,7 @@ __global__ void __launch_bounds__(64) series_scan_kernel(const SeriesPlan pl, in
 
 // sensors only, few runs, long series
 bool series_path_applies(const ginsim_mc_params& p) {
-    return p.algo_mask == 0 && !p.given_sensors && p.precision == 0 && !p.wave_trace && p.block_threads == 0 &&
+    return p.algo_mask == 0 && !p.given_sensors && p.precision == 0 && !p.wave_trace && p.block_threads == 0 && !any_vibration(p) &&
            p.runs <= 1024 && p.n >= 2048 && (p.sensor_layout == 1 || p.runs == 1);
 }
 

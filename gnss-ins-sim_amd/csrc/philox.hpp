@@ -24,6 +24,10 @@ enum : uint32_t {
     S_GYR_D_XY = 3, S_GYR_DZ_WX = 4, S_GYR_W_YZ = 5,
     S_ODO = 6, S_MAG_XY = 7, S_MAG_Z = 8,
     S_GPS_P_XY = 15, S_GPS_PZ_VX = 16, S_GPS_V_YZ = 17,
+    // vibration (Sim(env=...)): the three 'random' normals of a sample are one block per sensor; the three phase uniforms of a
+    // 'sinusoidal' vibration are words 0..2 of ONE block per run and sensor (sample 0), u = word * 2^-32
+    S_ACC_VIB_XY = 10, S_ACC_VIB_Z = 11, S_GYR_VIB_XY = 12, S_GYR_VIB_Z = 13,
+    S_GYR_VIB_PHASE = 24, S_ACC_VIB_PHASE = 26,
 };
 
 struct u32x4 { uint32_t x, y, z, w; };

@@ -28,6 +28,11 @@ class SensorModel(C.Structure):
                 ('white', C.c_double * 3), ('white_drift', C.c_int32 * 3), ('reserved', C.c_int32)]
 
 
+class Vibration(C.Structure):
+    """ginsim_vibration (ABI 5): type 0 none / 1 random / 2 sinusoidal."""
+    _fields_ = [('type', C.c_int32), ('random_phase', C.c_int32), ('amp', C.c_double * 3), ('omega_dt', C.c_double)]
+
+
 class McParams(C.Structure):
     _fields_ = [('n', C.c_int64), ('runs', C.c_int64), ('run_offset', C.c_uint64), ('seed', C.c_uint64),
                 ('fs', C.c_double), ('ref_frame', C.c_int32), ('algo_mask', C.c_int32),
@@ -42,7 +47,8 @@ class McParams(C.Structure):
                 ('wave_trace', C.c_void_p), ('block_threads', C.c_int32), ('end_pos_ned', C.c_int32),
                 ('precision', C.c_int32), ('proc_pos_ned', C.c_int32),
                 ('ref_nav', C.c_void_p), ('proc_first', C.c_int64), ('out_proc', C.c_void_p * 2),
-                ('out_end_ned', C.c_void_p * 2), ('sensor_layout', C.c_int32), ('reserved4', C.c_int32)]
+                ('out_end_ned', C.c_void_p * 2), ('sensor_layout', C.c_int32), ('reserved4', C.c_int32),
+                ('vib_accel', Vibration), ('vib_gyro', Vibration)]
 
 
 class PathgenParams(C.Structure):

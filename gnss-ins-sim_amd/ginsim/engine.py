@@ -273,6 +273,31 @@ def sensor_model(err, rw_key, fs):
     return m
 
 
+VIB_TYPES = {'random': 1, 'sinusoidal': 2}
+
+
+def vibration(vib_def, fs, random_phase):
+    """ginsim_vibration from the reference's vib_def dict ({'type': 'random' | 'sinusoidal', 'x', 'y', 'z'[, 'freq']}, what
+    Sim.__parse_env makes of an env string, ins_sim.py:642-701).  random_phase: gyro_gen draws one uniform phase per run and
+    axis for a sinusoidal vibration (pathgen.py:553-555), acc_gen uses phase 0 (:490-492).  'psd' is outside the path."""
+    v = _lib.Vibration()
+    if vib_def is None:
+        return v
+    kind = str(vib_def['type']).lower()
+    if kind == 'psd':
+        raise NotImplementedError("vibration from a PSD (time_series_from_psd.py: an inverse FFT per run and axis) is outside "
+                                  "the accelerated path (SURVEY.md section 2, #15); 'random' and 'sinusoidal' run on the device")
+    if kind not in VIB_TYPES:
+        raise ValueError('unknown vibration type %r' % (vib_def['type'],))
+    v.type = VIB_TYPES[kind]
+    v.amp[:] = [float(vib_def['x']), float(vib_def['y']), float(vib_def['z'])]
+    if kind == 'sinusoidal':
+        dt = 1.0 / fs
+        v.omega_dt = 2.0 * math.pi * float(vib_def['freq']) * dt           # the reference's product, left to right
+        v.random_phase = int(bool(random_phase))
+    return v
+
+
 def ini_table(ini):
     """(9|10,) or (9|10,k) initial states (free_integration.py:47-61) -> ((k,10) table, has_g)."""
     a = np.asarray(ini, dtype=np.float64)
@@ -350,12 +375,15 @@ class MonteCarloJob(object):
     Sensors-only jobs (algos=()) of few runs and long series (<= 1024 runs, >= 2048 samples) run on the time-parallel series
     kernels and keep their series SERIES-major, [run][axis][sample] (``sensor_layout == 'series'``; ginsim_mc_params.sensor_layout
     1): that is the layout ginsim_allan reads, so ``allan()`` needs no re-layout.  ``sensors()`` hides the difference.
+
+    vib_accel / vib_gyro: the reference's vib_def dicts ({'type': 'random' | 'sinusoidal', 'x', 'y', 'z'[, 'freq']},
+    ins_sim.py:642-701) -> the vibration term of pathgen.acc_gen / gyro_gen (pathgen.py:476-492, 538-556), fp64 only.
     """
 
     def __init__(self, ctx, fs, ref_frame, truth, accel_err, gyro_err, ini, runs, algos=('free',),
                  odo_err=None, earth_rot=True, seed=0, run_offset=0, ini_first=0,
                  keep_sensors=False, keep_traj=False, end_pos_ned=False, precision='f64', given=None,
-                 proc_first=None, proc_ned=False, end_ned=False):
+                 proc_first=None, proc_ned=False, end_ned=False, vib_accel=None, vib_gyro=None):
         self.ctx = ctx
         self.algos = tuple(algos)
         for a in self.algos:
@@ -398,7 +426,14 @@ class MonteCarloJob(object):
         if given is None:
             p.accel = sensor_model(accel_err, 'vrw', fs)
             p.gyro = sensor_model(gyro_err, 'arw', fs)
+            # vibration (Sim(env=...)): vib_def dicts as Sim.__parse_env makes them; the device kernels carry the term in fp64
+            p.vib_accel = vibration(vib_accel, float(fs), random_phase=False)
+            p.vib_gyro = vibration(vib_gyro, float(fs), random_phase=True)
+            if (p.vib_accel.type or p.vib_gyro.type) and precision != 'f64':
+                raise ValueError("a vibration model (env) needs precision='f64'")
         else:
+            if vib_accel is not None or vib_gyro is not None:
+                raise ValueError('given sensors: a vibration model cannot be added to sensor series that already exist')
             p.given_sensors = 1
             p.in_gyro = given['gyro'].ptr
             p.in_accel = given['accel'].ptr if 'accel' in given else None

@@ -71,7 +71,8 @@ def _key(seed):
     return int(np.random.randint(0, 2 ** 62)) if seed is None else int(seed)
 
 
-def _one_run_sensors(fs, ref_accel, ref_gyro, acc_err, gyro_err, ref_odo=None, odo_err=None, seed=None):
+def _one_run_sensors(fs, ref_accel, ref_gyro, acc_err, gyro_err, ref_odo=None, odo_err=None, seed=None, vib_accel=None,
+                     vib_gyro=None):
     """One realisation of the IMU error model over given truth series, on the device (sensors-only launch)."""
     import ginsim
     n = ref_accel.shape[0]
@@ -81,7 +82,7 @@ def _one_run_sensors(fs, ref_accel, ref_gyro, acc_err, gyro_err, ref_odo=None, o
     if ref_odo is not None:
         truth['ref_odo'] = np.ascontiguousarray(ref_odo, dtype=np.float64)
     job = ginsim.MonteCarloJob(ginsim.default_context(), fs, 0, truth, acc_err, gyro_err, None, runs=1, algos=(),
-                               odo_err=odo_err, seed=_key(seed), keep_sensors=True).run()
+                               odo_err=odo_err, seed=_key(seed), keep_sensors=True, vib_accel=vib_accel, vib_gyro=vib_gyro).run()
     return job
 
 
@@ -89,26 +90,20 @@ _QUIET = {'b': np.zeros(3), 'b_drift': np.zeros(3), 'b_corr': np.array([np.inf, 
           'vrw': np.zeros(3)}
 
 
-def _no_vibration(vib_def):
-    if vib_def is not None:
-        raise NotImplementedError('vibration models (vib_def) are outside the accelerated hot path (SURVEY.md section 2)')
-
-
 def acc_gen(fs, ref_a, acc_err, vib_def=None, *, seed=None):
-    """pathgen.acc_gen (pathgen.py:441-501): true specific force (n,3) + bias + Gauss-Markov drift + white noise."""
-    _no_vibration(vib_def)
+    """pathgen.acc_gen (pathgen.py:441-501): true specific force (n,3) + bias + Gauss-Markov drift + white noise + vibration
+    (vib_def: {'type': 'random' | 'sinusoidal', 'x', 'y', 'z'[, 'freq']}; a 'psd' vibration is outside the device path)."""
     ref_a = np.asarray(ref_a, dtype=np.float64)
-    job = _one_run_sensors(fs, ref_a, np.zeros_like(ref_a), acc_err, _QUIET, seed=seed)
+    job = _one_run_sensors(fs, ref_a, np.zeros_like(ref_a), acc_err, _QUIET, seed=seed, vib_accel=vib_def)
     out = job.sensors('accel', [0])[0]
     job.release()
     return out
 
 
 def gyro_gen(fs, ref_w, gyro_err, vib_def=None, *, seed=None):
-    """pathgen.gyro_gen (pathgen.py:503-563)."""
-    _no_vibration(vib_def)
+    """pathgen.gyro_gen (pathgen.py:503-563); a sinusoidal vibration gets a uniform random phase per axis (:553-555)."""
     ref_w = np.asarray(ref_w, dtype=np.float64)
-    job = _one_run_sensors(fs, np.zeros_like(ref_w), ref_w, _QUIET, gyro_err, seed=seed)
+    job = _one_run_sensors(fs, np.zeros_like(ref_w), ref_w, _QUIET, gyro_err, seed=seed, vib_gyro=vib_def)
     out = job.sensors('gyro', [0])[0]
     job.release()
     return out

@@ -30,6 +30,7 @@ Keyword-only extras (defaults keep the reference behaviour):
                        a checkout of the reference is named in $GNSS_INS_SIM_REFERENCE and ITS geomag.py is
                        evaluated once on the host (geoparams.reference_geomag_n; geo_mag_date pins the date).
 """
+import math
 import os
 import sys
 import time
@@ -166,9 +167,6 @@ class Sim(object):
         self.precision = precision      # 'f32': single-precision kernel (tolerances: tests/test_gpu_fp32.py)
         self.keep_runs, self.stats_start = max(int(keep_runs), 0), stats_start
         self.mc = None
-        if env is not None:
-            raise NotImplementedError('vibration models (env) are outside the accelerated hot path; every BASELINE '
-                                      'configuration uses env=None (SURVEY.md section 2, #15)')
 
     # ------------------------------------------------------------------------------------ run
     def run(self, num_times=1):
@@ -263,6 +261,20 @@ class Sim(object):
             if kinds[i] == 'odo' and not self.imu.odo:
                 raise ValueError("algorithm %d needs 'odo' but the IMU model has no odometer" % i)
 
+        # environment --> vibration parameters (ins_sim.py:482-489): 'random' and 'sinusoidal' models run in the kernels
+        vib_acc = vib_gyro = None
+        if self.env is not None:
+            if 'acc' in self.env.keys():
+                vib_acc = self._parse_env(self.env['acc'])
+            if 'gyro' in self.env.keys():
+                vib_gyro = self._parse_env(self.env['gyro'])
+            for v in (vib_acc, vib_gyro):
+                if v is not None:
+                    ginsim.vibration(v, fs_imu, False)       # raises for what the device path does not carry (a PSD)
+            if (vib_acc is not None or vib_gyro is not None) and self.precision != 'f64':
+                raise ValueError("a vibration model (env) needs precision='f64'")
+        vib = dict(vib_accel=vib_acc, vib_gyro=vib_gyro)
+
         rank, world, group, xdev = self._dist()
         first, count = distributed.shard(self.sim_count, world, rank)
         seed = self._pick_seed(group, xdev)
@@ -302,7 +314,7 @@ class Sim(object):
                                         g['ini'], runs=runs_, algos=tuple(kinds_), odo_err=self.imu.odo_err,
                                         earth_rot=g['earth_rot'], seed=seed, run_offset=first,
                                         ini_first=g['first'] + first, keep_sensors=keep_sens, keep_traj=keep_traj,
-                                        precision=self.precision, **kw)
+                                        precision=self.precision, **vib, **kw)
 
         f64 = self.precision == 'f64'
         online = (not keep) and f64 and self.stats_start is not None and self.stats_start != -1
@@ -339,7 +351,7 @@ class Sim(object):
             if not groups and kcount > 0:      # Sim without algorithm: sensor generation only (demo_no_algo.py)
                 sensor_job = ginsim.MonteCarloJob(ctx, fs_imu, self.ref_frame, truth, self.imu.accel_err,
                                                   self.imu.gyro_err, None, runs=kcount, algos=(), odo_err=self.imu.odo_err,
-                                                  seed=seed, run_offset=first, keep_sensors=True)
+                                                  seed=seed, run_offset=first, keep_sensors=True, **vib)
                 sensor_job.launch()
             ctx.sync()
         for i in fused:                         # FreeIntegration.run_times accounting (free_integration.py:69)
@@ -389,7 +401,7 @@ class Sim(object):
                 return ginsim.MonteCarloJob(ctx, fs_imu, self.ref_frame, truth, self.imu.accel_err, self.imu.gyro_err, g['ini'],
                                             runs=runs_, algos=(kinds[i],), odo_err=self.imu.odo_err, earth_rot=g['earth_rot'],
                                             seed=seed, run_offset=first + off, ini_first=g['first'] + first + off,
-                                            keep_sensors=False, keep_traj=True, precision=self.precision)
+                                            keep_sensors=False, keep_traj=True, precision=self.precision, **vib)
             esize = 4 if self.precision == 'f32' else 8
             block_runs = max(256, int(self.max_device_bytes // (9 * esize * n)) // 256 * 256)
             self.mc = _McResults([stats_jobs.get(i) for i in fused], [kept_jobs.get(i) for i in fused], names,
@@ -582,6 +594,50 @@ class Sim(object):
         return self.dmgr.get_data_properties(data_name)
 
     # ------------------------------------------------------------------------------------ helpers
+    def _parse_env(self, env):
+        """Sim.__parse_env (ins_sim.py:642-701): one entry of the env dict -> the vib_def dict acc_gen / gyro_gen take.
+        '[x y z]<g|d|>-random' (1 sigma) or '[x y z]<g|d|>-<f>Hz-sinusoidal' (peak); 'g' = 9.8 m/s^2, 'd' = deg/s;
+        an (n,4) array [freq, x, y, z] is a single-sided PSD, cut at fs/2."""
+        if env is None:
+            return None
+        if isinstance(env, np.ndarray):
+            if env.ndim == 2 and env.shape[1] == 4:
+                rows, half_fs = env.shape[0], 0.5 * self.fs[0]
+                if env[-1, 0] > half_fs:
+                    rows = np.where(env[:, 0] > half_fs)[0][0]
+                return {'type': 'psd', 'freq': env[:rows, 0], 'x': env[:rows, 1], 'y': env[:rows, 2], 'z': env[:rows, 3]}
+            raise TypeError('env should be of size (n,2)')
+        if not isinstance(env, str):
+            raise TypeError('env should be a string or a numpy array of size (n,2)')
+        text, vib = env.lower(), {}
+        if 'random' in text:
+            vib['type'] = 'random'
+            text = text.replace('-random', '')
+        elif 'sinusoidal' in text:
+            vib['type'] = 'sinusoidal'
+            text = text.replace('-sinusoidal', '')
+            if text[-2:] != 'hz':
+                raise ValueError('env = \'%s\' is not valid (No vib freq).' % text)
+            try:
+                mark = text.find('-')
+                vib['freq'] = math.fabs(float(text[mark + 1:-2]))
+                text = text[:mark]
+            except Exception:
+                raise ValueError('env = \'%s\' is not valid (invalid vib freq).' % text)
+        else:
+            raise ValueError('env = \'%s\' is not valid.' % text)
+        unit = 1.0                              # 1 sigma (random) or peak (sinusoidal)
+        if text[-1] == 'g':                     # accelerations in g
+            unit, text = 9.8, text[:-1]
+        elif text[-1] == 'd':                   # angular rates in deg/s
+            unit, text = attitude.D2R, text[:-1]
+        try:
+            amp = unit * np.array(text[1:-1].split(' '), dtype='float64')
+            vib['x'], vib['y'], vib['z'] = amp[0], amp[1], amp[2]
+        except Exception:
+            raise ValueError('Cannot convert \'%s\' to float' % text[1:-1].split(' '))
+        return vib
+
     @staticmethod
     def _parse_mode(mode):
         """Sim.__parse_mode (ins_sim.py:612-640)."""

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define GINSIM_ABI_VERSION 4
+#define GINSIM_ABI_VERSION 5
 
 /* status codes */
 #define GINSIM_OK          0
@@ -94,6 +94,24 @@ typedef struct {            /* one 3-axis sensor: pathgen.acc_gen / gyro_gen / b
     int32_t reserved;
 } ginsim_sensor_model;
 
+/* ABI 5.  The vibration term of one 3-axis sensor (pathgen.py:476-492 accel, :538-556 gyro; Sim.__parse_env, ins_sim.py:642-701,
+ * turns the env strings into these numbers).  meas = truth + bias + drift + white + VIB, added last as the reference does:
+ *   type 1 'random'      vib[j][k] = amp[k] N[j][k]                     (:485-488, :547-550; three more normals per sample)
+ *   type 2 'sinusoidal'  vib[j][k] = amp[k] sin(omega_dt j + phase[k])  omega_dt = 2 pi freq dt; phase = 0 for the accelerometer
+ *                        (:489-492), one uniform draw per run and axis times 2 pi for the gyroscope (:551-555)
+ * The 'psd' type (time_series_from_psd.py, an inverse FFT per run and axis) is outside the path.
+ * Vibration launches run on the general-sensor-model lane-per-run fp64 kernels (ginsim_mc_variant 0); precision 1, given
+ * sensors and sensor_layout 1 refuse it. */
+#define GINSIM_VIB_NONE       0
+#define GINSIM_VIB_RANDOM     1
+#define GINSIM_VIB_SINUSOIDAL 2
+typedef struct {
+    int32_t type;           /* GINSIM_VIB_* */
+    int32_t random_phase;   /* sinusoidal: 1 = a uniform phase per run and axis (gyro_gen), 0 = phase 0 (acc_gen) */
+    double  amp[3];         /* vib_def['x'/'y'/'z']: 1 sigma (random) or peak (sinusoidal), m/s^2 or rad/s */
+    double  omega_dt;       /* sinusoidal: ((2.0 * pi) * freq) * dt, rounded as the reference's left-to-right product */
+} ginsim_vibration;
+
 typedef struct {
     int64_t  n;             /* IMU samples per run */
     int64_t  runs;          /* Monte-Carlo runs on this device */
@@ -153,6 +171,8 @@ typedef struct {
                                * launches (algo_mask 0) take it; with <= 1024 runs and >= 2048 samples they run on the
                                * time-parallel series kernels (ginsim_mc_variant reports 2), otherwise layout 1 is refused. */
     int32_t   reserved4;
+    /* ---- ABI 5: vibration, Sim(env={'acc': ..., 'gyro': ...}) -> the vib term of pathgen.acc_gen / gyro_gen ---- */
+    ginsim_vibration vib_accel, vib_gyro;
 } ginsim_mc_params;
 
 int ginsim_mc_run(ginsim_ctx* ctx, const ginsim_mc_params* p);

@@ -176,6 +176,39 @@ static void sensor_gen(uint64_t seed, uint64_t run, uint32_t s0, int64_t n, cons
     }
 }
 
+/* The vibration term of acc_gen / gyro_gen (pathgen.py:476-492 / 538-556), added last (:500, :562).  type 1 'random':
+ * amp N[j] with the normals of streams s_xy, s_xy + 1 (oracle/philox.py vib_normals); type 2 'sinusoidal':
+ * amp sin(omega_dt j + phase), phase = (u 2) pi with u = word 2^-32 of the phase block for gyro_gen (random_phase), 0 for acc_gen. */
+typedef struct {
+    int32_t type, random_phase;
+    double amp[3];
+    double omega_dt;
+} vibration_t;
+
+static void vibration_add(uint64_t seed, uint64_t run, uint32_t s_xy, uint32_t s_phase, int64_t n, const vibration_t* v,
+                          double* meas) {
+    if (!v || v->type == 0) return;
+    if (v->type == 1) {
+        for (int64_t j = 0; j < n; ++j) {
+            double z[4];
+            normal_pair(seed, run, s_xy, (uint32_t)j, &z[0], &z[1]);
+            normal_pair(seed, run, s_xy + 1, (uint32_t)j, &z[2], &z[3]);
+            for (int i = 0; i < 3; ++i) meas[3 * j + i] = meas[3 * j + i] + v->amp[i] * z[i];
+        }
+        return;
+    }
+    double phase[3] = {0, 0, 0};
+    if (v->random_phase) {
+        uint32_t W[4] = {0u, s_phase >> 1, (uint32_t)run, (uint32_t)(run >> 32)};
+        philox4x32_7(W, (uint32_t)seed, (uint32_t)(seed >> 32));
+        for (int i = 0; i < 3; ++i) phase[i] = ((double)W[i] * 0x1p-32 * 2) * PI;
+    }
+    for (int64_t j = 0; j < n; ++j) {
+        const double cj = v->omega_dt * (double)j;
+        for (int i = 0; i < 3; ++i) meas[3 * j + i] = meas[3 * j + i] + v->amp[i] * sin(v->random_phase ? cj + phase[i] : cj);
+    }
+}
+
 /* ---------------------------------------------------------------- mechanisation of one run */
 /* att/pos/vel are [n][3] scratch (or output) arrays; odo == NULL selects free_integration.py */
 void oracle_free_integration(int ref_frame, double fs, int earth_rot, int64_t n, const double* gyro,
@@ -251,8 +284,19 @@ typedef struct {
 } oracle_mc_t;
 
 /* end_err [runs][9]; traj (optional) [n_keep][n][9] for the first n_keep runs; sens (optional) [n_keep][n][6] */
+int oracle_mc_run_vib(const oracle_mc_t* p, const vibration_t* vib_accel, const vibration_t* vib_gyro, const double* ini_table,
+                      const double* ref_accel, const double* ref_gyro, const double* ref_odo, double* end_err, int64_t n_keep,
+                      double* traj, double* sens);
+
 int oracle_mc_run(const oracle_mc_t* p, const double* ini_table, const double* ref_accel, const double* ref_gyro,
                   const double* ref_odo, double* end_err, int64_t n_keep, double* traj, double* sens) {
+    return oracle_mc_run_vib(p, NULL, NULL, ini_table, ref_accel, ref_gyro, ref_odo, end_err, n_keep, traj, sens);
+}
+
+/* the same with the vibration terms of Sim(env=...) (either may be NULL) */
+int oracle_mc_run_vib(const oracle_mc_t* p, const vibration_t* vib_accel, const vibration_t* vib_gyro, const double* ini_table,
+                      const double* ref_accel, const double* ref_gyro, const double* ref_odo, double* end_err, int64_t n_keep,
+                      double* traj, double* sens) {
     const int64_t n = p->n;
     int fail = 0;
 #pragma omp parallel
@@ -274,6 +318,8 @@ int oracle_mc_run(const oracle_mc_t* p, const double* ini_table, const double* r
                 const double* ini = ini_table + 10 * (call < (uint64_t)p->n_ini ? call : 0);
                 sensor_gen(p->seed, run, 0, n, ref_accel, &p->accel, acc);      /* ins_sim.py:491-493 */
                 sensor_gen(p->seed, run, 3, n, ref_gyro, &p->gyro, gyr);        /* ins_sim.py:494-496 */
+                vibration_add(p->seed, run, 10, 26, n, vib_accel, acc);
+                vibration_add(p->seed, run, 12, 24, n, vib_gyro, gyr);
                 if (p->algo_odo) {                                              /* ins_sim.py:504-506 */
                     for (int64_t j = 0; j < n; ++j) {
                         double z0, z1;

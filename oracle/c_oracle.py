@@ -1,6 +1,7 @@
 """ctypes access to the plain-C oracle (oracle/c/ginsim_oracle.c).  TEST ORACLE ONLY -- see
 oracle/__init__.py for who may import this."""
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -38,6 +39,23 @@ class McParams(C.Structure):
                 ('ref_end', C.c_double * 9)]
 
 
+class Vibration(C.Structure):
+    _fields_ = [('type', C.c_int32), ('random_phase', C.c_int32), ('amp', C.c_double * 3), ('omega_dt', C.c_double)]
+
+
+def _vibration(vib_def, fs, random_phase):
+    """vib_def dict of Sim.__parse_env (ins_sim.py:642-701) -> vibration_t; None -> NULL."""
+    if vib_def is None:
+        return None
+    v = Vibration()
+    v.type = {'random': 1, 'sinusoidal': 2}[vib_def['type'].lower()]
+    v.amp[:] = [float(vib_def['x']), float(vib_def['y']), float(vib_def['z'])]
+    if v.type == 2:
+        v.omega_dt = 2.0 * math.pi * float(vib_def['freq']) * (1.0 / fs)
+        v.random_phase = int(random_phase)
+    return v
+
+
 _lib = None
 
 
@@ -47,6 +65,9 @@ def lib():
         _lib = C.cdll.LoadLibrary(build())
         _lib.oracle_mc_run.restype = C.c_int
         _lib.oracle_mc_run.argtypes = [C.POINTER(McParams), _PD, _PD, _PD, _PD, _PD, C.c_int64, _PD, _PD]
+        _lib.oracle_mc_run_vib.restype = C.c_int
+        _lib.oracle_mc_run_vib.argtypes = [C.POINTER(McParams), C.POINTER(Vibration), C.POINTER(Vibration), _PD, _PD, _PD, _PD, _PD,
+                                           C.c_int64, _PD, _PD]
         _lib.oracle_free_integration.restype = None
         _lib.oracle_free_integration.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int64, _PD, _PD, _PD, _PD, C.c_int,
                                                  _PD, _PD, _PD]
@@ -82,8 +103,9 @@ def set_threads(k):
 
 
 def mc_run(seed, run_offset, runs, fs, ref_frame, truth, accel_err, gyro_err, ini, algo='free', odo_err=None,
-           earth_rot=True, ini_first=0, keep=0):
-    """Returns (end_err (runs,9), traj (keep,n,9) or None, sens (keep,n,6) or None)."""
+           earth_rot=True, ini_first=0, keep=0, vib_accel=None, vib_gyro=None):
+    """Returns (end_err (runs,9), traj (keep,n,9) or None, sens (keep,n,6) or None).  vib_accel / vib_gyro: the reference's
+    vib_def dicts ('random' | 'sinusoidal')."""
     ini = np.asarray(ini, dtype=np.float64)
     if ini.ndim == 1:
         ini = ini.reshape(-1, 1)
@@ -105,7 +127,9 @@ def mc_run(seed, run_offset, runs, fs, ref_frame, truth, accel_err, gyro_err, in
     out = np.empty((int(runs), 9))
     traj = np.empty((keep, n, 9)) if keep else None
     sens = np.empty((keep, n, 6)) if keep else None
-    rc = lib().oracle_mc_run(C.byref(p), _p(table), _p(ra), _p(rg), _p(ro), _p(out), int(keep), _p(traj), _p(sens))
+    va, vg = _vibration(vib_accel, fs, False), _vibration(vib_gyro, fs, True)
+    rc = lib().oracle_mc_run_vib(C.byref(p), None if va is None else C.byref(va), None if vg is None else C.byref(vg),
+                                 _p(table), _p(ra), _p(rg), _p(ro), _p(out), int(keep), _p(traj), _p(sens))
     if rc:
         raise MemoryError('oracle_mc_run')
     return out, traj, sens

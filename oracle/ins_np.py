@@ -275,8 +275,27 @@ def gm_coeffs(corr, drift, fs):
     return a, b, white
 
 
-def sensor_errors(fs, ref, err, rw_key, nd, nw):
-    """pathgen.acc_gen / gyro_gen (pathgen.py:441-501 / 503-563), no vibration.
+def vibration_series(fs, n, vib_def, nv=None, u=None):
+    """The vib term of pathgen.acc_gen / gyro_gen (pathgen.py:476-492 / 538-556) for R runs: (R,n,3) (or (1,n,3) when it is
+    the same for every run).  vib_def: the dict Sim.__parse_env makes ('random' | 'sinusoidal'; 'psd' is outside the path);
+    nv (R,n,3): the normals of a 'random' vibration; u (R,3) or None: the uniforms of a sinusoidal vibration's random phases
+    (gyro_gen: np.random.rand(1) per axis; None = phase 0, acc_gen)."""
+    amp = np.array([vib_def['x'], vib_def['y'], vib_def['z']], dtype=np.float64)
+    kind = vib_def['type'].lower()
+    if kind == 'random':
+        return amp * nv                                                     # pathgen.py:486-488
+    if kind == 'sinusoidal':
+        dt = 1.0 / fs
+        arg = 2.0 * math.pi * vib_def['freq'] * dt * np.arange(n)           # pathgen.py:490, left to right
+        if u is None:
+            return (amp * np.sin(arg)[:, None])[None]
+        phase = np.asarray(u, dtype=np.float64) * 2 * math.pi               # np.random.rand(1)*2*math.pi (:553)
+        return amp * np.sin(arg[None, :, None] + phase[:, None, :])
+    raise NotImplementedError(kind)
+
+
+def sensor_errors(fs, ref, err, rw_key, nd, nw, vib=None):
+    """pathgen.acc_gen / gyro_gen (pathgen.py:441-501 / 503-563); vib: the (R|1,n,3) vibration term (vibration_series) or None.
 
     ref (n,3) truth; err dict with 'b','b_drift','b_corr', rw_key in {'vrw','arw'};
     nd, nw (R,n,3) drift / white normals.  Returns (R,n,3).
@@ -292,7 +311,8 @@ def sensor_errors(fs, ref, err, rw_key, nd, nw):
             for j in range(1, n):                        # pathgen.py:589-590
                 d[:, j, i] = a[i] * d[:, j - 1, i] + b[i] * nd[:, j - 1, i]
     noise = nw * (np.asarray(err[rw_key], dtype=np.float64) / math.sqrt(dt))
-    return ref[None, :, :] + np.asarray(err['b'], dtype=np.float64) + d + noise
+    out = ref[None, :, :] + np.asarray(err['b'], dtype=np.float64) + d + noise
+    return out if vib is None else out + vib                                # pathgen.py:500, 562: the vibration is added last
 
 
 
@@ -393,7 +413,19 @@ def imu_err_dicts(imu):
             {k: np.array(v, dtype=np.float64) for k, v in imu.gyro_err.items()})
 
 
-def mc_sensors(seed, runs, fs, ref_accel, ref_gyro, accel_err, gyro_err):
+def mc_vibration(seed, runs, fs, n, vib_def, sensor):
+    """The vibration term of MC runs ``runs`` with the engine's counter RNG; sensor 'acc' | 'gyr' (gyro_gen draws random
+    phases for a sinusoidal vibration, acc_gen does not)."""
+    if vib_def is None:
+        return None
+    kind = vib_def['type'].lower()
+    if kind == 'random':
+        return vibration_series(fs, n, vib_def, nv=np.stack([philox.vib_normals(seed, r, n, sensor) for r in runs]))
+    u = np.stack([philox.vib_phase_uniforms(seed, r, sensor) for r in runs]) if sensor == 'gyr' else None
+    return vibration_series(fs, n, vib_def, u=u)
+
+
+def mc_sensors(seed, runs, fs, ref_accel, ref_gyro, accel_err, gyro_err, vib_accel=None, vib_gyro=None):
     """Sensor data of MC runs ``runs`` (1-D int array of global run ids) with the engine's
     counter RNG, following the loop body of Sim.__gen_data_from_pathgen (ins_sim.py:490-506)."""
     n = ref_accel.shape[0]
@@ -402,8 +434,8 @@ def mc_sensors(seed, runs, fs, ref_accel, ref_gyro, accel_err, gyro_err):
     nw_a = np.stack([x['acc_w'] for x in z])
     nd_g = np.stack([x['gyr_d'] for x in z])
     nw_g = np.stack([x['gyr_w'] for x in z])
-    accel = sensor_errors(fs, ref_accel, accel_err, 'vrw', nd_a, nw_a)
-    gyro = sensor_errors(fs, ref_gyro, gyro_err, 'arw', nd_g, nw_g)
+    accel = sensor_errors(fs, ref_accel, accel_err, 'vrw', nd_a, nw_a, mc_vibration(seed, runs, fs, n, vib_accel, 'acc'))
+    gyro = sensor_errors(fs, ref_gyro, gyro_err, 'arw', nd_g, nw_g, mc_vibration(seed, runs, fs, n, vib_gyro, 'gyr'))
     return accel, gyro
 
 

@@ -35,6 +35,10 @@ Stream ids (one stream -> two normals (z0, z1)):
     3: gyro  drift x, y     4: gyro  drift z, gyro  white x    5: gyro  white y, z
     6: odometer, -          7: mag x, y                        8: mag z, -
     15: gps pos x, y       16: gps pos z, vel x               17: gps vel y, z            (j = GPS sample index)
+    10: accel vib x, y     11: accel vib z, -                 12: gyro vib x, y           13: gyro vib z, -
+    ('random' vibration, Sim(env=...): one block per sensor and sample)
+    24 / 26: the three phase uniforms of a 'sinusoidal' gyro / accel vibration = words W0, W1, W2 of block 12 / 13 at
+    j = 0, u = W 2^-32 (one block per run and sensor)
 """
 import numpy as np
 
@@ -49,6 +53,8 @@ S_ACC_D_XY, S_ACC_DZ_WX, S_ACC_W_YZ = 0, 1, 2
 S_GYR_D_XY, S_GYR_DZ_WX, S_GYR_W_YZ = 3, 4, 5
 S_ODO, S_MAG_XY, S_MAG_Z = 6, 7, 8
 S_GPS_P_XY, S_GPS_PZ_VX, S_GPS_V_YZ = 15, 16, 17
+S_ACC_VIB_XY, S_ACC_VIB_Z, S_GYR_VIB_XY, S_GYR_VIB_Z = 10, 11, 12, 13
+S_GYR_VIB_PHASE, S_ACC_VIB_PHASE = 24, 26
 
 
 ROUNDS = 7
@@ -183,3 +189,22 @@ def gps_normals(seed, run, m):
     c = normal_pair(seed, run, S_GPS_V_YZ, j)
     return (np.stack([a[0], a[1], b[0]], axis=1),
             np.stack([b[1], c[0], c[1]], axis=1))
+
+
+def vib_normals(seed, run, n, sensor):
+    """(n,3) normals of a 'random' vibration (pathgen.py:485-488, 547-550); sensor 'acc' | 'gyr'."""
+    j = np.arange(n, dtype=np.uint64)
+    sxy, sz = (S_ACC_VIB_XY, S_ACC_VIB_Z) if sensor == 'acc' else (S_GYR_VIB_XY, S_GYR_VIB_Z)
+    a = normal_pair(seed, run, sxy, j)
+    b = normal_pair(seed, run, sz, j)
+    return np.stack([a[0], a[1], b[0]], axis=1)
+
+
+def vib_phase_uniforms(seed, run, sensor):
+    """(3,) uniforms in [0, 1) of a 'sinusoidal' vibration's random phases (np.random.rand(1) x 3, pathgen.py:553-555):
+    words 0..2 of the phase block at sample 0, times 2^-32."""
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    stream = S_ACC_VIB_PHASE if sensor == 'acc' else S_GYR_VIB_PHASE
+    run = np.uint64(run)
+    w = philox4x32(np.uint64(0), np.uint64(stream >> 1), run & MASK32, run >> np.uint64(32), seed & 0xFFFFFFFF, seed >> 32)
+    return np.array([float(w[0]), float(w[1]), float(w[2])]) * 2.0 ** -32

@@ -22,8 +22,13 @@ from . import philox
 
 
 class RandnShim:
-    def __init__(self, seed, n, acc_corr, gyro_corr, gps_m=0, mag=False, odo=False, first_run=0):
+    def __init__(self, seed, n, acc_corr, gyro_corr, gps_m=0, mag=False, odo=False, first_run=0, vib_acc=None, vib_gyro=None):
+        """vib_acc / vib_gyro: None | 'random' | 'sinusoidal' -- the vibration type Sim(env=...) gives each sensor: a 'random'
+        vibration draws randn(n) three times between the drift and the white-noise draws (pathgen.py:486-488, 548-550); a
+        'sinusoidal' gyro vibration draws np.random.rand(1) three times (:553-555), served by ``rand``."""
         self.seed, self.n = seed, n
+        self.vib = (vib_acc, vib_gyro)
+        self._phase_k = 0
         self.acc_inf = np.isinf(np.asarray(acc_corr, dtype=np.float64))
         self.gyro_inf = np.isinf(np.asarray(gyro_corr, dtype=np.float64))
         self.gps_m, self.mag, self.odo = gps_m, mag, odo
@@ -33,9 +38,13 @@ class RandnShim:
     def _plan(self):
         z = philox.imu_normals(self.seed, self.run, self.n)
         q = []
-        for d, w, inf in ((z['acc_d'], z['acc_w'], self.acc_inf), (z['gyr_d'], z['gyr_w'], self.gyro_inf)):
+        for d, w, inf, vib, sensor in ((z['acc_d'], z['acc_w'], self.acc_inf, self.vib[0], 'acc'),
+                                       (z['gyr_d'], z['gyr_w'], self.gyro_inf, self.vib[1], 'gyr')):
             for i in range(3):
                 q.append(d[:, i].copy() if inf[i] else d.copy())
+            if vib == 'random':
+                v = philox.vib_normals(self.seed, self.run, self.n, sensor)
+                q += [v[:, 0].copy(), v[:, 1].copy(), v[:, 2].copy()]
             q.append(w.copy())
         if self.gps_m:
             p, v = philox.gps_normals(self.seed, self.run, self.gps_m)
@@ -56,11 +65,21 @@ class RandnShim:
         return out
 
 
+    def rand(self, *shape):
+        """np.random.rand(1) of gyro_gen's sinusoidal vibration: the phase uniforms of the CURRENT run, x, y, z in turn."""
+        if tuple(shape) != (1,) or self.vib[1] != 'sinusoidal' or self.run == 0:
+            raise AssertionError('reference asked rand%s outside a sinusoidal gyro vibration' % (shape,))
+        u = philox.vib_phase_uniforms(self.seed, self.run - 1, 'gyr')[self._phase_k]
+        self._phase_k = (self._phase_k + 1) % 3
+        return np.array([u])
+
+
 @contextlib.contextmanager
 def injected(shim):
-    saved = np.random.randn
+    saved, saved_rand = np.random.randn, np.random.rand
     np.random.randn = shim
+    np.random.rand = shim.rand
     try:
         yield shim
     finally:
-        np.random.randn = saved
+        np.random.randn, np.random.rand = saved, saved_rand

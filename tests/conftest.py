@@ -37,6 +37,25 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
 
 
+def golden_vibration(g):
+    """(vib_def of the accelerometer, of the gyroscope) of a T3 golden made with Sim(env=...): the dicts the reference's own
+    Sim.__parse_env produced (ins_sim.py:642-701), or None."""
+    out = []
+    for sensor in ('acc', 'gyro'):
+        if 'vib_%s_type' % sensor not in g:
+            out.append(None)
+            continue
+        amp = g['vib_%s_amp' % sensor]
+        v = {'type': str(g['vib_%s_type' % sensor]), 'x': float(amp[0]), 'y': float(amp[1]), 'z': float(amp[2])}
+        if v['type'] == 'sinusoidal':
+            v['freq'] = float(g['vib_%s_freq' % sensor])
+        out.append(v)
+    return tuple(out)
+
+
+T3_VIB = ['t3_vib_random_rf1', 't3_vib_sin_rf0', 't3_vib_mixed_rf1']
+
+
 @pytest.fixture(scope='session')
 def golden():
     return load_golden

@@ -248,8 +248,9 @@ def err_dict_arrays(prefix, e):
     return {prefix + k: np.array(v, dtype=np.float64) for k, v in e.items()}
 
 
-def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=6, csv=None, fs=100.0):
-    """csv: a motion definition as text (default: the reference's 90-degree turn file, n = 1000 at 100 Hz)."""
+def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=6, csv=None, fs=100.0, env=None):
+    """csv: a motion definition as text (default: the reference's 90-degree turn file, n = 1000 at 100 Hz).
+    env: the reference's vibration dict ({'acc': '...', 'gyro': '...'}, ins_sim.py:108-124), string models only."""
     if csv is None:
         csv = MOTION + 'motion_def-90deg_turn.csv'
         ini = read_ini(csv)
@@ -269,9 +270,10 @@ def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=
     for a in algos:
         mod = free_integration_odo if a == 'odo' else free_integration
         objs.append(mod.FreeIntegration(ini.copy()))
-    sim = ins_sim.Sim([fs, fs_gps, 0.0], csv, ref_frame=ref_frame, imu=imu, algorithm=objs)
+    sim = ins_sim.Sim([fs, fs_gps, 0.0], csv, ref_frame=ref_frame, imu=imu, env=env, algorithm=objs)
+    kind = lambda e: None if e is None else ('random' if 'random' in e.lower() else 'sinusoidal')
     shim = RandnShim(SEED, n, imu.accel_err['b_corr'], imu.gyro_err['b_corr'], gps_m=m, mag=(axis == 9),
-                     odo=odo_opt is not None)
+                     odo=odo_opt is not None, vib_acc=kind((env or {}).get('acc')), vib_gyro=kind((env or {}).get('gyro')))
     with injected(shim):
         sim.run(R)
     assert shim.run == R and not shim.queue
@@ -284,6 +286,13 @@ def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=
     out.update(err_dict_arrays('gyro_', imu.gyro_err))
     out['accel'] = np.stack([d.accel.data[r][k] for r in range(R)])
     out['gyro'] = np.stack([d.gyro.data[r][k] for r in range(R)])
+    for sensor in ('acc', 'gyro'):          # the env strings and what the reference's own Sim.__parse_env makes of them
+        if env and sensor in env:
+            vd = sim._Sim__parse_env(env[sensor])
+            out['env_' + sensor] = np.array(env[sensor])
+            out['vib_%s_type' % sensor] = np.array(vd['type'])
+            out['vib_%s_amp' % sensor] = np.array([vd['x'], vd['y'], vd['z']], dtype=np.float64)
+            out['vib_%s_freq' % sensor] = np.float64(vd.get('freq', 0.0))
     if odo_opt is not None:
         out['ref_odo'] = d.ref_odo.data
         out['odo'] = np.stack([d.odo.data[r][k] for r in range(R)])
@@ -556,6 +565,9 @@ CASES = [
     ('t3_mag9_gps_rf0', 't3_mag9(0)', ['t3_mag9_gps_rf0.npz']),
     ('t3_mag9_gps_rf1', 't3_mag9(1)', ['t3_mag9_gps_rf1.npz']),
     ('t3_drive200_rf0', "t3_case('t3_drive200_rf0', 0, 'low-accuracy', True, {'scale': 0.998, 'stdv': 0.05}, ['fi', 'odo'], 2, fs_gps=5.0, csv=DRIVE, fs=200.0)", ['t3_drive200_rf0.npz']),
+    ('t3_vib_random_rf1', "t3_case('t3_vib_random_rf1', 1, 'mid-accuracy', False, None, ['fi'], 3, env={'acc': '[0.03 0.001 0.01]-random', 'gyro': '[0.1 0.2 0.3]d-random'})", ['t3_vib_random_rf1.npz']),
+    ('t3_vib_sin_rf0', "t3_case('t3_vib_sin_rf0', 0, 'low-accuracy', False, {'scale': 0.999, 'stdv': 0.1}, ['fi', 'odo'], 3, env={'acc': '[0.01 0.02 0.03]g-2.5Hz-sinusoidal', 'gyro': '[0.5 0.4 0.3]d-0.7Hz-sinusoidal'})", ['t3_vib_sin_rf0.npz']),
+    ('t3_vib_mixed_rf1', "t3_case('t3_vib_mixed_rf1', 1, dict(DEMO_IMU), False, None, ['fi'], 2, env={'acc': '[0.5 0.1 0.2]-12Hz-sinusoidal', 'gyro': '[0.002 0.001 0.003]-random'})", ['t3_vib_mixed_rf1.npz']),
     ('csv_case', 'csv_case()', ['csv_files_rf0.npz']),
     ('summary_case', 'summary_case()', ['summary_text_rf0.npz']),
     ('allan_case', 'allan_case()', ['allan_ref.npz']),

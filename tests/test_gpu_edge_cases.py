@@ -334,7 +334,7 @@ def test_time_parallel_series_general_sensor_model_and_ragged_lengths(ctx, runs,
 def test_pathgen_sensor_generators_under_their_reference_names(ctx):
     """pathgen.acc_gen / gyro_gen / odo_gen / gps_gen / mag_gen (pathgen.py:441-661) with the reference's signatures, served by the
     device: one realisation of the error model over given truth, equal to the oracle's for the same key; np.random.seed makes
-    a call repeatable as it does for the reference; vibration is refused."""
+    a call repeatable as it does for the reference; random / sinusoidal vibration on the device, a PSD refused."""
     from gnss_ins_sim.pathgen import pathgen
     from ginsim import workloads
     from oracle import ins_np
@@ -367,5 +367,82 @@ def test_pathgen_sensor_generators_under_their_reference_names(ctx):
     ref_mag = np.tile(np.array([30.0, 2.0, 40.0]), (500, 1))
     mg = pathgen.mag_gen(ref_mag, mag_err, seed=95)
     np.testing.assert_allclose(mg.mean(0), (ref_mag[0] + mag_err['hi']).dot(mag_err['si'].T), atol=0.05)
-    with pytest.raises(NotImplementedError):
-        pathgen.acc_gen(100.0, truth['ref_accel'], acc, vib_def={'type': 'random'})
+    # vib_def as the reference's callers pass it (pathgen.py:447-462): random / sinusoidal on the device, a PSD refused
+    vr = {'type': 'random', 'x': 0.3, 'y': 0.1, 'z': 0.2}
+    vs = {'type': 'sinusoidal', 'x': 0.02, 'y': 0.01, 'z': 0.03, 'freq': 3.0}
+    av = pathgen.acc_gen(100.0, truth['ref_accel'], acc, vr, seed=91)
+    a_ref, _ = ins_np.mc_sensors(91, np.array([0]), 100.0, truth['ref_accel'], zero, acc, quiet, vib_accel=vr)
+    np.testing.assert_allclose(av, a_ref[0], rtol=0, atol=1e-12)
+    assert 0.25 < (av - a)[:, 0].std() < 0.35                      # same key: the difference IS the vibration
+    wv = pathgen.gyro_gen(100.0, truth['ref_gyro'], gyr, vs, seed=92)
+    _, w_ref = ins_np.mc_sensors(92, np.array([0]), 100.0, zero, truth['ref_gyro'], quiet, gyr, vib_gyro=vs)
+    np.testing.assert_allclose(wv, w_ref[0], rtol=0, atol=1e-14)
+    assert abs(np.abs(wv - w)[:, 2].max() - 0.03) < 1e-3            # a sine of the peak value given
+    with pytest.raises(NotImplementedError, match='PSD'):
+        pathgen.acc_gen(100.0, truth['ref_accel'], acc, vib_def={'type': 'psd', 'freq': np.array([1.0, 10.0]), 'x': np.ones(2),
+                                                                'y': np.ones(2), 'z': np.ones(2)})
+
+
+VIB_CASES = {
+    'random': ({'type': 'random', 'x': 0.2, 'y': 0.05, 'z': 0.1}, {'type': 'random', 'x': 2e-3, 'y': 1e-3, 'z': 3e-3}),
+    'sinusoidal': ({'type': 'sinusoidal', 'x': 0.3, 'y': 0.1, 'z': 0.2, 'freq': 7.0},
+                   {'type': 'sinusoidal', 'x': 5e-3, 'y': 2e-3, 'z': 1e-3, 'freq': 0.9}),
+    'accel only': ({'type': 'sinusoidal', 'x': 0.0, 'y': 0.4, 'z': 0.0, 'freq': 21.5}, None),
+    'gyro only': (None, {'type': 'random', 'x': 1e-3, 'y': 1e-3, 'z': 1e-3}),
+}
+
+
+@pytest.mark.parametrize('case', sorted(VIB_CASES))
+@pytest.mark.parametrize('rf,algos', [(1, ('free',)), (0, ('free', 'odo')), (0, ('odo',))])
+def test_vibration_models_against_the_oracles(ctx, turn, case, rf, algos):
+    """Sim(env=...)'s vibration term in the fused kernel (ABI 5; pathgen.py:476-492, 538-556): a ragged batch with global run
+    ids offset, sensors per sample and end-point errors against the NumPy and the C restatements; the launch is invariant to
+    how the runs are split (counter RNG: the vibration normals and phases belong to the GLOBAL run id)."""
+    import ginsim
+    from ginsim import workloads
+    from oracle import ins_np, c_oracle
+    ini, truth = turn[rf]
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    va, vg = VIB_CASES[case]
+    odo_err = {'scale': 0.999, 'stdv': 0.1}
+    R, off, seed = 150, 4000, 1234
+    kw = dict(algos=algos, odo_err=odo_err, seed=seed, vib_accel=va, vib_gyro=vg)
+    job = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc, gyr, ini, runs=R, run_offset=off, keep_sensors=True, keep_traj=True, **kw).run()
+    assert job.kernel_name().endswith('true>') and ginsim.lib.ginsim_mc_variant is not None
+    runs = np.arange(off, off + R)
+    a_ref, g_ref = ins_np.mc_sensors(seed, runs, 100.0, truth['ref_accel'], truth['ref_gyro'], acc, gyr, va, vg)
+    pick = np.array([0, 63, 64, 149])
+    np.testing.assert_allclose(job.sensors('accel', pick), a_ref[pick], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(job.sensors('gyro', pick), g_ref[pick], rtol=0, atol=1e-14)
+    for a in algos:
+        end, _, _ = c_oracle.mc_run(seed, off, R, 100.0, rf, truth, acc, gyr, ini, algo=a, odo_err=odo_err, vib_accel=va, vib_gyro=vg)
+        got = job.end_errors(a)
+        np.testing.assert_allclose(got[:, 3:], end[:, 3:], rtol=0, atol=2e-8)      # |pos| ~ 5e6 m in ref_frame 1
+        assert np.max(np.abs(np.mod(got[:, :3] - end[:, :3] + np.pi, 2 * np.pi) - np.pi)) < 1e-9
+    # the same runs as two launches (statistics only) give the same end-point errors to the bit
+    parts = [ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc, gyr, ini, runs=r, run_offset=off + o, **kw).run() for o, r in ((0, 70), (70, 80))]
+    for a in algos:
+        assert np.array_equal(np.concatenate([q.end_errors(a) for q in parts]), job.end_errors(a))
+    for q in parts + [job]:
+        q.release()
+
+
+def test_vibration_is_refused_where_it_does_not_live(ctx, turn):
+    import ginsim
+    from ginsim import workloads
+    ini, truth = turn[1]
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    v = {'type': 'random', 'x': 0.1, 'y': 0.1, 'z': 0.1}
+    with pytest.raises(ValueError, match='f64'):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=64, precision='f32', vib_accel=v)
+    with pytest.raises(ValueError, match='unknown vibration type'):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=64, vib_gyro={'type': 'square', 'x': 1, 'y': 1, 'z': 1})
+    job = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=64, vib_accel=v)
+    job.params.vib_accel.type = 7
+    with pytest.raises(ValueError, match='vibration type'):
+        job.launch()
+    job.params.vib_accel.type = 1
+    job.params.vib_accel.amp[1] = float('nan')
+    with pytest.raises(ValueError, match='finite'):
+        job.launch()
+    job.release()

@@ -9,7 +9,7 @@ compared modulo 2*pi; end-point statistics 1e-7 relative (std of R=3..4 samples 
 import numpy as np
 import pytest
 
-from conftest import load_golden, assert_traj_close, ang_close
+from conftest import load_golden, assert_traj_close, ang_close, golden_vibration, T3_VIB
 
 pytestmark = pytest.mark.gpu
 
@@ -185,9 +185,10 @@ def _golden_algo_order(name):
     return [x.strip("' ") for x in m.group(1).strip('[]').split(',')]
 
 
-@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'])
+@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'] + T3_VIB)
 def test_t3_injected_noise_vs_reference(ctx, name):
-    """Unmodified reference Sim.run(R) fed the engine's Philox normals == fused kernel, per sample."""
+    """Unmodified reference Sim.run(R) fed the engine's Philox normals == fused kernel, per sample.  T3_VIB: the reference ran
+    with Sim(env=...) -- random / sinusoidal vibration on either sensor (pathgen.py:476-492, 538-556)."""
     import ginsim
     g = load_golden(name)
     R, k, fs, rf = int(g['R']), g['rows'], float(g['fs']), int(g['ref_frame'])
@@ -199,8 +200,11 @@ def test_t3_injected_noise_vs_reference(ctx, name):
     if 'odo' in g:
         truth['ref_odo'] = g['ref_odo']
         odo_err = {'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])}
+    vib_acc, vib_gyro = golden_vibration(g)
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc_err, gyr_err, g['ini'], runs=R, algos=algos, odo_err=odo_err,
-                               seed=int(g['seed']), keep_sensors=True, keep_traj=True).run()
+                               seed=int(g['seed']), keep_sensors=True, keep_traj=True, vib_accel=vib_acc, vib_gyro=vib_gyro).run()
+    if name in T3_VIB:
+        assert job.kernel_name().endswith(', true>') and job.kernel_name().startswith('ginsim::mc_kernel<'), job.kernel_name()
     runs = np.arange(R)
     np.testing.assert_allclose(job.sensors('accel', runs)[:, k], g['accel'], rtol=0, atol=1e-12)
     np.testing.assert_allclose(job.sensors('gyro', runs)[:, k], g['gyro'], rtol=0, atol=1e-14)

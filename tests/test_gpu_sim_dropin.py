@@ -76,6 +76,60 @@ def test_demo_free_integration_sequence(capsys):
     assert data[0] == 1 and data[1] == fs and data[2][3].shape == (1000, 3)
 
 
+@pytest.mark.parametrize('name,accuracy,rf,odo_opt,algo_tags,keep', [
+    ('t3_vib_random_rf1', 'mid-accuracy', 1, None, ['fi'], True),
+    ('t3_vib_sin_rf0', 'low-accuracy', 0, {'scale': 0.999, 'stdv': 0.1}, ['fi', 'odo'], True),
+    ('t3_vib_sin_rf0', 'low-accuracy', 0, {'scale': 0.999, 'stdv': 0.1}, ['fi', 'odo'], False),
+    ('t3_vib_mixed_rf1', _demo_imu(), 1, None, ['fi'], False)])
+def test_sim_with_a_vibration_environment(name, accuracy, rf, odo_opt, algo_tags, keep, capsys):
+    """Sim(env={'acc': ..., 'gyro': ...}) (ins_sim.py:108-124, 482-495): the env STRINGS the golden recipe gave the unmodified
+    reference, through the drop-in Sim -- sensor series per sample, end-point and process statistics as the reference computed
+    them on the same injected noise.  keep=False: nothing materialised, the statistics come from the kernels' accumulators
+    (the vibration variants of the online-statistics kernels)."""
+    from gnss_ins_sim.sim import imu_model
+    from gnss_ins_sim.sim import ins_sim
+    from demo_algorithms import free_integration_odo
+    from demo_algorithms import free_integration
+    g = load_golden(name)
+    env = {k: str(g['env_' + k]) for k in ('acc', 'gyro') if 'env_' + k in g}
+    assert env
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    imu = imu_model.IMU(accuracy=accuracy, axis=6, gps=False, odo=odo_opt is not None, odo_opt=odo_opt)
+    mods = {'fi': free_integration, 'odo': free_integration_odo}
+    algos = [mods[t].FreeIntegration(g['ini'].copy()) for t in algo_tags]
+    R = int(g['R'])
+    sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=rf, imu=imu, mode=None, env=env, algorithm=algos, seed=int(g['seed']),
+                      keep_trajectories=keep, keep_runs=0 if keep else 2, stats_start=2.0)
+    sim.run(R)
+    k = g['rows']
+    d = sim.dmgr
+    for r in range(R if keep else 2):
+        np.testing.assert_allclose(d.accel.data[r][k], g['accel'][r], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(d.gyro.data[r][k], g['gyro'][r], rtol=0, atol=1e-14)
+        for ai, t in enumerate(algo_tags):
+            key = 'algo%d_%d' % (ai, r) if len(algo_tags) > 1 else 'algo0_%d' % r
+            assert_traj_close(d.att_euler.data[key][k], d.pos.data[key][k], d.vel.data[key][k], g[t + '_att'][r], g[t + '_pos'][r],
+                              g[t + '_vel'][r], rtol=1e-9, what=name + t)
+    sim.results(err_stats_start=-1)
+    for dn in ('att_euler', 'pos', 'vel'):
+        st = sim.err_stats[dn]
+        for s in ('max', 'avg', 'std'):
+            for ai in range(len(algo_tags)):
+                got = st[s]['algo%d' % ai] if hasattr(st[s], 'keys') else st[s]
+                np.testing.assert_allclose(got, g['stat_%s_%s_algo%d' % (dn, s, ai)], rtol=1e-6, atol=1e-11)
+    # process statistics from t = 2 s (internal units in the golden)
+    sim.results(err_stats_start=2.0)
+    keys = ['algo%d_%d' % (ai, r) for ai in range(len(algo_tags)) for r in range(R)]
+    r2d = 180.0 / math.pi
+    unit = {'att_euler': np.full(3, r2d), 'pos': np.array([r2d, r2d, 1.0]) if rf == 0 else np.ones(3), 'vel': np.ones(3)}
+    for dn in ('att_euler', 'pos', 'vel'):
+        st = sim.err_stats[dn]
+        for s in ('max', 'avg', 'std'):
+            got = np.stack([np.asarray(st[s][kk]) for kk in keys])
+            np.testing.assert_allclose(got, g['proc_%s_%s' % (dn, s)] * unit[dn], rtol=2e-6, atol=1e-9)
+    capsys.readouterr()
+
+
 def test_plugin_run_given_data_like_openimu_demo():
     """demo_free_integration_openimu.py recipe: plugin.run() on logged data, ref_frame 0, external gravity."""
     from demo_algorithms import free_integration

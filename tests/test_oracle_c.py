@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import c_oracle, ins_np, philox
-from conftest import load_golden, assert_traj_close, ang_close
+from conftest import load_golden, assert_traj_close, ang_close, golden_vibration, T3_VIB
 
 
 def test_c_normals_match_numpy():
@@ -29,7 +29,7 @@ def _errs(g):
     return acc, gyr
 
 
-@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'])
+@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'] + T3_VIB)
 def test_c_t3_injected_noise(name):
     g = load_golden(name)
     R, k, fs, rf = int(g['R']), g['rows'], float(g['fs']), int(g['ref_frame'])
@@ -43,8 +43,9 @@ def test_c_t3_injected_noise(name):
     for a, tag in (('free', 'fi'), ('odo', 'odo')):
         if tag + '_att' not in g:
             continue
+        vib_acc, vib_gyro = golden_vibration(g)
         end, traj, sens = c_oracle.mc_run(int(g['seed']), 0, R, fs, rf, truth, acc_err, gyr_err, g['ini'], algo=a,
-                                          odo_err=odo_err, keep=R)
+                                          odo_err=odo_err, keep=R, vib_accel=vib_acc, vib_gyro=vib_gyro)
         np.testing.assert_allclose(sens[:, k, 0:3], g['accel'], rtol=0, atol=1e-12)
         np.testing.assert_allclose(sens[:, k, 3:6], g['gyro'], rtol=0, atol=1e-14)
         assert_traj_close(traj[:, k, 0:3], traj[:, k, 3:6], traj[:, k, 6:9], g[tag + '_att'], g[tag + '_pos'],
