@@ -13,7 +13,8 @@ Differences from the reference, all stated: ``path_gen`` leaves ``motion_def`` a
 overwrites ``motion_def[:, 7]`` and ``output_def[1:, 1]``, pathgen.py:122, 137, 143); only ``simulation_over_sample_rate``
 1 is built (every caller in the reference passes 1.0, ins_sim.py:459); the generators draw their noise from the engine's
 counter-based stream with a key taken from ``np.random`` -- so ``np.random.seed`` makes them
-repeatable, like the reference -- or from the keyword-only ``seed``; ``vib_def`` (vibration) is outside the hot path.
+repeatable, like the reference -- or from the keyword-only ``seed``; ``vib_def``: the 'random' and 'sinusoidal'
+vibration models are carried by the kernels, a 'psd' one (time_series_from_psd.py) is outside the hot path.
 There is no CPU implementation behind the generators: without a GPU they raise.
 """
 import math
