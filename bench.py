@@ -674,7 +674,7 @@ def main():
         r2d = 180.0 / np.pi
         build = lib_hash()
         kname = job.kernel_name()
-        given_name = 'ginsim::mc_kernel<%d, 1, true, false, 0>' % rf
+        given_name = 'ginsim::mc_kernel<%d, 1, true, false, 0, false>' % rf
         traffic, traffic_source, pmc = None, None, None
         if world == 1 and args.precision == 'f64' and keep:
             if args.pmc == 'live':

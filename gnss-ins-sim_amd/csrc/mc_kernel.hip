@@ -721,7 +721,7 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
                 else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1, true>), grid, block, lds, stream, p);
                 return hipGetLastError();
             }
-            GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d>", RF, ALGOS, ned ? 2 : 1)
+            GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d, false>", RF, ALGOS, ned ? 2 : 1)
             if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1>), grid, block, lds, stream, p);
             else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1>), grid, block, lds, stream, p);
             return hipGetLastError();
@@ -734,7 +734,7 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
             return hipGetLastError();
         }
     }
-    GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, %s, 0>", RF, ALGOS, tf(WD))
+    GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, %s, 0, false>", RF, ALGOS, tf(WD))
     hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, WD>), grid, block, lds, stream, p);
     return hipGetLastError();
 }
@@ -743,7 +743,7 @@ template <int RF, int ALGOS>
 static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
     if (p.given_sensors) {
         if constexpr (ALGOS != 0) {
-            GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, true, false, 0>", RF, ALGOS)
+            GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, true, false, 0, false>", RF, ALGOS)
             const int tb = p.block_threads > 0 ? p.block_threads : kBlock;
             const int64_t waves = (p.runs + kWave - 1) / kWave;
             const int per_cu = waves <= 1024 ? 1 : 2;

@@ -446,7 +446,7 @@ def test_dispatch_queries_and_sensor_layout_rules_without_a_gpu():
         return v.value, buf.value.decode()
 
     assert query(params()) == (1, 'ginsim::mc_kernel_split<1, 1, false, 2, true>')                    # C2: the wave-specialised kernel
-    assert query(params(given_sensors=1, in_gyro=4096, in_accel=4096)) == (0, 'ginsim::mc_kernel<1, 1, true, false, 0>')
+    assert query(params(given_sensors=1, in_gyro=4096, in_accel=4096)) == (0, 'ginsim::mc_kernel<1, 1, true, false, 0, false>')
     assert query(params(precision=1))[1].startswith('ginsim::f32::mc_kernel_f32_split<1, 1, false, 3,')
     # sensors only, few runs, long series: the time-parallel kernels -- with the series-major layout, or with one run (same thing)
     few = dict(algo_mask=0, runs=32, n=1440000)
