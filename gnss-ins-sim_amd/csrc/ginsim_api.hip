@@ -314,7 +314,8 @@ int ginsim_mc_kernel_name(const ginsim_mc_params* p, char* buf, size_t cap) {
     if (rc) return rc;
     buf[0] = 0;
     if (p->precision == 1) (void)launch_mc_f32(*p, nullptr, nullptr, buf, cap);
-    else if (series_path_applies(*p)) snprintf(buf, cap, "ginsim::series_kernel<1>");   // the dominant one of series_kernel<0>, series_scan_kernel, series_kernel<1>
+    else if (series_path_applies(*p))       // the dominant one of series_kernel<0>, series_scan_kernel, series_kernel<1 | 2>
+        snprintf(buf, cap, (p->vib_accel.type || p->vib_gyro.type) ? "ginsim::series_kernel<2>" : "ginsim::series_kernel<1>");
     else (void)launch_mc(*p, nullptr, buf, cap);
     REQUIRE(buf[0], "mc_kernel_name: no kernel serves these parameters");
     return GINSIM_OK;
@@ -374,8 +375,7 @@ static int check_mc_params(const ginsim_mc_params* p) {
         REQUIRE(v->type == GINSIM_VIB_NONE || v->type == GINSIM_VIB_RANDOM || v->type == GINSIM_VIB_SINUSOIDAL,
                 "mc_run: vibration type must be 0 (none), 1 (random) or 2 (sinusoidal)");
         if (v->type == GINSIM_VIB_NONE) continue;
-        REQUIRE(!p->given_sensors && p->precision == 0 && p->sensor_layout == 0,
-                "mc_run: a vibration term needs generate mode, fp64 and sensor_layout 0 (it lives in the lane-per-run fp64 kernels)");
+        REQUIRE(!p->given_sensors && p->precision == 0, "mc_run: a vibration term needs generate mode and fp64");
         REQUIRE(std::isfinite(v->amp[0]) && std::isfinite(v->amp[1]) && std::isfinite(v->amp[2]) && std::isfinite(v->omega_dt),
                 "mc_run: vibration amplitudes / frequency must be finite");
     }

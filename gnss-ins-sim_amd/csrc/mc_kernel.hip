@@ -878,8 +878,10 @@ static void scanq_host(double q, ScanQ* out) {
 
 constexpr int kSeriesBlock = 256;       // four wavefronts = four chunks per workgroup
 
+// PASS 0: pass A; 1: pass B; 2: pass B with the vibration term of Sim(env=...) (a per-sample term: nothing to scan)
 template <int PASS>
 __global__ void __launch_bounds__(kSeriesBlock) series_kernel(const ginsim_mc_params a, const SeriesPlan pl) {
+    constexpr bool VIB = PASS == 2;
     __shared__ uint32_t ntab[kNormalTableWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -933,6 +935,11 @@ __global__ void __launch_bounds__(kSeriesBlock) series_kernel(const ginsim_mc_pa
     double* const oa = a.out_accel ? a.out_accel + r * pl.sr : nullptr;
     double* const og = a.out_gyro ? a.out_gyro + r * pl.sr : nullptr;
     double* const oo = a.out_odo ? a.out_odo + r * pl.odo_sr : nullptr;
+    Vec3 vpa{0.0, 0.0, 0.0}, vpg{0.0, 0.0, 0.0};
+    if (VIB) {
+        vpa = vibration_phase<S_ACC_VIB_PHASE>(&kp->vib_accel, key);
+        vpg = vibration_phase<S_GYR_VIB_PHASE>(&kp->vib_gyro, key);
+    }
     for (int64_t jb = j0; jb < j1; jb += 64) {
         const int64_t j = jb + lane;
         const bool on = j < j1;
@@ -962,6 +969,11 @@ __global__ void __launch_bounds__(kSeriesBlock) series_kernel(const ginsim_mc_pa
                 const double tak = k == 0 ? ta.x : (k == 1 ? ta.y : ta.z), tgk = k == 0 ? tg.x : (k == 1 ? tg.y : tg.z);
                 o[k] = tak + ma->bias[k] + ua + ma->white[k] * zw[k];
                 o[3 + k] = tgk + mg->bias[k] + ug + mg->white[k] * zw[3 + k];
+            }
+            if (VIB) {          // added last, as pathgen.py:500, 562 do
+                const Vec3 va = add_vibration<S_ACC_VIB_XY>(Vec3{o[0], o[1], o[2]}, &kernarg_params()->vib_accel, key, (uint32_t)j, tab, vpa);
+                const Vec3 vg = add_vibration<S_GYR_VIB_XY>(Vec3{o[3], o[4], o[5]}, &kernarg_params()->vib_gyro, key, (uint32_t)j, tab, vpg);
+                o[0] = va.x; o[1] = va.y; o[2] = va.z; o[3] = vg.x; o[4] = vg.y; o[5] = vg.z;
             }
             if (oa) { st(oa + j * pl.sj, o[0]); st(oa + pl.sc + j * pl.sj, o[1]); st(oa + 2 * pl.sc + j * pl.sj, o[2]); }
             if (og) { st(og + j * pl.sj, o[3]); st(og + pl.sc + j * pl.sj, o[4]); st(og + 2 * pl.sc + j * pl.sj, o[5]); }
@@ -1001,7 +1013,7 @@ __global__ void __launch_bounds__(64) series_scan_kernel(const SeriesPlan pl, in
 
 // sensors only, few runs, long series
 bool series_path_applies(const ginsim_mc_params& p) {
-    return p.algo_mask == 0 && !p.given_sensors && p.precision == 0 && !p.wave_trace && p.block_threads == 0 && !any_vibration(p) &&
+    return p.algo_mask == 0 && !p.given_sensors && p.precision == 0 && !p.wave_trace && p.block_threads == 0 &&
            p.runs <= 1024 && p.n >= 2048 && (p.sensor_layout == 1 || p.runs == 1);
 }
 
@@ -1037,7 +1049,8 @@ hipError_t launch_series(const ginsim_mc_params& p, double* carry, hipStream_t s
     const dim3 grid((unsigned)((pl.nchunks + kSeriesBlock / 64 - 1) / (kSeriesBlock / 64)), (unsigned)p.runs), block(kSeriesBlock);
     hipLaunchKernelGGL((series_kernel<0>), grid, block, 0, stream, p, pl);
     hipLaunchKernelGGL(series_scan_kernel, dim3((unsigned)(p.runs * 6)), dim3(64), 0, stream, pl, p.runs);
-    hipLaunchKernelGGL((series_kernel<1>), grid, block, 0, stream, p, pl);
+    if (any_vibration(p)) hipLaunchKernelGGL((series_kernel<2>), grid, block, 0, stream, p, pl);
+    else hipLaunchKernelGGL((series_kernel<1>), grid, block, 0, stream, p, pl);
     return hipGetLastError();
 }
 

@@ -427,6 +427,37 @@ def test_vibration_models_against_the_oracles(ctx, turn, case, rf, algos):
         q.release()
 
 
+@pytest.mark.parametrize('case', sorted(VIB_CASES))
+@pytest.mark.parametrize('runs,n', [(1, 50000), (6, 4099)])
+def test_vibration_on_the_time_parallel_series_kernels(ctx, case, runs, n):
+    """Few runs, long series, Sim(env=...) -- the data generator of the Allan flow with a vibration environment: a per-sample term,
+    so pass B of the series kernels carries it (series_kernel<2>); against the oracle and against the lane-per-run kernel."""
+    import ginsim
+    from ginsim import workloads
+    from oracle import ins_np
+    ini, truth, _ = workloads.truth_from_profile('long_drive', 200.0, 0)
+    t = {k: (v[:n] if hasattr(v, 'shape') and v.shape and v.shape[0] > n else v) for k, v in truth.items()}
+    acc, gyr = workloads.imu_grade('low-accuracy')
+    va, vg = VIB_CASES[case]
+    job = ginsim.MonteCarloJob(ctx, 200.0, 0, t, acc, gyr, None, runs=runs, run_offset=9, algos=(), seed=31, keep_sensors=True,
+                               vib_accel=va, vib_gyro=vg).run()
+    assert job.sensor_layout == 'series' and job.kernel_name() == 'ginsim::series_kernel<2>'
+    ids = np.arange(runs)
+    a_ref, g_ref = ins_np.mc_sensors(31, 9 + ids, 200.0, t['ref_accel'], t['ref_gyro'], acc, gyr, va, vg)
+    np.testing.assert_allclose(job.sensors('accel', ids), a_ref, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(job.sensors('gyro', ids), g_ref, rtol=0, atol=1e-14)
+    big = ginsim.MonteCarloJob(ctx, 200.0, 0, t, acc, gyr, None, runs=1100, run_offset=9, algos=(), seed=31, keep_sensors=True,
+                               vib_accel=va, vib_gyro=vg).run()     # > 1024 runs: one lane per run
+    assert big.kernel_name() == 'ginsim::mc_kernel<0, 0, false, true, 0, true>'
+    np.testing.assert_allclose(job.sensors('accel', ids), big.sensors('accel', ids), rtol=0, atol=4e-15)
+    np.testing.assert_allclose(job.sensors('gyro', ids), big.sensors('gyro', ids), rtol=0, atol=2e-16)
+    if runs == 1:       # and through the Allan call of the job (series-major: no re-layout)
+        tau, ad = job.allan(names=('gyro',))
+        assert ad['gyro'].shape == (1, tau.size, 3) and np.all(np.isfinite(ad['gyro']))
+    big.release()
+    job.release()
+
+
 def test_vibration_is_refused_where_it_does_not_live(ctx, turn):
     import ginsim
     from ginsim import workloads

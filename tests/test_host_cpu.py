@@ -458,7 +458,7 @@ def test_dispatch_queries_and_sensor_layout_rules_without_a_gpu():
         with pytest.raises(ValueError, match='sensor_layout'):
             query(params(**bad))
     # ABI 5: a vibration term (Sim(env=...)) is served by the vibration variants of the plain general-model kernels, whatever
-    # the batch would otherwise run on; fp32, given sensors and the series-major layout refuse it
+    # the batch would otherwise run on (sensors only for few runs: pass B of the series kernels); fp32 and given sensors refuse it
     v = ginsim.vibration({'type': 'random', 'x': 0.1, 'y': 0.1, 'z': 0.1}, 100.0, False)
     s = ginsim.vibration({'type': 'sinusoidal', 'x': 0.1, 'y': 0.1, 'z': 0.1, 'freq': 2.0}, 100.0, True)
     assert (s.type, s.random_phase) == (2, 1) and s.omega_dt == 2.0 * np.pi * 2.0 * (1.0 / 100.0) and v.type == 1
@@ -466,8 +466,9 @@ def test_dispatch_queries_and_sensor_layout_rules_without_a_gpu():
     assert query(params(vib_gyro=s, ref_frame=0, algo_mask=3, ref_odo=4096)) == (0, 'ginsim::mc_kernel<0, 3, false, true, 0, true>')
     assert query(params(vib_gyro=s, ref_frame=0, ref_nav=4096, out_proc=(C.c_void_p * 2)(4096, None), proc_pos_ned=1)) == \
         (0, 'ginsim::mc_kernel<0, 1, false, true, 2, true>')
-    assert query(params(vib_accel=v, **few)) == (0, 'ginsim::mc_kernel<1, 0, false, true, 0, true>')       # not the series kernels
-    for bad in (dict(precision=1), dict(given_sensors=1, in_gyro=4096, in_accel=4096), dict(sensor_layout=1, **few)):
+    assert query(params(vib_accel=v, sensor_layout=1, **few)) == (2, 'ginsim::series_kernel<2>')           # per-sample term: time-parallel too
+    assert query(params(vib_accel=v, **few)) == (0, 'ginsim::mc_kernel<1, 0, false, true, 0, true>')
+    for bad in (dict(precision=1), dict(given_sensors=1, in_gyro=4096, in_accel=4096)):
         with pytest.raises(ValueError, match='vibration'):
             query(params(vib_accel=v, **bad))
 
