@@ -375,7 +375,7 @@ static int check_mc_params(const ginsim_mc_params* p) {
         REQUIRE(v->type == GINSIM_VIB_NONE || v->type == GINSIM_VIB_RANDOM || v->type == GINSIM_VIB_SINUSOIDAL,
                 "mc_run: vibration type must be 0 (none), 1 (random) or 2 (sinusoidal)");
         if (v->type == GINSIM_VIB_NONE) continue;
-        REQUIRE(!p->given_sensors && p->precision == 0, "mc_run: a vibration term needs generate mode and fp64");
+        REQUIRE(!p->given_sensors, "mc_run: a vibration term cannot be added to given sensors");
         REQUIRE(std::isfinite(v->amp[0]) && std::isfinite(v->amp[1]) && std::isfinite(v->amp[2]) && std::isfinite(v->omega_dt),
                 "mc_run: vibration amplitudes / frequency must be finite");
     }

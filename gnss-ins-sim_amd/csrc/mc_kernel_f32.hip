@@ -324,6 +324,55 @@ F32_FM V3 sense3(const double (&truth)[3], const Model& m, float (&drift)[3], co
     return V3{o[0], o[1], o[2]};
 }
 
+// The vibration term of Sim(env=...) in single precision (ABI 5; pathgen.py:476-492, 538-556), added last as the reference's sum
+// does and DEFINED like the rest of this file: the amplitudes rounded to float once; 'random': o = fma(amp, z, o) with the
+// normals of streams STREAM, STREAM + 1 (one Philox block); 'sinusoidal': the angle omega_dt * j (+ phase) in fp64 -- one
+// product, one sum --, its sine by sincos_def (fp64 polynomial, rounded to float once), o = fma(amp, sin, o).
+struct Vib { int type, random_phase; float amp[3]; double omega_dt, phase[3]; };
+
+template <uint32_t PHASE_STREAM>
+F32_FM void load_vib(const ginsim_vibration& v, const RngKey& key, Vib& o) {
+    o.type = v.type;
+    o.random_phase = v.random_phase;
+    o.omega_dt = v.omega_dt;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o.amp[i] = (float)v.amp[i]; o.phase[i] = 0.0; }
+    if (v.type == GINSIM_VIB_SINUSOIDAL && v.random_phase) {
+        const u32x4 w = philox4x32(0u, PHASE_STREAM >> 1, key.r0, key.r1, key.k0, key.k1);
+        o.phase[0] = ((double)w.x * 0x1p-32 * 2.0) * 3.14159265358979323846;
+        o.phase[1] = ((double)w.y * 0x1p-32 * 2.0) * 3.14159265358979323846;
+        o.phase[2] = ((double)w.z * 0x1p-32 * 2.0) * 3.14159265358979323846;
+    }
+}
+
+template <uint32_t STREAM>
+F32_FM V3 add_vibration(const V3& o, const Vib& v, const RngKey& key, uint32_t j, const NormalTables& tab) {
+    V3 r = o;
+    if (v.type == GINSIM_VIB_RANDOM) {
+        float z0[2], z1[2];
+        normal_pairs_f32<STREAM, 2>(key, j, z0, z1, tab);
+        r.x = fm(v.amp[0], z0[0], o.x);
+        r.y = fm(v.amp[1], z1[0], o.y);
+        r.z = fm(v.amp[2], z0[1], o.z);
+    } else if (v.type == GINSIM_VIB_SINUSOIDAL) {
+        const double cj = v.omega_dt * (double)j;
+        float sn[3], cs;
+        if (v.random_phase) {
+            sincos_def(cj + v.phase[0], sn[0], cs);
+            sincos_def(cj + v.phase[1], sn[1], cs);
+            sincos_def(cj + v.phase[2], sn[2], cs);
+        } else {
+            sincos_def(cj, sn[0], cs);
+            sn[1] = sn[0];
+            sn[2] = sn[0];
+        }
+        r.x = fm(v.amp[0], sn[0], o.x);
+        r.y = fm(v.amp[1], sn[1], o.y);
+        r.z = fm(v.amp[2], sn[2], o.z);
+    }
+    return r;
+}
+
 // first normal of the odometer stream (S_ODO = 6: the low half of block 3) at sample j
 F32_FM float odo_normal(const RngKey& key, uint32_t j, const NormalTables& tab) {
     const u32x4 w = philox4x32(j, S_ODO >> 1, key.r0, key.r1, key.k0, key.k1);
@@ -333,8 +382,9 @@ F32_FM float odo_normal(const RngKey& key, uint32_t j, const NormalTables& tab) 
     return z0[0];
 }
 
-template <int RF, int ALGOS, bool GIVEN, bool WD>
+template <int RF, int ALGOS, bool GIVEN, bool WD, bool VIB = false>
 __global__ void __launch_bounds__(256, 2) mc_kernel_f32(const ginsim_mc_params a) {
+    static_assert(!VIB || (!GIVEN && WD), "vibration: generate mode, general sensor model");
     __shared__ uint32_t ntab[GIVEN ? 4 : kNormalTableWords];
     NormalTables tab{};
     if (!GIVEN) {
@@ -359,6 +409,11 @@ __global__ void __launch_bounds__(256, 2) mc_kernel_f32(const ginsim_mc_params a
     load_model(a.gyro, mg);
     const float odo_scale = (float)a.odo_scale, odo_stdv = (float)a.odo_stdv;
     float da[3] = {0.f, 0.f, 0.f}, dg[3] = {0.f, 0.f, 0.f};
+    Vib va, vg;
+    if (VIB) {
+        load_vib<S_ACC_VIB_PHASE>(a.vib_accel, key, va);
+        load_vib<S_GYR_VIB_PHASE>(a.vib_gyro, key, vg);
+    }
     float* o_acc = reinterpret_cast<float*>(a.out_accel);
     float* o_gyr = reinterpret_cast<float*>(a.out_gyro);
     float* o_odo = reinterpret_cast<float*>(a.out_odo);
@@ -391,6 +446,10 @@ __global__ void __launch_bounds__(256, 2) mc_kernel_f32(const ginsim_mc_params a
             const float zdg[3] = {z0[3], z1[3], z0[4]}, zwg[3] = {z1[4], z0[5], z1[5]};
             acc = sense3<WD>(ta, ma, da, zda, zwa);
             gyr = sense3<WD>(tg, mg, dg, zdg, zwg);
+            if (VIB) {
+                acc = add_vibration<S_ACC_VIB_XY>(acc, va, key, jj, tab);
+                gyr = add_vibration<S_GYR_VIB_XY>(gyr, vg, key, jj, tab);
+            }
             if (o_acc) { st(o_acc + off, acc.x); st(o_acc + plane + off, acc.y); st(o_acc + 2 * plane + off, acc.z); }
             if (o_gyr) { st(o_gyr + off, gyr.x); st(o_gyr + plane + off, gyr.y); st(o_gyr + 2 * plane + off, gyr.z); }
             if (ODO || o_odo) {
@@ -650,7 +709,10 @@ static int keep_mode_f32(const ginsim_mc_params& p) {
     return all ? 1 : (none ? 0 : -1);
 }
 
+static bool any_vibration_f32(const ginsim_mc_params& p) { return p.vib_accel.type != GINSIM_VIB_NONE || p.vib_gyro.type != GINSIM_VIB_NONE; }
+
 int mc_variant_f32(const ginsim_mc_params& p) {
+    if (any_vibration_f32(p)) return 0;         // the vibration term lives in the plain kernel (general sensor model)
     if (!(p.algo_mask & GINSIM_ALGO_FREE) || p.given_sensors || p.block_threads != 0 || p.n < 2) return 0;      // block_threads: the plain kernel (tests)
     const int keep = keep_mode_f32(p);
     if (keep < 0) return 0;
@@ -712,13 +774,20 @@ static hipError_t launch3_f32(const ginsim_mc_params& p, const float* truth32, h
             return keep ? launch_split_f32<RF, ALGOS, WD, 1, true>(p, truth32, stream) : launch_split_f32<RF, ALGOS, WD, 1, false>(p, truth32, stream);
         }
     }
+    const bool vib = WD && any_vibration_f32(p);
     if (name) {
-        snprintf(name, cap, "ginsim::f32::mc_kernel_f32<%d, %d, false, %s>", RF, ALGOS, WD ? "true" : "false");
+        snprintf(name, cap, "ginsim::f32::mc_kernel_f32<%d, %d, false, %s, %s>", RF, ALGOS, WD ? "true" : "false", vib ? "true" : "false");
         return hipSuccess;
     }
     // exactly k workgroups per CU (k + 1 do not fit the LDS reservation)
     const int per_cu = waves <= 1024 ? 1 : (waves <= 2048 ? 2 : 3);
     const size_t lds = (160 * 1024) / (per_cu + 1) + 1024 - sizeof(uint32_t) * kNormalTableWords;
+    if constexpr (WD) {
+        if (vib) {
+            hipLaunchKernelGGL((f32::mc_kernel_f32<RF, ALGOS, false, true, true>), dim3((unsigned)((p.runs + tb - 1) / tb)), dim3(tb), lds, stream, p);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((f32::mc_kernel_f32<RF, ALGOS, false, WD>), dim3((unsigned)((p.runs + tb - 1) / tb)), dim3(tb), lds, stream, p);
     return hipGetLastError();
 }
@@ -727,7 +796,7 @@ template <int RF, int ALGOS>
 static hipError_t launch2_f32(const ginsim_mc_params& p, const float* truth32, hipStream_t stream, char* name, size_t cap) {
     if (p.given_sensors) {
         if (name) {
-            snprintf(name, cap, "ginsim::f32::mc_kernel_f32<%d, %d, true, false>", RF, ALGOS);
+            snprintf(name, cap, "ginsim::f32::mc_kernel_f32<%d, %d, true, false, false>", RF, ALGOS);
             return hipSuccess;
         }
         const int64_t waves = (p.runs + 63) / 64;
@@ -736,7 +805,8 @@ static hipError_t launch2_f32(const ginsim_mc_params& p, const float* truth32, h
         hipLaunchKernelGGL((f32::mc_kernel_f32<RF, ALGOS, true, false>), dim3((unsigned)((p.runs + 255) / 256)), dim3(256), lds, stream, p);
         return hipGetLastError();
     }
-    return any_white_drift_f32(p) ? launch3_f32<RF, ALGOS, true>(p, truth32, stream, name, cap) : launch3_f32<RF, ALGOS, false>(p, truth32, stream, name, cap);
+    return any_white_drift_f32(p) || any_vibration_f32(p) ? launch3_f32<RF, ALGOS, true>(p, truth32, stream, name, cap)
+                                                          : launch3_f32<RF, ALGOS, false>(p, truth32, stream, name, cap);
 }
 
 template <int RF>

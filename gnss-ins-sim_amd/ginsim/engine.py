@@ -377,7 +377,7 @@ class MonteCarloJob(object):
     1): that is the layout ginsim_allan reads, so ``allan()`` needs no re-layout.  ``sensors()`` hides the difference.
 
     vib_accel / vib_gyro: the reference's vib_def dicts ({'type': 'random' | 'sinusoidal', 'x', 'y', 'z'[, 'freq']},
-    ins_sim.py:642-701) -> the vibration term of pathgen.acc_gen / gyro_gen (pathgen.py:476-492, 538-556), fp64 only.
+    ins_sim.py:642-701) -> the vibration term of pathgen.acc_gen / gyro_gen (pathgen.py:476-492, 538-556).
     """
 
     def __init__(self, ctx, fs, ref_frame, truth, accel_err, gyro_err, ini, runs, algos=('free',),
@@ -426,11 +426,10 @@ class MonteCarloJob(object):
         if given is None:
             p.accel = sensor_model(accel_err, 'vrw', fs)
             p.gyro = sensor_model(gyro_err, 'arw', fs)
-            # vibration (Sim(env=...)): vib_def dicts as Sim.__parse_env makes them; the device kernels carry the term in fp64
+            # vibration (Sim(env=...)): vib_def dicts as Sim.__parse_env makes them; the lane-per-run kernels of both precisions
+            # and the time-parallel series kernels carry the term
             p.vib_accel = vibration(vib_accel, float(fs), random_phase=False)
             p.vib_gyro = vibration(vib_gyro, float(fs), random_phase=True)
-            if (p.vib_accel.type or p.vib_gyro.type) and precision != 'f64':
-                raise ValueError("a vibration model (env) needs precision='f64'")
         else:
             if vib_accel is not None or vib_gyro is not None:
                 raise ValueError('given sensors: a vibration model cannot be added to sensor series that already exist')

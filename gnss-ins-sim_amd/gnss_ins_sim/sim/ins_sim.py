@@ -271,8 +271,6 @@ class Sim(object):
             for v in (vib_acc, vib_gyro):
                 if v is not None:
                     ginsim.vibration(v, fs_imu, False)       # raises for what the device path does not carry (a PSD)
-            if (vib_acc is not None or vib_gyro is not None) and self.precision != 'f64':
-                raise ValueError("a vibration model (env) needs precision='f64'")
         vib = dict(vib_accel=vib_acc, vib_gyro=vib_gyro)
 
         rank, world, group, xdev = self._dist()

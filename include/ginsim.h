@@ -100,8 +100,9 @@ typedef struct {            /* one 3-axis sensor: pathgen.acc_gen / gyro_gen / b
  *   type 2 'sinusoidal'  vib[j][k] = amp[k] sin(omega_dt j + phase[k])  omega_dt = 2 pi freq dt; phase = 0 for the accelerometer
  *                        (:489-492), one uniform draw per run and axis times 2 pi for the gyroscope (:551-555)
  * The 'psd' type (time_series_from_psd.py, an inverse FFT per run and axis) is outside the path.
- * Vibration launches run on the general-sensor-model lane-per-run fp64 kernels (ginsim_mc_variant 0) or, sensors only for few
- * runs, on the time-parallel series kernels (variant 2); precision 1 and given sensors refuse it. */
+ * Vibration launches run on the general-sensor-model lane-per-run kernels (ginsim_mc_variant 0; fp64 and fp32 -- the fp32 term
+ * is defined operation by operation, csrc/mc_kernel_f32.hip add_vibration) or, sensors only for few runs, on the time-parallel
+ * series kernels (variant 2); given sensors refuse it. */
 #define GINSIM_VIB_NONE       0
 #define GINSIM_VIB_RANDOM     1
 #define GINSIM_VIB_SINUSOIDAL 2

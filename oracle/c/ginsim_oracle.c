@@ -606,8 +606,49 @@ void oracle_free_integration_f32_given(int ref_frame, double fs, int earth_rot, 
 
 /* end_err [runs][9] (double); traj (optional) [n_keep][n][9] float = att3, position displacement3, vel3; sens (optional)
  * [n_keep][n][6] float; odo_out (optional) [n_keep][n] float */
+/* the vibration term in single precision, as csrc/mc_kernel_f32.hip add_vibration defines it: amplitudes rounded to float;
+ * 'random' o = fma(amp, z, o); 'sinusoidal' the angle omega_dt * j (+ phase) in fp64, its sine by sincos_def, o = fma(amp, sin, o) */
+static void vibration_add_f32(uint64_t seed, uint64_t run, uint32_t s_xy, uint32_t s_phase, int64_t n, const vibration_t* v,
+                              float* meas) {
+    if (!v || v->type == 0) return;
+    const float amp[3] = {(float)v->amp[0], (float)v->amp[1], (float)v->amp[2]};
+    if (v->type == 1) {
+        for (int64_t j = 0; j < n; ++j) {
+            float z[4];
+            normal_pair_f32(seed, run, s_xy, (uint32_t)j, &z[0], &z[1]);
+            normal_pair_f32(seed, run, s_xy + 1, (uint32_t)j, &z[2], &z[3]);
+            for (int i = 0; i < 3; ++i) meas[3 * j + i] = fmaf(amp[i], z[i], meas[3 * j + i]);
+        }
+        return;
+    }
+    double phase[3] = {0, 0, 0};
+    if (v->random_phase) {
+        uint32_t W[4] = {0u, s_phase >> 1, (uint32_t)run, (uint32_t)(run >> 32)};
+        philox4x32_7(W, (uint32_t)seed, (uint32_t)(seed >> 32));
+        for (int i = 0; i < 3; ++i) phase[i] = ((double)W[i] * 0x1p-32 * 2) * PI;
+    }
+    for (int64_t j = 0; j < n; ++j) {
+        const double cj = v->omega_dt * (double)j;
+        for (int i = 0; i < 3; ++i) {
+            float sn, cs;
+            sincos_def(v->random_phase ? cj + phase[i] : cj, &sn, &cs);
+            meas[3 * j + i] = fmaf(amp[i], sn, meas[3 * j + i]);
+        }
+    }
+}
+
+int oracle_mc_run_f32_vib(const oracle_mc_t* p, const vibration_t* vib_accel, const vibration_t* vib_gyro, const double* ini_table,
+                          const double* ref_accel, const double* ref_gyro, const double* ref_odo, double* end_err, int64_t n_keep,
+                          float* traj, float* sens, float* odo_out);
+
 int oracle_mc_run_f32(const oracle_mc_t* p, const double* ini_table, const double* ref_accel, const double* ref_gyro,
                       const double* ref_odo, double* end_err, int64_t n_keep, float* traj, float* sens, float* odo_out) {
+    return oracle_mc_run_f32_vib(p, NULL, NULL, ini_table, ref_accel, ref_gyro, ref_odo, end_err, n_keep, traj, sens, odo_out);
+}
+
+int oracle_mc_run_f32_vib(const oracle_mc_t* p, const vibration_t* vib_accel, const vibration_t* vib_gyro, const double* ini_table,
+                          const double* ref_accel, const double* ref_gyro, const double* ref_odo, double* end_err, int64_t n_keep,
+                          float* traj, float* sens, float* odo_out) {
     const int64_t n = p->n;
     int fail = 0;
 #pragma omp parallel
@@ -629,6 +670,8 @@ int oracle_mc_run_f32(const oracle_mc_t* p, const double* ini_table, const doubl
                 const double* ini = ini_table + 10 * (call < (uint64_t)p->n_ini ? call : 0);
                 sensor_gen_f32(p->seed, run, 0, n, ref_accel, &p->accel, acc);
                 sensor_gen_f32(p->seed, run, 3, n, ref_gyro, &p->gyro, gyr);
+                vibration_add_f32(p->seed, run, 10, 26, n, vib_accel, acc);
+                vibration_add_f32(p->seed, run, 12, 24, n, vib_gyro, gyr);
                 if (ref_odo) {
                     for (int64_t j = 0; j < n; ++j) {
                         float z0, z1;

@@ -75,6 +75,9 @@ def lib():
         _lib.oracle_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, _PD, _PD]
         _lib.oracle_mc_run_f32.restype = C.c_int
         _lib.oracle_mc_run_f32.argtypes = [C.POINTER(McParams), _PD, _PD, _PD, _PD, _PD, C.c_int64, _PF, _PF, _PF]
+        _lib.oracle_mc_run_f32_vib.restype = C.c_int
+        _lib.oracle_mc_run_f32_vib.argtypes = [C.POINTER(McParams), C.POINTER(Vibration), C.POINTER(Vibration), _PD, _PD, _PD, _PD, _PD,
+                                               C.c_int64, _PF, _PF, _PF]
         _lib.oracle_free_integration_f32_given.restype = None
         _lib.oracle_free_integration_f32_given.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int64, _PD, _PD, _PD, _PD, C.c_int,
                                                            _PF, _PF, _PF, _PD]
@@ -140,7 +143,7 @@ def _pf(a):
 
 
 def mc_run_f32(seed, run_offset, runs, fs, ref_frame, truth, accel_err, gyro_err, ini, algo='free', odo_err=None,
-               earth_rot=True, ini_first=0, keep=0):
+               earth_rot=True, ini_first=0, keep=0, vib_accel=None, vib_gyro=None):
     """The float restatement (oracle_mc_run_f32): what the fp32 kernel must reproduce to the bit.
     Returns (end_err (runs,9) float64, traj (keep,n,9) float32 = att3, position DISPLACEMENT3, vel3, sens (keep,n,6) float32,
     odo (keep,n) float32 or None)."""
@@ -166,7 +169,9 @@ def mc_run_f32(seed, run_offset, runs, fs, ref_frame, truth, accel_err, gyro_err
     traj = np.empty((keep, n, 9), dtype=np.float32) if keep else None
     sens = np.empty((keep, n, 6), dtype=np.float32) if keep else None
     odo = np.empty((keep, n), dtype=np.float32) if (keep and ro is not None) else None
-    rc = lib().oracle_mc_run_f32(C.byref(p), _p(table), _p(ra), _p(rg), _p(ro), _p(out), int(keep), _pf(traj), _pf(sens), _pf(odo))
+    va, vg = _vibration(vib_accel, fs, False), _vibration(vib_gyro, fs, True)
+    rc = lib().oracle_mc_run_f32_vib(C.byref(p), None if va is None else C.byref(va), None if vg is None else C.byref(vg),
+                                     _p(table), _p(ra), _p(rg), _p(ro), _p(out), int(keep), _pf(traj), _pf(sens), _pf(odo))
     if rc:
         raise MemoryError('oracle_mc_run_f32')
     return out, traj, sens, odo

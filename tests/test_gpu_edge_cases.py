@@ -464,8 +464,11 @@ def test_vibration_is_refused_where_it_does_not_live(ctx, turn):
     ini, truth = turn[1]
     acc, gyr = workloads.imu_grade('mid-accuracy')
     v = {'type': 'random', 'x': 0.1, 'y': 0.1, 'z': 0.1}
-    with pytest.raises(ValueError, match='f64'):
-        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=64, precision='f32', vib_accel=v)
+    given = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=64, keep_sensors=True).run()
+    with pytest.raises(ValueError, match='given sensors'):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, None, None, ini, runs=64, vib_accel=v,
+                             given={'gyro': given.buffer('gyro'), 'accel': given.buffer('accel')})
+    given.release()
     with pytest.raises(ValueError, match='unknown vibration type'):
         ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=64, vib_gyro={'type': 'square', 'x': 1, 'y': 1, 'z': 1})
     job = ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=64, vib_accel=v)

@@ -13,7 +13,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_golden, ang_close
+from conftest import load_golden, ang_close, golden_vibration, T3_VIB
 
 pytestmark = pytest.mark.gpu
 ZERO = {'b': np.zeros(3), 'b_drift': np.zeros(3), 'b_corr': np.full(3, 100.0), 'arw': np.zeros(3), 'vrw': np.zeros(3)}
@@ -54,8 +54,10 @@ def _close_to_f64(att, dpos_plus, vel, a64, p64, v64, rf, what, scale=1.0):
 
 
 @pytest.mark.parametrize('plain', [False, True])
-@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'])
+@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'] + T3_VIB)
 def test_fp32_kernel_equals_float_oracle_and_reference_t3(ctx, name, plain):
+    """T3_VIB: with the vibration term of Sim(env=...) -- defined in single precision like the rest (mc_kernel_f32.hip add_vibration),
+    so the float oracle reproduces it to the bit; against the reference run with env within the fp32 tolerances."""
     import ginsim
     from oracle import c_oracle
     g = load_golden(name)
@@ -69,18 +71,22 @@ def test_fp32_kernel_equals_float_oracle_and_reference_t3(ctx, name, plain):
         truth['ref_odo'] = g['ref_odo']
         odo_err = {'scale': float(g['odo_scale']), 'stdv': float(g['odo_stdv'])}
     RR = 70                      # more runs than the golden holds: a ragged wavefront; the first R are the golden's
+    vib_acc, vib_gyro = golden_vibration(g)
+    vib = vib_acc is not None or vib_gyro is not None
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc_err, gyr_err, g['ini'], runs=RR, algos=tuple(algos), odo_err=odo_err,
-                               seed=seed, keep_sensors=True, keep_traj=True, precision='f32')
+                               seed=seed, keep_sensors=True, keep_traj=True, precision='f32', vib_accel=vib_acc, vib_gyro=vib_gyro)
     if plain:
         job.params.block_threads = 256
     job.run()
-    assert ('split' in job.kernel_name()) == (not plain and 'free' in algos), job.kernel_name()
+    assert ('split' in job.kernel_name()) == (not plain and 'free' in algos and not vib), job.kernel_name()
+    assert job.kernel_name().endswith(', true>') == vib or 'split' in job.kernel_name(), job.kernel_name()
     ids = np.arange(RR)
     scale = 5.0 if g['ref_accel'].shape[0] > 1000 else 1.0
     for a, tag in (('free', 'fi'), ('odo', 'odo')):
         if a not in algos:
             continue
-        end, traj, sens, odo = c_oracle.mc_run_f32(seed, 0, RR, fs, rf, truth, acc_err, gyr_err, g['ini'], algo=a, odo_err=odo_err, keep=RR)
+        end, traj, sens, odo = c_oracle.mc_run_f32(seed, 0, RR, fs, rf, truth, acc_err, gyr_err, g['ini'], algo=a, odo_err=odo_err, keep=RR,
+                                                   vib_accel=vib_acc, vib_gyro=vib_gyro)
         _bits_equal(job.sensors('accel', ids), sens[:, :, 0:3], name + ' accel')
         _bits_equal(job.sensors('gyro', ids), sens[:, :, 3:6], name + ' gyro')
         if odo is not None:
@@ -391,5 +397,34 @@ def test_sim_fp32_results_with_the_reference_defaults(ctx):
     for dn in ('att_euler', 'pos', 'vel'):
         for s in ('max', 'avg', 'std'):
             np.testing.assert_array_equal(stats['kept'][dn][s], stats['blocks'][dn][s])       # same runs, same kernel, same reduction
+            scale = np.abs(stats['f64'][dn]['max']).max()
+            np.testing.assert_allclose(stats['kept'][dn][s], stats['f64'][dn][s], rtol=0, atol=2e-3 * scale + 1e-7)
+
+
+def test_sim_fp32_with_a_vibration_environment(ctx):
+    """Sim(precision='f32', env=...): the vibration variants of the float kernel behind the drop-in Sim -- kept trajectories and
+    statistics only (re-integrated block by block) agree with each other and, within the fp32 tolerance, with the fp64 Sim."""
+    import contextlib
+    import io
+    import os
+    from conftest import PKG
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration
+    g = load_golden('t3_vib_sin_rf0')
+    env = {k: str(g['env_' + k]) for k in ('acc', 'gyro')}
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    stats = {}
+    for tag, kw in (('f64', dict(precision='f64')), ('kept', dict(precision='f32', keep_trajectories=True)),
+                    ('blocks', dict(precision='f32', keep_trajectories=False, max_device_bytes=9 * 4 * 1000 * 300))):
+        imu = imu_model.IMU(accuracy='low-accuracy', axis=6, gps=False)
+        sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=0, imu=imu, env=env, algorithm=free_integration.FreeIntegration(g['ini']),
+                          seed=int(g['seed']), **kw)
+        sim.run(600)
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim.results(err_stats_start=-1)
+        stats[tag] = {dn: {s: np.asarray(sim.err_stats[dn][s]) for s in ('max', 'avg', 'std')} for dn in ('att_euler', 'pos', 'vel')}
+    for dn in ('att_euler', 'pos', 'vel'):
+        for s in ('max', 'avg', 'std'):
+            np.testing.assert_array_equal(stats['kept'][dn][s], stats['blocks'][dn][s])
             scale = np.abs(stats['f64'][dn]['max']).max()
             np.testing.assert_allclose(stats['kept'][dn][s], stats['f64'][dn][s], rtol=0, atol=2e-3 * scale + 1e-7)

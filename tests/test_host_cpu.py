@@ -458,7 +458,7 @@ def test_dispatch_queries_and_sensor_layout_rules_without_a_gpu():
         with pytest.raises(ValueError, match='sensor_layout'):
             query(params(**bad))
     # ABI 5: a vibration term (Sim(env=...)) is served by the vibration variants of the plain general-model kernels, whatever
-    # the batch would otherwise run on (sensors only for few runs: pass B of the series kernels); fp32 and given sensors refuse it
+    # the batch would otherwise run on (sensors only for few runs: pass B of the series kernels; fp32: the plain float kernel); given sensors refuse it
     v = ginsim.vibration({'type': 'random', 'x': 0.1, 'y': 0.1, 'z': 0.1}, 100.0, False)
     s = ginsim.vibration({'type': 'sinusoidal', 'x': 0.1, 'y': 0.1, 'z': 0.1, 'freq': 2.0}, 100.0, True)
     assert (s.type, s.random_phase) == (2, 1) and s.omega_dt == 2.0 * np.pi * 2.0 * (1.0 / 100.0) and v.type == 1
@@ -468,9 +468,9 @@ def test_dispatch_queries_and_sensor_layout_rules_without_a_gpu():
         (0, 'ginsim::mc_kernel<0, 1, false, true, 2, true>')
     assert query(params(vib_accel=v, sensor_layout=1, **few)) == (2, 'ginsim::series_kernel<2>')           # per-sample term: time-parallel too
     assert query(params(vib_accel=v, **few)) == (0, 'ginsim::mc_kernel<1, 0, false, true, 0, true>')
-    for bad in (dict(precision=1), dict(given_sensors=1, in_gyro=4096, in_accel=4096)):
-        with pytest.raises(ValueError, match='vibration'):
-            query(params(vib_accel=v, **bad))
+    assert query(params(vib_accel=v, precision=1)) == (0, 'ginsim::f32::mc_kernel_f32<1, 1, false, true, true>')
+    with pytest.raises(ValueError, match='vibration'):
+        query(params(vib_accel=v, given_sensors=1, in_gyro=4096, in_accel=4096))
 
 
 def test_env_strings_parse_like_the_reference_and_bad_ones_raise():
@@ -500,6 +500,3 @@ def test_env_strings_parse_like_the_reference_and_bad_ones_raise():
     s2 = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, env={'acc': psd}, algorithm=None)
     with pytest.raises(NotImplementedError, match='PSD'):
         s2.run(1)
-    s3 = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, env={'gyro': '[1 1 1]d-random'}, algorithm=None, precision='f32')
-    with pytest.raises(ValueError, match='f64'):
-        s3.run(1)
