@@ -1,0 +1,144 @@
+"""Randomised differential test of the hot path: seeded random motion profiles (all five command types, aggressive rates so that
+the pitch fold and the +-2 pi wraps of attitude.euler_update_zyx are exercised), random IMU error models (finite / infinite
+correlation times, constant biases, zero axes), random vibration environments, both frames, every algorithm set, ragged run
+counts, 64-bit run offsets -- device against the C restatement (oracle/c/ginsim_oracle.c) and against itself under sharding
+(fp64: to 1e-8 up to the Euler singularity, see the comment in the test; fp32: bit for bit, singularity or not).
+The truth comes from the native path generator (pinned against the reference by tests/test_host_cpu.py); sizes are small, the
+whole file takes seconds."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+D2R = np.pi / 180
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import ginsim
+    c = ginsim.Context(0)
+    yield c
+    c.close()
+
+
+def _random_case(i):
+    import ginsim
+    rng = np.random.RandomState(7000 + i)
+    rf = int(rng.randint(0, 2))
+    fs = float(rng.choice([50.0, 100.0, 200.0]))
+    ini = np.array([rng.uniform(-70, 70) * D2R, rng.uniform(-170, 170) * D2R, rng.uniform(0, 800), rng.uniform(0, 20), 0.0, 0.0,
+                    rng.uniform(-180, 180) * D2R, rng.uniform(-20, 20) * D2R, rng.uniform(-30, 30) * D2R])
+    segs = []
+    for _ in range(rng.randint(1, 5)):
+        t = int(rng.randint(1, 6))
+        dur = float(rng.uniform(1.0, 6.0))
+        if t == 1:      # rates: up to a full pitch-over within the segment
+            segs.append([t, rng.uniform(-60, 60), rng.uniform(-50, 50), rng.uniform(-90, 90), rng.uniform(-2, 2), 0.0, 0.0, dur, 1])
+        elif t in (2, 4):
+            segs.append([t, rng.uniform(-180, 180), rng.uniform(-60, 60), rng.uniform(-120, 120), rng.uniform(0, 20) if t == 2 else rng.uniform(-4, 4),
+                         0.0, 0.0, dur, 1])
+        else:
+            segs.append([t, rng.uniform(-170, 170), rng.uniform(-40, 40), rng.uniform(-90, 90), rng.uniform(0, 20) if t == 5 else rng.uniform(-4, 4),
+                         0.0, 0.0, dur, 1])
+    md = np.array(segs, dtype=np.float64)
+    md[:, 1:4] *= D2R
+    mob = (rng.uniform(1.0, 8.0), rng.uniform(20.0, 200.0) * D2R, rng.uniform(40.0, 300.0) * D2R)
+    raw = ginsim.pathgen(ini, md, fs, 0.0, mob, rf)
+    truth = {'ref_accel': np.ascontiguousarray(raw['imu'][:, 1:4]), 'ref_gyro': np.ascontiguousarray(raw['imu'][:, 4:7]),
+             'ref_pos': np.ascontiguousarray(raw['nav'][:, 1:4]), 'ref_vel': np.ascontiguousarray(raw['nav'][:, 4:7]),
+             'ref_att': np.ascontiguousarray(raw['nav'][:, 7:10]), 'ref_odo': np.ascontiguousarray(raw['odo'][:, 2])}
+
+    def corr():
+        c = rng.uniform(0.5, 500.0, 3)
+        c[rng.rand(3) < 0.25] = np.inf
+        return c
+
+    def maybe_zero(v):
+        v = np.array(v, dtype=np.float64)
+        v[rng.rand(3) < 0.2] = 0.0
+        return v
+    acc = {'b': maybe_zero(rng.normal(0, 0.02, 3)) if rng.rand() < 0.5 else np.zeros(3), 'b_drift': maybe_zero(rng.uniform(1e-5, 5e-4, 3)),
+           'b_corr': corr(), 'vrw': maybe_zero(rng.uniform(1e-4, 2e-3, 3))}
+    gyr = {'b': maybe_zero(rng.normal(0, 1e-3, 3)) if rng.rand() < 0.5 else np.zeros(3), 'b_drift': maybe_zero(rng.uniform(1e-6, 1e-4, 3)),
+           'b_corr': corr(), 'arw': maybe_zero(rng.uniform(1e-5, 5e-4, 3))}
+
+    def vib(scale):
+        k = rng.randint(0, 3)
+        if k == 0:
+            return None
+        v = {'type': 'random' if k == 1 else 'sinusoidal', 'x': rng.uniform(0, scale), 'y': rng.uniform(0, scale), 'z': rng.uniform(0, scale)}
+        if k == 2:
+            v['freq'] = rng.uniform(0.1, 0.45 * fs)
+        return v
+    algos = [('free',), ('odo',), ('free', 'odo')][rng.randint(0, 3)]
+    return dict(rf=rf, fs=fs, ini=ini, truth=truth, acc=acc, gyr=gyr, va=vib(0.5), vg=vib(5e-3), algos=algos,
+                odo_err={'scale': rng.uniform(0.99, 1.01), 'stdv': rng.uniform(0.0, 0.2)}, runs=int(rng.randint(1, 200)),
+                off=int(rng.choice([0, 12345, 2 ** 40 + 17])), seed=int(rng.randint(0, 2 ** 62)), earth_rot=bool(rng.randint(0, 2)))
+
+
+@pytest.mark.parametrize('i', range(40))
+def test_random_configuration_against_the_c_oracle(ctx, i):
+    import ginsim
+    from oracle import c_oracle
+    c = _random_case(i)
+    kw = dict(algos=c['algos'], odo_err=c['odo_err'], earth_rot=c['earth_rot'], seed=c['seed'], vib_accel=c['va'], vib_gyro=c['vg'])
+    R, off = c['runs'], c['off']
+    job = ginsim.MonteCarloJob(ctx, c['fs'], c['rf'], c['truth'], c['acc'], c['gyr'], c['ini'], runs=R, run_offset=off, keep_sensors=True,
+                               keep_traj=True, **kw).run()
+    keep = min(R, 3)
+    n = c['truth']['ref_accel'].shape[0]
+    for a in c['algos']:
+        end, traj, sens = c_oracle.mc_run(c['seed'], off, R, c['fs'], c['rf'], c['truth'], c['acc'], c['gyr'], c['ini'], algo=a, odo_err=c['odo_err'],
+                                          earth_rot=c['earth_rot'], keep=keep, vib_accel=c['va'], vib_gyro=c['vg'])
+        ids = np.arange(keep)
+        np.testing.assert_allclose(job.sensors('accel', ids), sens[:, :, 0:3], rtol=0, atol=2e-12, err_msg='case %d accel' % i)
+        np.testing.assert_allclose(job.sensors('gyro', ids), sens[:, :, 3:6], rtol=0, atol=2e-14, err_msg='case %d gyro' % i)
+        att, pos, vel = job.trajectories(a, ids)
+        # The Euler-rate integration of the reference (attitude.py:679-721) divides by cos(pitch): a run that passes the
+        # singularity amplifies rounding differences without bound (the NumPy and the C restatement then differ from EACH OTHER:
+        # 5e-4 rad in case 23, min |cos pitch| 8e-5) and may take the pitch fold on one side only.  Such a run is compared up to
+        # the sample where |cos pitch| first drops below 0.02; what follows is as (in)accurate in every implementation.
+        tol = 1e-8 * max(1.0, n / 1000.0)
+        for r in range(keep):
+            near = np.where(np.abs(np.cos(traj[r, :, 1])) < 0.02)[0]
+            upto = int(near[0]) if near.size else n
+            if upto < 2:
+                continue
+            d = np.mod(att[r, :upto] - traj[r, :upto, 0:3] + np.pi, 2 * np.pi) - np.pi
+            assert np.abs(d).max() < tol, 'case %d %s run %d attitude %.3e (compared %d of %d samples)' % (i, a, r, np.abs(d).max(), upto, n)
+            scale = np.maximum(1.0, np.abs(traj[r, :upto, 3:9]))
+            err = np.abs(np.concatenate([pos[r, :upto], vel[r, :upto]], axis=1) - traj[r, :upto, 3:9]) / scale
+            assert err.max() < tol, 'case %d %s run %d pos/vel %.3e (compared %d of %d samples)' % (i, a, r, err.max(), upto, n)
+    # sharding: the same global runs as two launches, nothing kept -> the same end-point errors to the bit
+    if R >= 2:
+        cut = R // 3 + 1
+        parts = [ginsim.MonteCarloJob(ctx, c['fs'], c['rf'], c['truth'], c['acc'], c['gyr'], c['ini'], runs=r, run_offset=off + o, **kw).run()
+                 for o, r in ((0, cut), (cut, R - cut))]
+        for a in c['algos']:
+            assert np.array_equal(np.concatenate([q.end_errors(a) for q in parts]), job.end_errors(a)), 'case %d shard' % i
+        for q in parts:
+            q.release()
+    job.release()
+
+
+@pytest.mark.parametrize('i', range(40, 52))
+def test_random_configuration_fp32_against_the_float_oracle(ctx, i):
+    """The same generator through the single-precision kernels: bit for bit against the float restatement."""
+    import ginsim
+    from oracle import c_oracle
+    c = _random_case(i)
+    algos = tuple(a for a in c['algos'])
+    R, off = min(c['runs'], 70), c['off']
+    job = ginsim.MonteCarloJob(ctx, c['fs'], c['rf'], c['truth'], c['acc'], c['gyr'], c['ini'], runs=R, run_offset=off, keep_sensors=True,
+                               keep_traj=True, precision='f32', algos=algos, odo_err=c['odo_err'], earth_rot=c['earth_rot'], seed=c['seed'],
+                               vib_accel=c['va'], vib_gyro=c['vg']).run()
+    ids = np.arange(R)
+    for a in algos:
+        end, traj, sens, odo = c_oracle.mc_run_f32(c['seed'], off, R, c['fs'], c['rf'], c['truth'], c['acc'], c['gyr'], c['ini'], algo=a,
+                                                   odo_err=c['odo_err'], earth_rot=c['earth_rot'], keep=R, vib_accel=c['va'], vib_gyro=c['vg'])
+        for name, dev, ora in (('accel', job.sensors('accel', ids), sens[:, :, 0:3]), ('gyro', job.sensors('gyro', ids), sens[:, :, 3:6])):
+            assert np.array_equal(dev.astype(np.float32), ora), 'case %d %s: %d samples differ' % (i, name, int((dev.astype(np.float32) != ora).sum()))
+        att, dpos, vel = job.trajectories(a, ids, displacement=True)
+        for name, dev, ora in (('att', att, traj[:, :, 0:3]), ('displacement', dpos, traj[:, :, 3:6]), ('vel', vel, traj[:, :, 6:9])):
+            bad = dev.astype(np.float32) != ora
+            assert not bad.any(), 'case %d %s %s: %d of %d samples differ' % (i, a, name, int(bad.sum()), bad.size)
+    job.release()
