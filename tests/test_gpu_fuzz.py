@@ -142,3 +142,66 @@ def test_random_configuration_fp32_against_the_float_oracle(ctx, i):
             bad = dev.astype(np.float32) != ora
             assert not bad.any(), 'case %d %s %s: %d of %d samples differ' % (i, a, name, int(bad.sum()), bad.size)
     job.release()
+
+
+@pytest.mark.parametrize('i', range(60, 76))
+def test_random_configuration_statistics_replay_and_series(ctx, i):
+    """The other launch forms on the same random configurations: online process statistics (statistics-only kernels) against the
+    kernel that reads kept trajectories and against the NumPy restatement of InsDataMgr.__process_error_stats; the given-sensors
+    replay (the plugin boundary for a whole batch) bit for bit; the time-parallel series path against the lane-per-run kernels."""
+    import ginsim
+    from oracle import ins_np
+    c = _random_case(i)
+    rng = np.random.RandomState(9000 + i)
+    a = c['algos'][int(rng.randint(0, len(c['algos'])))]
+    R, off = c['runs'], c['off']
+    n = c['truth']['ref_accel'].shape[0]
+    kw = dict(odo_err=c['odo_err'], earth_rot=c['earth_rot'], seed=c['seed'], vib_accel=c['va'], vib_gyro=c['vg'])
+    kept = ginsim.MonteCarloJob(ctx, c['fs'], c['rf'], c['truth'], c['acc'], c['gyr'], c['ini'], runs=R, run_offset=off, algos=(a,),
+                                keep_sensors=True, keep_traj=True, **kw).run()
+    first = int(rng.randint(0, n - 1))
+    ned = bool(c['rf'] == 0 and rng.randint(0, 2))
+    online = ginsim.MonteCarloJob(ctx, c['fs'], c['rf'], c['truth'], c['acc'], c['gyr'], c['ini'], runs=R, run_offset=off, algos=(a,),
+                                  proc_first=first, proc_ned=ned, end_ned=(c['rf'] == 0), **kw).run()
+    assert np.array_equal(online.end_errors(a), kept.end_errors(a)), 'case %d: statistics-only launch, other trajectories' % i
+    st = online.process_stats_online(a)
+    st_kept = kept.process_stats(a, first, pos_ned=ned)
+    # raw sums (online) against Welford (kept): the floor of the raw-sum form is 1.5e-8 |mean| on the std (DESIGN 4.1b)
+    # NED metres are a difference of ECEF coordinates (6e6 m: an ulp is 1e-9 m) formed by two different instruction sequences
+    ecef = np.zeros(9)
+    if ned:
+        ecef[3:6] = 2e-8
+    floor = 3e-8 * np.abs(st_kept[:, 1]) + 1e-13 + ecef
+    assert np.all(np.abs(st[:, 0] - st_kept[:, 0]) <= 1e-12 * st_kept[:, 0] + 1e-15 + ecef), 'case %d max' % i
+    assert np.all(np.abs(st[:, 1] - st_kept[:, 1]) <= 1e-9 * np.abs(st_kept[:, 1]) + 1e-13 + ecef), 'case %d mean' % i
+    assert np.all(np.abs(st[:, 2] - st_kept[:, 2]) <= 1e-7 * st_kept[:, 2] + floor), 'case %d std' % i
+    ids = np.arange(min(R, 4))
+    att, pos, vel = kept.trajectories(a, ids)
+    want = ins_np.process_error_stats(att, pos, vel, c['truth']['ref_att'], c['truth']['ref_pos'], c['truth']['ref_vel'], first, pos_ned=ned)
+    np.testing.assert_allclose(st_kept[ids], want, rtol=1e-8, atol=1e-12 + (2e-8 if ned else 0.0), err_msg='case %d kept statistics vs NumPy' % i)
+    # the plugin boundary for a batch: FreeIntegration.run on the device-resident sensors of `kept`
+    given = {'gyro': kept.buffer('gyro')}
+    if a == 'free':
+        given['accel'] = kept.buffer('accel')
+    else:
+        given['odo'] = kept.buffer('odo')
+    rep = ginsim.MonteCarloJob(ctx, c['fs'], c['rf'], c['truth'], None, None, c['ini'], runs=R, algos=(a,), earth_rot=c['earth_rot'],
+                               keep_traj=True, given=given).run()
+    for x, y in zip(rep.trajectories(a, ids), (att, pos, vel)):
+        assert np.array_equal(x, y), 'case %d: replay of the materialised sensors differs' % i
+    assert np.array_equal(rep.end_errors(a), kept.end_errors(a))
+    # sensors only, few runs, the truth tiled to a long series: time-parallel kernels against one lane per run
+    reps = int(np.ceil(2300.0 / n))
+    long_truth = {k: (np.tile(v, (reps, 1)) if v.ndim == 2 else np.tile(v, reps)) for k, v in c['truth'].items()}
+    few = int(rng.randint(1, 6))
+    skw = dict(algos=(), odo_err=c['odo_err'], seed=c['seed'], vib_accel=c['va'], vib_gyro=c['vg'], keep_sensors=True)
+    ser = ginsim.MonteCarloJob(ctx, c['fs'], c['rf'], long_truth, c['acc'], c['gyr'], None, runs=few, run_offset=off, **skw).run()
+    lane = ginsim.MonteCarloJob(ctx, c['fs'], c['rf'], long_truth, c['acc'], c['gyr'], None, runs=1030, run_offset=off, **skw).run()
+    assert ser.sensor_layout == 'series' and lane.sensor_layout == 'runs'
+    sid = np.arange(few)
+    sa = np.abs(long_truth['ref_accel']).max() + 1.0
+    np.testing.assert_allclose(ser.sensors('accel', sid), lane.sensors('accel', sid), rtol=0, atol=4e-16 * sa * 8, err_msg='case %d series accel' % i)
+    np.testing.assert_allclose(ser.sensors('gyro', sid), lane.sensors('gyro', sid), rtol=0, atol=2e-15, err_msg='case %d series gyro' % i)
+    np.testing.assert_allclose(ser.sensors('odo', sid), lane.sensors('odo', sid), rtol=0, atol=1e-13, err_msg='case %d series odo' % i)
+    for q in (kept, online, rep, ser, lane):
+        q.release()
