@@ -738,6 +738,12 @@ def main():
                                'materialised (60 B/sample*MC)', 'turn_90deg', 100.0, 1, 65536, True, 'f32', 20, traffic=traffic))
             legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32_262144', 'fp32 kernel, 262 144 runs, materialised', 'turn_90deg', 100.0, 1,
                                262144, True, 'f32', 10))
+            # Sim(env=...) (beyond BASELINE's configurations, all of which use env=None): the C2 launch in a vibration environment
+            legs.append(leg_mc(ginsim, workloads, ctx, 'C2_vibration_random', 'the C2 launch with Sim(env={acc: [0.03 0.03 0.03]g-random, '
+                               'gyro: [0.5 0.5 0.5]d-random}): the vibration variant of the plain general-model kernel', 'turn_90deg',
+                               100.0, 1, 65536, True, 'f64', 10,
+                               vib_accel={'type': 'random', 'x': 0.294, 'y': 0.294, 'z': 0.294},
+                               vib_gyro={'type': 'random', 'x': 0.5 * np.pi / 180, 'y': 0.5 * np.pi / 180, 'z': 0.5 * np.pi / 180}))
             legs.append(leg_allan(ginsim, workloads, ctx, pmc=pmc))
             legs.append(leg_sim_e2e(workloads))
             out['configs'] = legs
