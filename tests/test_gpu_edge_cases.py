@@ -161,6 +161,12 @@ def test_argument_validation(ctx, turn):
         ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4).run().trajectories('free', [0])   # not kept
     with pytest.raises(ValueError, match='out of range'):
         ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=4, keep_traj=True).run().trajectories('free', [4])
+    # empty batches are refused by the C ABI, not launched (a rank without runs simply has no job: ginsim.distributed.shard)
+    with pytest.raises(ValueError, match='must be >= 1'):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=0).run()
+    none = {k: (v[:0] if hasattr(v, 'shape') and v.ndim >= 1 and v.shape[0] > 1 else v) for k, v in truth.items()}
+    with pytest.raises((ValueError, IndexError)):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, none, acc, gyr, ini, runs=4).run()
 
 
 @pytest.mark.parametrize('rf,algos,keep,precision', [(1, ('free',), True, 'f64'), (0, ('free', 'odo'), False, 'f64'),
