@@ -19,6 +19,7 @@
 #include "ginsim.h"
 #include "ins_math.hpp"
 #include "philox.hpp"
+#include "device_once.hpp"
 
 namespace ginsim {
 
@@ -681,26 +682,24 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
                 const bool keep = p.out_accel || p.out_gyro || p.out_odo || p.out_traj[0] || p.out_traj[1];
                 if (!keep && prod != 1) {
                     GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, 2, false>", RF, ALGOS, tf(WD))
-                    static bool once2 = [] {
+                    static PerDeviceOnce once2;
+                    once2.run([] {
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 2, false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
-                        return true;
-                    }();
-                    (void)once2;
+                    });
                     hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD, 2, false>), sgrid, dim3(768), kSplitLds, stream, p);
                     return hipGetLastError();
                 }
             }
             const bool two = prod == PROD && PROD > 1;
             GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, %d, true>", RF, ALGOS, tf(WD), two ? PROD : 1)
-            static bool once = [] {
+            static PerDeviceOnce once;
+            once.run([] {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, PROD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds);
-                return true;
-            }();
-            (void)once;
+            });
             if (two)
                 hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD, PROD>), sgrid, dim3(256 * (1 + PROD)), kSplitLds, stream, p);
             else

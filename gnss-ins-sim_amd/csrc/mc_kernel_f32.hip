@@ -27,6 +27,7 @@
 #include "ginsim.h"
 #include "ins_math.hpp"
 #include "philox.hpp"
+#include "device_once.hpp"
 
 namespace ginsim {
 
@@ -732,12 +733,11 @@ static bool any_white_drift_f32(const ginsim_mc_params& p) {
 
 template <int RF, int ALGOS, bool WD, int PROD, bool KEEP>
 static hipError_t launch_split_f32(const ginsim_mc_params& p, const float* truth32, hipStream_t stream) {
-    static bool once = [] {
+    static PerDeviceOnce once;
+    once.run([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&f32::mc_kernel_f32_split<RF, ALGOS, WD, PROD, KEEP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)f32::kSplitLdsF);
-        return true;
-    }();
-    (void)once;
+    });
     hipLaunchKernelGGL((f32::mc_kernel_f32_split<RF, ALGOS, WD, PROD, KEEP>), dim3((unsigned)((p.runs + 255) / 256)), dim3(256 * (1 + PROD)),
                        f32::kSplitLdsF, stream, p, truth32);
     return hipGetLastError();

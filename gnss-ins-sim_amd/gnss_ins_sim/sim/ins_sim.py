@@ -24,6 +24,12 @@ Keyword-only extras (defaults keep the reference behaviour):
                        reference's default; -1 = end-point only).  The process-error statistics of that window are
                        accumulated inside the kernel; asking ``results()`` for another window integrates once more.
     device             GPU index (default LOCAL_RANK or 0).
+    devices            'all' | [ids]: spread the runs of THIS process over several GPUs -- one context and one Python thread per
+                       entry, contiguous run ranges, per-device records folded with the library's Chan merge (ginsim.multi;
+                       no torch, no launcher).  The reference's loop being sharded is ins_sim.py:490-506.  An id may repeat
+                       (``devices=[0, 0]``: two contexts on one GPU).  Not together with torch.distributed, where the
+                       split is one process per GPU.  $GINSIM_DEVICES (same values, comma separated) supplies the default,
+                       so that an UNCHANGED demo script uses every GPU of the node with GINSIM_DEVICES=all.
     geo_mag_n          geomagnetic field [uT] in the N frame at the initial position, needed for a 9-axis IMU.  The
                        reference evaluates the WMM model once per run for this vector (pathgen.py:164-168,
                        date = today); that model is outside the accelerated path: either the caller supplies the vector, or
@@ -56,8 +62,12 @@ class _McResults(object):
     """
 
     def __init__(self, jobs, kept, names, kinds, first_run, runs_local, total_runs, group, device, make_ps_job=None, ctx=None,
-                 make_kept_job=None, block_runs=0):
+                 make_kept_job=None, block_runs=0, ned_from_traj=False):
         self.jobs, self.kept, self.algo_names, self.kinds = jobs, kept, names, kinds
+        # does the NED end-point record have to be recomputed from trajectories?  Decided by Sim from the CONFIGURATION
+        # (identical on every rank), never from a rank's own jobs: a rank without runs has none, and the ranks must enter the
+        # same collective
+        self._ned_needs_traj = bool(ned_from_traj)
         self.first_run, self.runs_local, self.total_runs = first_run, runs_local, total_runs
         self._group, self._device, self._stats = group, device, {}
         self._make_ps_job, self._ctx = make_ps_job, ctx
@@ -73,10 +83,9 @@ class _McResults(object):
             import ginsim
             from ginsim import distributed
             job, kind = self.job_of(name), self.kinds[self.algo_names.index(name)]
-            # every rank takes the same branch (same Sim configuration); a rank without runs (world > sim_count) has job None
-            # and contributes the empty record
-            probe = next((j for j in self.jobs if j is not None), None)
-            from_traj = ned and probe is not None and not probe.end_ned
+            # every rank takes the same branch: the flag comes from the Sim configuration, which is the same on every rank; a
+            # rank without runs (world > sim_count) has job None and contributes the empty record to the SAME collective
+            from_traj = ned and self._ned_needs_traj
             if from_traj:                           # NED record recomputed from trajectories (kept, or re-integrated block by block)
                 part = ginsim.StatsResult.zero() if job is None else self._ned_from_traj(self.algo_names.index(name))
                 self._stats[key] = part if self._group is None else distributed.allreduce_stats(part, self._group, self._device)
@@ -149,7 +158,7 @@ class _McResults(object):
 class Sim(object):
     def __init__(self, fs, motion_def, ref_frame=0, imu=None, mode=None, env=None, algorithm=None, *,
                  seed=None, keep_trajectories='auto', max_device_bytes=64 * 2 ** 30, device=None, geo_mag_n=None, precision='f64',
-                 keep_runs=0, stats_start=0, geo_mag_date=None):
+                 keep_runs=0, stats_start=0, geo_mag_date=None, devices=None):
         self.name, self.version = NAME, VERSION
         self.fs, self.imu, self.mode, self.env = fs, imu, mode, env
         self.ref_frame = ref_frame if ref_frame in (0, 1) else 0
@@ -166,6 +175,11 @@ class Sim(object):
         self.geo_mag_n, self.geo_mag_date = geo_mag_n, geo_mag_date
         self.precision = precision      # 'f32': single-precision kernel (tolerances: tests/test_gpu_fp32.py)
         self.keep_runs, self.stats_start = max(int(keep_runs), 0), stats_start
+        if devices is None and device is None and os.environ.get('GINSIM_DEVICES'):
+            env = os.environ['GINSIM_DEVICES'].strip()
+            devices = env if env == 'all' else [int(x) for x in env.split(',') if x.strip()]
+        self.devices = devices
+        self._devset = None
         self.mc = None
 
     # ------------------------------------------------------------------------------------ run
@@ -178,7 +192,15 @@ class Sim(object):
         self.sim_complete = True
 
     def _context(self):
+        """Where this process integrates: a ginsim.Context (one GPU) or, with devices=..., a ginsim.multi.DeviceSet."""
         import ginsim
+        if self.devices is not None:
+            from ginsim import multi
+            if self.device is not None:
+                raise ValueError('Sim: give device (one GPU) or devices (several), not both')
+            if self._devset is None or self._devset.devices != multi.parse_devices(self.devices):
+                self._devset = multi.DeviceSet(self.devices)
+            return self._devset
         if self.device is None:
             return ginsim.default_context()
         return ginsim.Context(self.device)
@@ -276,12 +298,22 @@ class Sim(object):
         rank, world, group, xdev = self._dist()
         first, count = distributed.shard(self.sim_count, world, rank)
         seed = self._pick_seed(group, xdev)
-        ctx = self._context()
+        ctx = self._context()               # one GPU (Context) or, with devices=..., several (multi.DeviceSet)
+        from ginsim import multi
+        spread = isinstance(ctx, multi.DeviceSet)
+        ndev = len(ctx) if spread else 1
+        if spread and group is not None:
+            raise ValueError('Sim(devices=...) spreads the runs of ONE process over several GPUs; under torch.distributed the '
+                             'split is one process per GPU (drop devices=, or do not initialise a process group)')
+        new_job = (lambda *a, **kw: multi.JobSet(ctx, *a, **kw)) if spread else (lambda *a, **kw: ginsim.MonteCarloJob(ctx, *a, **kw))
         per_sample = 48 + (8 if self.imu.odo else 0) + 72 * len(fused) + (24 if self.imu.magnetometer else 0) + \
             (48.0 * raw['gps'].shape[0] / n if self.imu.gps else 0)
         keep = self.keep_trajectories
         if keep == 'auto':
-            keep = per_sample * n * max(count, 1) <= self.max_device_bytes
+            # decided on the LARGEST share of any rank / device (rank 0's), so that every rank takes the same decision -- the
+            # ranks enter collectives that depend on it
+            largest = -(-distributed.shard(self.sim_count, world, 0)[1] // ndev)
+            keep = per_sample * n * max(largest, 1) <= self.max_device_bytes
         if hosted and not keep:
             raise ValueError('plugins outside the fused kernel need the sensor series: use keep_trajectories=True')
         self.kept = bool(keep)
@@ -308,11 +340,11 @@ class Sim(object):
             return int(hit[0]) if hit.shape[0] else 0
 
         def make_job(g, kinds_, runs_, keep_sens, keep_traj, **kw):
-            return ginsim.MonteCarloJob(ctx, fs_imu, self.ref_frame, truth, self.imu.accel_err, self.imu.gyro_err,
-                                        g['ini'], runs=runs_, algos=tuple(kinds_), odo_err=self.imu.odo_err,
-                                        earth_rot=g['earth_rot'], seed=seed, run_offset=first,
-                                        ini_first=g['first'] + first, keep_sensors=keep_sens, keep_traj=keep_traj,
-                                        precision=self.precision, **vib, **kw)
+            return new_job(fs_imu, self.ref_frame, truth, self.imu.accel_err, self.imu.gyro_err,
+                           g['ini'], runs=runs_, algos=tuple(kinds_), odo_err=self.imu.odo_err,
+                           earth_rot=g['earth_rot'], seed=seed, run_offset=first,
+                           ini_first=g['first'] + first, keep_sensors=keep_sens, keep_traj=keep_traj,
+                           precision=self.precision, **vib, **kw)
 
         f64 = self.precision == 'f64'
         online = (not keep) and f64 and self.stats_start is not None and self.stats_start != -1
@@ -347,9 +379,9 @@ class Sim(object):
                     for i in g['idx']:
                         kept_jobs[i] = kj
             if not groups and kcount > 0:      # Sim without algorithm: sensor generation only (demo_no_algo.py)
-                sensor_job = ginsim.MonteCarloJob(ctx, fs_imu, self.ref_frame, truth, self.imu.accel_err,
-                                                  self.imu.gyro_err, None, runs=kcount, algos=(), odo_err=self.imu.odo_err,
-                                                  seed=seed, run_offset=first, keep_sensors=True, **vib)
+                sensor_job = new_job(fs_imu, self.ref_frame, truth, self.imu.accel_err,
+                                     self.imu.gyro_err, None, runs=kcount, algos=(), odo_err=self.imu.odo_err,
+                                     seed=seed, run_offset=first, keep_sensors=True, **vib)
                 sensor_job.launch()
             ctx.sync()
         for i in fused:                         # FreeIntegration.run_times accounting (free_integration.py:69)
@@ -367,10 +399,10 @@ class Sim(object):
             if self.imu.odo:
                 d.add_data(d.odo.name, sens('odo', squeeze=True))
         if kcount > 0 and (self.imu.gps or self.imu.magnetometer):      # ins_sim.py:497-503
-            aux = ginsim.AuxSensorJob(ctx, kcount, seed=seed, run_offset=first,
-                                      ref_gps=d.ref_gps.data if self.imu.gps else None, gps_err=self.imu.gps_err,
-                                      ref_frame=self.ref_frame,
-                                      ref_mag=d.ref_mag.data if self.imu.magnetometer else None, mag_err=self.imu.mag_err).run()
+            aux = (multi.AuxJobSet if spread else ginsim.AuxSensorJob)(
+                ctx, kcount, seed=seed, run_offset=first,
+                ref_gps=d.ref_gps.data if self.imu.gps else None, gps_err=self.imu.gps_err, ref_frame=self.ref_frame,
+                ref_mag=d.ref_mag.data if self.imu.magnetometer else None, mag_err=self.imu.mag_err).run()
             self._aux = aux
             view = lambda nm: McSeries(kcount, lambda pos, a=aux, nm=nm: a.series(nm, pos), key_of=lambda i: first + i,
                                        pos_of=in_kept)
@@ -396,15 +428,16 @@ class Sim(object):
             def make_kept_job(idx, off, runs_):      # a block of this rank's runs, trajectories kept (fp32 statistics)
                 i = fused[idx]
                 g = group_of[i]
-                return ginsim.MonteCarloJob(ctx, fs_imu, self.ref_frame, truth, self.imu.accel_err, self.imu.gyro_err, g['ini'],
-                                            runs=runs_, algos=(kinds[i],), odo_err=self.imu.odo_err, earth_rot=g['earth_rot'],
-                                            seed=seed, run_offset=first + off, ini_first=g['first'] + first + off,
-                                            keep_sensors=False, keep_traj=True, precision=self.precision, **vib)
+                return new_job(fs_imu, self.ref_frame, truth, self.imu.accel_err, self.imu.gyro_err, g['ini'],
+                               runs=runs_, algos=(kinds[i],), odo_err=self.imu.odo_err, earth_rot=g['earth_rot'],
+                               seed=seed, run_offset=first + off, ini_first=g['first'] + first + off,
+                               keep_sensors=False, keep_traj=True, precision=self.precision, **vib)
             esize = 4 if self.precision == 'f32' else 8
-            block_runs = max(256, int(self.max_device_bytes // (9 * esize * n)) // 256 * 256)
+            block_runs = ndev * max(256, int(self.max_device_bytes // (9 * esize * n)) // 256 * 256)
             self.mc = _McResults([stats_jobs.get(i) for i in fused], [kept_jobs.get(i) for i in fused], names,
                                  [kinds[i] for i in fused], first, count, self.sim_count, group, xdev, make_ps_job, ctx=ctx,
-                                 make_kept_job=make_kept_job, block_runs=block_runs)
+                                 make_kept_job=make_kept_job, block_runs=block_runs, ned_from_traj=not end_ned)
+            self.mc.devices = list(ctx.devices) if spread else None
             d.set_mc_results(self.mc)
         # plugins outside the fused kernel: the reference's per-run loop over host copies (user code)
         if hosted:
