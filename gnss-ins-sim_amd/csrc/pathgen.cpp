@@ -95,10 +95,103 @@ inline V3 euler_range(const V3& a) {
     return V3{{wrap_pi(a1), a2, wrap_pi(a3)}};
 }
 
+// pathgen.calc_true_sensor_output (pathgen.py:331-411): ideal accelerometer / gyroscope output and the position rate of one
+// kinematic state.  g is used in ref_frame 1 only (ref_frame 0 takes the WGS-84 value at pos).  vel_dot_n (pathgen.py:391) is
+// not used by path_gen itself; the C entry point below returns it as the reference function does.
+struct TrueSensor { V3 acc, gyro, vel_dot_n, pos_dot; };
+inline TrueSensor true_sensor_output(const V3& pos, const V3& vel_b, const V3& att, const M3& c_nb, const V3& vel_dot_b,
+                                     const V3& att_dot, int ref_frame, double g, bool want_vel_dot_n) {
+    TrueSensor o;
+    const V3 vn = mul(c_nb, vel_b);
+    V3 w_en{{0, 0, 0}}, w_ie{{0, 0, 0}};
+    if (ref_frame == 0) {
+        const Earth e = earth(pos[0], pos[2]);
+        const double rm_e = e.rm + pos[2], rn_e = e.rn + pos[2];
+        g = e.g;
+        w_en = V3{{vn[1] / rn_e, -vn[0] / rm_e, -vn[1] * e.sl / e.cl / rn_e}};
+        w_ie = V3{{kWie * e.cl, 0.0, -kWie * e.sl}};
+        o.pos_dot = V3{{vn[0] / rm_e, vn[1] / rn_e / e.cl, -vn[2]}};
+    } else {
+        o.pos_dot = vn;
+    }
+    const double sh = std::sin(att[0]), ch = std::cos(att[0]);
+    const V3 w_nb{{-sh * att_dot[1] + c_nb.m[0][0] * att_dot[2], ch * att_dot[1] + c_nb.m[1][0] * att_dot[2],
+                   att_dot[0] + c_nb.m[2][0] * att_dot[2]}};
+    o.vel_dot_n = V3{{0, 0, 0}};
+    if (want_vel_dot_n) {
+        const V3 a = mul(c_nb, vel_dot_b), c = cross(w_nb, vn);
+        o.vel_dot_n = V3{{a[0] + c[0], a[1] + c[1], a[2] + c[2]}};
+    }
+    o.gyro = mul_t(c_nb, V3{{w_nb[0] + w_en[0] + w_ie[0], w_nb[1] + w_en[1] + w_ie[1], w_nb[2] + w_en[2] + w_ie[2]}});
+    const V3 w_ie_b = mul_t(c_nb, w_ie);
+    const V3 cor = cross(V3{{w_ie_b[0] + o.gyro[0], w_ie_b[1] + o.gyro[1], w_ie_b[2] + o.gyro[2]}}, vel_b);
+    const V3 gb = mul_t(c_nb, V3{{0.0, 0.0, g}});
+    for (int i = 0; i < 3; ++i) o.acc[i] = vel_dot_b[i] + cor[i] - gb[i];
+    return o;
+}
+
+// pathgen.parse_motion_def (pathgen.py:413-439): the command of a segment -> target attitude and body velocity; types 3 / 5
+// take the attitude, 3 / 4 the velocity relative to the state at the segment's start.  false: no such command type.
+inline bool motion_target(const double* row, const V3& att, const V3& vel_b, V3& tgt_a, V3& tgt_v) {
+    if (!(row[0] == 1 || row[0] == 2 || row[0] == 3 || row[0] == 4 || row[0] == 5)) return false;
+    const bool rel_a = (row[0] == 3 || row[0] == 5), rel_v = (row[0] == 3 || row[0] == 4);
+    for (int i = 0; i < 3; ++i) {
+        tgt_a[i] = rel_a ? att[i] + row[1 + i] : row[1 + i];
+        tgt_v[i] = rel_v ? vel_b[i] + row[4 + i] : row[4 + i];
+    }
+    return true;
+}
+
 }  // namespace
 }  // namespace ginsim
 
 using namespace ginsim;
+
+// ---- the leaves of path_gen / FreeIntegration.run under their own entry points (host code; what a hosted plugin calls)
+extern "C" int ginsim_calc_true_sensor_output(const double* pos_n, const double* vel_b, const double* att, const double* c_nb,
+                                              const double* vel_dot_b, const double* att_dot, int32_t ref_frame, double g,
+                                              double* acc, double* gyro, double* vel_dot_n, double* pos_dot_n) {
+    if (!pos_n || !vel_b || !att || !c_nb || !vel_dot_b || !att_dot || !acc || !gyro || !vel_dot_n || !pos_dot_n) {
+        set_error("calc_true_sensor_output: NULL argument");
+        return GINSIM_ERR_ARG;
+    }
+    M3 c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.m[i][j] = c_nb[3 * i + j];
+    const TrueSensor o = true_sensor_output(V3{{pos_n[0], pos_n[1], pos_n[2]}}, V3{{vel_b[0], vel_b[1], vel_b[2]}},
+                                            V3{{att[0], att[1], att[2]}}, c, V3{{vel_dot_b[0], vel_dot_b[1], vel_dot_b[2]}},
+                                            V3{{att_dot[0], att_dot[1], att_dot[2]}}, ref_frame == 0 ? 0 : 1, g, true);
+    for (int i = 0; i < 3; ++i) { acc[i] = o.acc[i]; gyro[i] = o.gyro[i]; vel_dot_n[i] = o.vel_dot_n[i]; pos_dot_n[i] = o.pos_dot[i]; }
+    return GINSIM_OK;
+}
+
+extern "C" int ginsim_parse_motion_def(const double* seg, const double* att, const double* vel, double* att_com, double* vel_com) {
+    if (!seg || !att || !vel || !att_com || !vel_com) { set_error("parse_motion_def: NULL argument"); return GINSIM_ERR_ARG; }
+    V3 a, v;
+    if (!motion_target(seg, V3{{att[0], att[1], att[2]}}, V3{{vel[0], vel[1], vel[2]}}, a, v)) {
+        set_error("parse_motion_def: unsupported motion type %g", seg[0]);
+        return GINSIM_ERR_ARG;
+    }
+    for (int i = 0; i < 3; ++i) { att_com[i] = a[i]; vel_com[i] = v[i]; }
+    return GINSIM_OK;
+}
+
+// attitude.euler_update_zyx (attitude.py:679-721): Euler-rate integration over dt, pitch fold at +-pi/2, ONE +-2 pi wrap of yaw
+// and roll.  The per-step form of what Att::step (ins_math.hpp) does on the device with cached trigonometry.
+extern "C" int ginsim_euler_update_zyx(const double* x, const double* w, double dt, double* y) {
+    if (!x || !w || !y) { set_error("euler_update_zyx: NULL argument"); return GINSIM_ERR_ARG; }
+    const double cr = std::cos(x[2]), sr = std::sin(x[2]);
+    const double t = w[2] * cr + w[1] * sr;
+    double yaw = x[0] + (t / std::cos(x[1])) * dt;
+    double pit = x[1] + (w[1] * cr - w[2] * sr) * dt;
+    double rol = x[2] + (w[0] + t * std::tan(x[1])) * dt;
+    if (pit > 0.5 * kPi) { pit = kPi - pit; yaw = yaw + kPi; rol = rol + kPi; }
+    else if (pit < -0.5 * kPi) { pit = -kPi - pit; yaw = yaw + kPi; rol = rol + kPi; }
+    if (yaw > kPi) yaw = yaw - 2.0 * kPi; else if (yaw < -kPi) yaw = yaw + 2.0 * kPi;
+    if (rol > kPi) rol = rol - 2.0 * kPi; else if (rol < -kPi) rol = rol + 2.0 * kPi;
+    y[0] = yaw; y[1] = pit; y[2] = rol;
+    return GINSIM_OK;
+}
 
 extern "C" int ginsim_pathgen_capacity(const ginsim_pathgen_params* p, const double* md, int64_t* cap) {
     if (!p || !md || !cap || p->n_seg < 1 || !(p->fs > 0)) { set_error("pathgen: bad arguments"); return GINSIM_ERR_ARG; }
@@ -164,14 +257,9 @@ extern "C" int ginsim_pathgen(const ginsim_pathgen_params* p, const double* md, 
         const long typ = std::lround(row[0]);                    // pathgen.py:178 (Python round: half-to-even; types are integers)
         const double vis = row[8];
         V3 tgt_a, tgt_v;                                          // parse_motion_def, pathgen.py:413-439
-        const bool rel_a = (row[0] == 3 || row[0] == 5), rel_v = (row[0] == 3 || row[0] == 4);
-        if (!(row[0] == 1 || row[0] == 2 || row[0] == 3 || row[0] == 4 || row[0] == 5)) {
+        if (!motion_target(row, att, vel_b, tgt_a, tgt_v)) {
             set_error("pathgen: unsupported motion type %g in segment %d", row[0], seg);
             return GINSIM_ERR_ARG;
-        }
-        for (int i = 0; i < 3; ++i) {
-            tgt_a[i] = rel_a ? att[i] + row[1 + i] : row[1 + i];
-            tgt_v[i] = rel_v ? vel_b[i] + row[4 + i] : row[4 + i];
         }
         V3 filt_a = att, filt_v = vel_b;                          // pathgen.py:191-192
         const double stop = (double)k + std::nearbyint(row[7] * fs);     // pathgen.py:122, 194 (round half-to-even)
@@ -197,26 +285,9 @@ extern "C" int ginsim_pathgen(const ginsim_pathgen_params* p, const double* md, 
             }
             // calc_true_sensor_output, pathgen.py:331-411
             const V3 pos{{pos0[0] + dpos[0], pos0[1] + dpos[1], pos0[2] + dpos[2]}};
-            const V3 vn = mul(c_nb, vel_b);
-            V3 w_en{{0, 0, 0}}, w_ie{{0, 0, 0}}, pos_dot;
-            double g = g0;
-            if (p->ref_frame == 0) {
-                const Earth e = earth(pos[0], pos[2]);
-                const double rm_e = e.rm + pos[2], rn_e = e.rn + pos[2];
-                g = e.g;
-                w_en = V3{{vn[1] / rn_e, -vn[0] / rm_e, -vn[1] * e.sl / e.cl / rn_e}};
-                w_ie = V3{{kWie * e.cl, 0.0, -kWie * e.sl}};
-                pos_dot = V3{{vn[0] / rm_e, vn[1] / rn_e / e.cl, -vn[2]}};
-            } else {
-                pos_dot = vn;
-            }
-            const double sh = std::sin(att[0]), ch = std::cos(att[0]);
-            const V3 w_nb{{-sh * att_dot[1] + c_nb.m[0][0] * att_dot[2], ch * att_dot[1] + c_nb.m[1][0] * att_dot[2],
-                           att_dot[0] + c_nb.m[2][0] * att_dot[2]}};
-            const V3 gyro = mul_t(c_nb, V3{{w_nb[0] + w_en[0] + w_ie[0], w_nb[1] + w_en[1] + w_ie[1], w_nb[2] + w_en[2] + w_ie[2]}});
-            const V3 w_ie_b = mul_t(c_nb, w_ie);
-            const V3 cor = cross(V3{{w_ie_b[0] + gyro[0], w_ie_b[1] + gyro[1], w_ie_b[2] + gyro[2]}}, vel_b);
-            const V3 gb = mul_t(c_nb, V3{{0.0, 0.0, g}});
+            const TrueSensor ts = true_sensor_output(pos, vel_b, att, c_nb, vel_dot_b, att_dot, p->ref_frame, g0, false);
+            const V3& gyro = ts.gyro;
+            const V3& pos_dot = ts.pos_dot;
             // emit rows, pathgen.py:244-303
             double* qi = imu + 7 * k;
             double* qn = nav + 10 * k;
@@ -224,7 +295,7 @@ extern "C" int ginsim_pathgen(const ginsim_pathgen_params* p, const double* md, 
             qi[0] = (double)k;
             qn[0] = (double)k;
             for (int i = 0; i < 3; ++i) {
-                qi[1 + i] = vel_dot_b[i] + cor[i] - gb[i];
+                qi[1 + i] = ts.acc[i];
                 qi[4 + i] = gyro[i];
                 qn[1 + i] = pos[i];
                 qn[4 + i] = vel_n[i];

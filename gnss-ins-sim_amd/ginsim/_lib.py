@@ -92,6 +92,9 @@ _SIGS = {
     'ginsim_pathgen_capacity': (C.c_int, [C.POINTER(PathgenParams), _PD, C.POINTER(C.c_int64)]),
     'ginsim_pathgen': (C.c_int, [C.POINTER(PathgenParams), _PD, C.c_int64, _PD, _PD, _PD, _PD, _PD,
                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'ginsim_calc_true_sensor_output': (C.c_int, [_PD, _PD, _PD, _PD, _PD, _PD, C.c_int32, C.c_double, _PD, _PD, _PD, _PD]),
+    'ginsim_parse_motion_def': (C.c_int, [_PD, _PD, _PD, _PD, _PD]),
+    'ginsim_euler_update_zyx': (C.c_int, [_PD, _PD, C.c_double, _PD]),
     'ginsim_aux_sensors': (C.c_int, [C.c_void_p, C.POINTER(AuxParams)]),
     'ginsim_mc_run': (C.c_int, [C.c_void_p, C.POINTER(McParams)]),
     'ginsim_mc_variant': (C.c_int, [C.POINTER(McParams), C.POINTER(C.c_int32)]),

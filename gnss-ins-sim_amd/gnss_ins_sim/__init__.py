@@ -9,3 +9,6 @@ reference's ``demo_free_integration.py`` run unchanged:
 Only the path of SURVEY.md section 8 is provided (Sim / IMU / FreeIntegration plugins / error statistics);
 plotting, KML export, the GUI bridge and the other demo algorithms are out of scope.
 """
+from . import _reference as _reference          # noqa: E402
+
+_reference.install()        # modules this package lacks come from $GNSS_INS_SIM_REFERENCE when it names a checkout

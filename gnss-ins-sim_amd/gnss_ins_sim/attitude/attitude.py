@@ -1,7 +1,10 @@
 """ZYX subset of the reference's attitude module (gnss_ins_sim/attitude/attitude.py), vectorised NumPy.
 
 Host-side helpers for DERIVED data only (lazy att_quat, unit handling).  The per-timestep attitude
-propagation of the hot path lives in csrc/ins_math.hpp and runs on the GPU.
+propagation of the hot path lives in csrc/ins_math.hpp and runs on the GPU; its one-step form is offered here under its
+reference name (``euler_update_zyx``, native host code of libginsim) for hosted plugins that call it step by step.
+Every other name of the reference's module (quat_update, dcm2quat, rot_x ...) is looked up in the reference checkout named by
+$GNSS_INS_SIM_REFERENCE (module ``__getattr__`` -> gnss_ins_sim/_reference.py).
 """
 import math
 
@@ -44,3 +47,21 @@ def angle_range_pi(x):
     """attitude.angle_range_pi (attitude.py:799-812), scalar or array."""
     x = np.mod(x, TWO_PI)
     return np.where(x > math.pi, x - TWO_PI, x) if isinstance(x, np.ndarray) else (x - TWO_PI if x > math.pi else x)
+
+
+def euler_update_zyx(x, w, dt):
+    """attitude.euler_update_zyx (attitude.py:679-721): propagate the ZYX Euler angles x = [yaw, pitch, roll] by the body rate w
+    over dt -- Euler-rate integration, pitch fold at +-pi/2, ONE +-2 pi wrap of yaw and roll.  Through the C ABI
+    (ginsim_euler_update_zyx: native host code of libginsim; the kernels run the same update with cached trigonometry)."""
+    import ginsim
+    from ginsim._lib import lib, check, dptr
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(3))
+    w = np.ascontiguousarray(np.asarray(w, dtype=np.float64).reshape(3))
+    y = np.empty(3)
+    check(lib.ginsim_euler_update_zyx(dptr(x), dptr(w), float(dt), dptr(y)))
+    return y
+
+
+def __getattr__(name):
+    from .. import _reference
+    return _reference.delegate(__name__, name)

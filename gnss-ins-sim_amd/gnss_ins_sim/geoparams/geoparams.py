@@ -1,5 +1,6 @@
 """WGS-84 helpers with the reference's names (gnss_ins_sim/geoparams/geoparams.py), host side.
-The per-step Earth model of the hot path is csrc/ins_math.hpp::geo_param (device)."""
+The per-step Earth model of the hot path is csrc/ins_math.hpp::geo_param (device).  Names of the reference's module that are
+not here (earth_radius, ecef2lla ...) fall through to a reference checkout named by $GNSS_INS_SIM_REFERENCE."""
 import math
 
 import numpy as np
@@ -73,3 +74,8 @@ def reference_geomag_n(lat, lon, alt, when=None, root=None):
         print('geomagnetic field evaluated by %s for %s (pass geo_mag_date to repeat this run another day)' % (f, when.isoformat()))
     r = gm.GeoMag(lat / d2r, lon / d2r, alt, when)
     return np.array([r.bx, r.by, r.bz]) / 1000.0
+
+
+def __getattr__(name):
+    from .. import _reference
+    return _reference.delegate(__name__, name)

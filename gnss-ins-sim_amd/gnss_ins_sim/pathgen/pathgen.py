@@ -8,6 +8,9 @@ reference's signatures, argument meaning, return values and exceptions -- over t
     odo_gen    pathgen.py:627-641   /
     gps_gen    pathgen.py:596-625   \  ginsim_aux_sensors
     mag_gen    pathgen.py:643-661   /
+    bias_drift               pathgen.py:565-594  -> the drift term of the same sensor model (ginsim_mc_run, everything else zero)
+    calc_true_sensor_output  pathgen.py:331-411  -> ginsim_calc_true_sensor_output  (host C++, the function path_gen runs inline)
+    parse_motion_def         pathgen.py:413-439  -> ginsim_parse_motion_def         (the same)
 
 Differences from the reference, all stated: ``path_gen`` leaves ``motion_def`` and ``output_def`` unmodified (the reference
 overwrites ``motion_def[:, 7]`` and ``output_def[1:, 1]``, pathgen.py:122, 137, 143); only ``simulation_over_sample_rate``
@@ -138,3 +141,47 @@ def mag_gen(ref_mag, mag_err, *, seed=None):
     out = job.series('mag', [0])[0]
     job.release()
     return out
+
+
+def bias_drift(corr_time, drift, n, fs, *, seed=None):
+    """pathgen.bias_drift (pathgen.py:565-594): (n,3) bias-drift series -- first-order Gauss-Markov per axis with a finite
+    correlation time, white N(0, drift) otherwise -- as the fused kernels generate it (sense3 in csrc/mc_kernel.hip): one
+    sensors-only launch whose truth, constant bias and white noise are zero, so the measurement IS the drift."""
+    err = {'b': np.zeros(3), 'b_drift': np.asarray(drift, dtype=np.float64) * np.ones(3),
+           'b_corr': np.asarray(corr_time, dtype=np.float64) * np.ones(3), 'vrw': np.zeros(3)}
+    zeros = np.zeros((int(n), 3))
+    job = _one_run_sensors(fs, zeros, zeros, err, _QUIET, seed=seed)
+    out = job.sensors('accel', [0])[0]
+    job.release()
+    return out
+
+
+def calc_true_sensor_output(pos_n, vel_b, att, c_nb, vel_dot_b, att_dot, ref_frame, g):
+    """pathgen.calc_true_sensor_output (pathgen.py:331-411): (acc, gyro, vel_dot_n, pos_dot_n) of one kinematic state; c_nb is
+    the body -> nav matrix the caller holds for att (as in the reference), g is used in ref_frame 1 only."""
+    from ginsim._lib import lib, check, dptr
+    a = [np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1)) for v in (pos_n, vel_b, att, c_nb, vel_dot_b, att_dot)]
+    if a[3].size != 9 or any(v.size != 3 for v in a[:3] + a[4:]):
+        raise ValueError('calc_true_sensor_output: 3-vectors and a 3x3 matrix are expected')
+    out = [np.empty(3) for _ in range(4)]
+    check(lib.ginsim_calc_true_sensor_output(dptr(a[0]), dptr(a[1]), dptr(a[2]), dptr(a[3]), dptr(a[4]), dptr(a[5]),
+                                             int(ref_frame), float(g), *[dptr(o) for o in out]))
+    return tuple(out)
+
+
+def parse_motion_def(motion_def_seg, att, vel):
+    """pathgen.parse_motion_def (pathgen.py:413-439): (target attitude, target velocity) of a motion command of type 1..5."""
+    from ginsim._lib import lib, check, dptr
+    seg = np.ascontiguousarray(np.asarray(motion_def_seg, dtype=np.float64).reshape(-1))
+    if seg.size < 7:
+        raise ValueError('parse_motion_def: a segment has at least 7 elements')
+    a = np.ascontiguousarray(np.asarray(att, dtype=np.float64).reshape(3))
+    v = np.ascontiguousarray(np.asarray(vel, dtype=np.float64).reshape(3))
+    att_com, vel_com = np.empty(3), np.empty(3)
+    check(lib.ginsim_parse_motion_def(dptr(seg), dptr(a), dptr(v), dptr(att_com), dptr(vel_com)))
+    return att_com, vel_com
+
+
+def __getattr__(name):
+    from .. import _reference
+    return _reference.delegate(__name__, name)

@@ -230,6 +230,53 @@ class InsDataMgr(object):
                             -cl * co * err[:, 0] - cl * so * err[:, 1] - sl * err[:, 2]], axis=1)
         return err
 
+    def calc_data_err(self, data_name, ref_data_name, angle=False, err_opt=''):
+        """InsDataMgr.calc_data_err (ins_data_manager.py:454-517): the error SERIES of `data_name` against `ref_data_name` as a
+        Sim_data 'err_<name>' -- array_error per key (angles wrapped to [-pi, pi]; err_opt 'ned' / 'ecef' for LLA positions in
+        ref_frame 0), the reference interpolated onto algo_time where the lengths differ.  For Monte-Carlo series that live on
+        the GPU the result is a lazy mapping: the error of a run is formed when that run is read (the statistics do not come
+        this way: get_error_stats reduces on the device)."""
+        if data_name not in self.available or ref_data_name not in self.available:
+            print('%s or %s is not available.' % (data_name, ref_data_name))
+            return None
+        src = self._all[data_name]
+        err = sim_data.Sim_data(name='err_' + data_name, description='ERROR of ' + src.description, units=src.units,
+                                output_units=src.output_units, plottable=src.plottable, logx=src.logx, logy=src.logy,
+                                grid=src.grid, legend=src.legend)
+        lla = 0
+        if data_name == self.pos.name and self.ref_frame.data == 0 and err_opt in ('ned', 'ecef'):
+            lla = 1 if err_opt == 'ned' else 2
+            err.description = 'ERROR of NED position' if lla == 1 else 'ERROR of ECEF position'
+            err.units, err.output_units = list(_XYZ), list(_XYZ)
+            err.legend = ['pos_N', 'pos_E', 'pos_D'] if lla == 1 else ['pos_x', 'pos_y', 'pos_z']
+        ref_all = np.asarray(self._all[ref_data_name].data)
+        t = np.asarray(self.time.data) if 'time' in self.available else None
+
+        def one(key, x):
+            x = np.asarray(x, dtype=np.float64)
+            ref = ref_all
+            if ref.shape[0] != x.shape[0]:                      # :489-497, 835-849
+                at = self.algo_time.data if 'algo_time' in self.available else None
+                at = at.get(key) if hasattr(at, 'get') else at
+                if at is None or t is None:
+                    raise ValueError('%s or %s is not available.' % (self.algo_time.name, self.time.name))
+                tk = np.asarray(at, dtype=np.float64)
+                ref = np.interp(tk, t, ref) if ref.ndim == 1 else np.stack([np.interp(tk, t, ref[:, c]) for c in range(ref.shape[1])], 1)
+            return self.array_error(x, ref, angle, lla)
+
+        data = src.data
+        try:
+            if isinstance(data, (sim_data.McSeries, sim_data.ChainSeries)):
+                err.data = sim_data.DerivedSeries(data, one)
+            elif isinstance(data, dict):
+                err.data = {k: one(k, v) for k, v in data.items()}
+            elif isinstance(data, np.ndarray):
+                err.data = one(None, data)
+        except ValueError as e:
+            print(e)
+            return None
+        return err
+
     def _host_error_stats(self, data_name, data, err_stats_start, angle, ned):
         """Reference statistics of host arrays: data = {key: (n,k) array} or {None: array}."""
         ref_all = np.asarray(self._all['ref_' + data_name].data)

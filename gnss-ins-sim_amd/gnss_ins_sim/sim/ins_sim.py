@@ -28,8 +28,11 @@ Keyword-only extras (defaults keep the reference behaviour):
                        entry, contiguous run ranges, per-device records folded with the library's Chan merge (ginsim.multi;
                        no torch, no launcher).  The reference's loop being sharded is ins_sim.py:490-506.  An id may repeat
                        (``devices=[0, 0]``: two contexts on one GPU).  Not together with torch.distributed, where the
-                       split is one process per GPU.  $GINSIM_DEVICES (same values, comma separated) supplies the default,
-                       so that an UNCHANGED demo script uses every GPU of the node with GINSIM_DEVICES=all.
+                       split is one process per GPU.  Default (None): $GINSIM_DEVICES if set (same values, comma separated;
+                       'one' = never spread), else EVERY visible GPU when the batch is large enough to pay for it
+                       (sim_count x samples >= 2^30, e.g. BASELINE configs 3 and 4) and nothing says this process owns one
+                       GPU only (no device=, no $LOCAL_RANK, no initialised process group) -- so that an UNCHANGED
+                       demo_free_integration.py uses the whole node.
     geo_mag_n          geomagnetic field [uT] in the N frame at the initial position, needed for a 9-axis IMU.  The
                        reference evaluates the WMM model once per run for this vector (pathgen.py:164-168,
                        date = today); that model is outside the accelerated path: either the caller supplies the vector, or
@@ -175,9 +178,13 @@ class Sim(object):
         self.geo_mag_n, self.geo_mag_date = geo_mag_n, geo_mag_date
         self.precision = precision      # 'f32': single-precision kernel (tolerances: tests/test_gpu_fp32.py)
         self.keep_runs, self.stats_start = max(int(keep_runs), 0), stats_start
-        if devices is None and device is None and os.environ.get('GINSIM_DEVICES'):
-            env = os.environ['GINSIM_DEVICES'].strip()
-            devices = env if env == 'all' else [int(x) for x in env.split(',') if x.strip()]
+        self._auto_devices = False
+        if devices is None and device is None:
+            env = os.environ.get('GINSIM_DEVICES', '').strip()
+            if env and env != 'one':
+                devices = env if env == 'all' else [int(x) for x in env.split(',') if x.strip()]
+            elif not env:
+                self._auto_devices = True           # decided per run(), when the size of the batch is known
         self.devices = devices
         self._devset = None
         self.mc = None
@@ -191,9 +198,16 @@ class Sim(object):
             self._run_monte_carlo()
         self.sim_complete = True
 
-    def _context(self):
-        """Where this process integrates: a ginsim.Context (one GPU) or, with devices=..., a ginsim.multi.DeviceSet."""
+    AUTO_SPREAD_WORK = 2 ** 30      # sample x run products from which an un-configured Sim uses every visible GPU
+
+    def _context(self, work=0, distributed=False):
+        """Where this process integrates: a ginsim.Context (one GPU) or a ginsim.multi.DeviceSet (devices=..., or by default
+        every visible GPU for a batch of at least AUTO_SPREAD_WORK sample x run products when this process is not one rank
+        of a one-process-per-GPU job)."""
         import ginsim
+        if self.devices is None and self._auto_devices and not distributed and 'LOCAL_RANK' not in os.environ \
+                and work >= self.AUTO_SPREAD_WORK and ginsim.device_count() > 1:
+            self.devices = 'all'
         if self.devices is not None:
             from ginsim import multi
             if self.device is not None:
@@ -268,7 +282,7 @@ class Sim(object):
             d.add_data(d.ref_mag.name, np.ascontiguousarray(raw['mag'][:, 1:4]))
         if self.imu.odo:
             d.add_data(d.ref_odo.name, np.ascontiguousarray(raw['odo'][:, 2]))
-        d.add_data(d.ref_att_quat.name, sim_data.Lazy(lambda e=d.ref_att_euler.data: attitude.euler2quat(e)))    # ins_sim.py:729-748, on first read
+        d.add_data(d.ref_att_quat.name, sim_data.Lazy(lambda e=d.ref_att_euler.data.copy(): attitude.euler2quat(e)))    # ins_sim.py:729-748, on first read
         truth = {'ref_accel': d.ref_accel.data, 'ref_gyro': d.ref_gyro.data, 'ref_pos': d.ref_pos.data,
                  'ref_vel': d.ref_vel.data, 'ref_att': d.ref_att_euler.data}
         if self.imu.odo:
@@ -298,7 +312,7 @@ class Sim(object):
         rank, world, group, xdev = self._dist()
         first, count = distributed.shard(self.sim_count, world, rank)
         seed = self._pick_seed(group, xdev)
-        ctx = self._context()               # one GPU (Context) or, with devices=..., several (multi.DeviceSet)
+        ctx = self._context(self.sim_count * n, group is not None)     # one GPU (Context) or several (multi.DeviceSet)
         from ginsim import multi
         spread = isinstance(ctx, multi.DeviceSet)
         ndev = len(ctx) if spread else 1

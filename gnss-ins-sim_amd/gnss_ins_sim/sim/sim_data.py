@@ -220,6 +220,28 @@ class ChainSeries(Mapping):
         return self
 
 
+class DerivedSeries(Mapping):
+    """key -> fn(key, source[key]), formed when the key is read (e.g. the error series of a run that lives on the GPU)."""
+
+    def __init__(self, source, fn):
+        self.source, self.fn = source, fn
+
+    def __len__(self):
+        return len(self.source)
+
+    def __iter__(self):
+        return iter(self.source)
+
+    def __contains__(self, key):
+        return key in self.source
+
+    def __getitem__(self, key):
+        return self.fn(key, self.source[key])
+
+    def copy(self):
+        return self
+
+
 class Lazy(object):
     """A derived series that is computed when it is first read (``Sim_data.data``): e.g. the quaternion form of the true
     attitude (ins_sim.py:729-748), which the reference computes eagerly in every run() and no statistic uses."""

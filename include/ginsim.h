@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define GINSIM_ABI_VERSION 5
+#define GINSIM_ABI_VERSION 6
 
 /* status codes */
 #define GINSIM_OK          0
@@ -80,6 +80,18 @@ int ginsim_pathgen_capacity(const ginsim_pathgen_params* p, const double* motion
 int ginsim_pathgen(const ginsim_pathgen_params* p, const double* motion_def, int64_t cap,
                    double* imu, double* nav, double* gps, double* odo, double* mag /*[cap][4] = idx,mag3 or NULL*/,
                    int64_t* n_out, int64_t* m_out);
+
+/* ---- ABI 6: the leaves of the path under their own entry points (host code, for hosted plugins and tools that call the
+ * reference functions of the same names one state at a time; ginsim_pathgen and the kernels run the same code inline) ---- */
+/* pathgen.calc_true_sensor_output (pathgen.py:331-411): c_nb [3][3] row-major (body -> nav, as the reference passes it); g is
+ * used in ref_frame 1 only.  Outputs: acc, gyro (body frame), vel_dot_n, pos_dot_n (lat/lon/alt rates in ref_frame 0). */
+int ginsim_calc_true_sensor_output(const double* pos_n, const double* vel_b, const double* att, const double* c_nb,
+                                   const double* vel_dot_b, const double* att_dot, int32_t ref_frame, double g,
+                                   double* acc, double* gyro, double* vel_dot_n, double* pos_dot_n);
+/* pathgen.parse_motion_def (pathgen.py:413-439): seg[0] = command type 1..5, seg[1..3] attitude, seg[4..6] velocity command. */
+int ginsim_parse_motion_def(const double* seg, const double* att, const double* vel, double* att_com, double* vel_com);
+/* attitude.euler_update_zyx (attitude.py:679-721): x = [yaw, pitch, roll], w body rate, one step of dt. */
+int ginsim_euler_update_zyx(const double* x, const double* w, double dt, double* y);
 
 /* ---- Monte-Carlo fused kernel: noise injection + mechanisation + end-point error ------------- */
 #define GINSIM_ALGO_FREE 1   /* demo_algorithms/free_integration.py:63-174      */
@@ -170,7 +182,11 @@ typedef struct {
                                * odometer) -- every series contiguous, the input layout of ginsim_allan (series_stride = n) and of
                                * the reference's own per-run arrays dmgr.accel.data[i] (ins_sim.py:491-496).  Only sensors-only
                                * launches (algo_mask 0) take it; with <= 1024 runs and >= 2048 samples they run on the
-                               * time-parallel series kernels (ginsim_mc_variant reports 2), otherwise layout 1 is refused. */
+                               * time-parallel series kernels (ginsim_mc_variant reports 2), otherwise layout 1 is refused.
+                               * PERFORMANCE CLIFF: with layout 0 and 2..1024 runs a sensors-only launch takes the lane-per-run
+                               * kernel, whose time loop is ONE sequential chain over n per lane -- for long series (config 5:
+                               * 1 440 000 samples) seconds instead of a millisecond.  A caller that wants few long series
+                               * sets sensor_layout = 1 (or asks ginsim_mc_variant first: 2 = time-parallel). */
     int32_t   reserved4;
     /* ---- ABI 5: vibration, Sim(env={'acc': ..., 'gyro': ...}) -> the vib term of pathgen.acc_gen / gyro_gen ---- */
     ginsim_vibration vib_accel, vib_gyro;

@@ -524,6 +524,62 @@ def allan_case():
     save('allan_ref', seed=SEED, n=n, fs=fs, avar=avar, tau=tau)
 
 
+def leaves_case():
+    """The leaves of the hot path under their reference names, evaluated by the unmodified reference on seeded inputs:
+    attitude.euler_update_zyx (attitude.py:679-721; with pitch folds and yaw / roll wraps), pathgen.calc_true_sensor_output
+    (pathgen.py:331-411, both frames), pathgen.parse_motion_def (:413-439, the five command types), pathgen.bias_drift
+    (:565-594, under the randn shim: the accelerometer drift normals of run 0) and InsDataMgr.array_error (:519-553)."""
+    from gnss_ins_sim.attitude import attitude
+    from gnss_ins_sim.sim import ins_data_manager
+    rs = np.random.RandomState(SEED)
+    # --- euler_update_zyx
+    N = 240
+    x = rs.uniform(-1.0, 1.0, (N, 3)) * np.array([math.pi, 0.5 * math.pi, math.pi])
+    w = rs.uniform(-3.0, 3.0, (N, 3))
+    dt = rs.choice([0.0025, 0.005, 0.01, 0.02, 0.1], N)
+    x[:60, 1] = np.sign(x[:60, 1]) * (0.5 * math.pi - rs.uniform(0.0, 0.02, 60))        # next to the pitch fold
+    w[:60, 1:] *= 4.0
+    x[60:100, 0] = np.sign(x[60:100, 0]) * (math.pi - rs.uniform(0.0, 0.01, 40))        # next to the yaw / roll wrap
+    x[100:140, 2] = np.sign(x[100:140, 2]) * (math.pi - rs.uniform(0.0, 0.01, 40))
+    y = np.array([attitude.euler_update_zyx(x[i], w[i], dt[i]) for i in range(N)])
+    out = {'eu_x': x, 'eu_w': w, 'eu_dt': dt, 'eu_y': y}
+    # --- calc_true_sensor_output
+    M = 48
+    for rf in (0, 1):
+        pos = np.stack([rs.uniform(-1.3, 1.3, M), rs.uniform(-3.1, 3.1, M), rs.uniform(-100.0, 9000.0, M)], 1) if rf == 0 \
+            else rs.uniform(-5e3, 5e3, (M, 3))
+        vel_b, att = rs.uniform(-40.0, 40.0, (M, 3)), rs.uniform(-1.0, 1.0, (M, 3)) * np.array([math.pi, 1.4, math.pi])
+        vdot, adot, g = rs.uniform(-5.0, 5.0, (M, 3)), rs.uniform(-1.0, 1.0, (M, 3)), rs.uniform(9.7, 9.9, M)
+        c_nb = np.array([attitude.euler2dcm(att[i], 'zyx').T for i in range(M)])
+        res = [pathgen.calc_true_sensor_output(pos[i], vel_b[i], att[i], c_nb[i], vdot[i], adot[i], rf, g[i]) for i in range(M)]
+        out.update({'ts%d_pos' % rf: pos, 'ts%d_vel_b' % rf: vel_b, 'ts%d_att' % rf: att, 'ts%d_c_nb' % rf: c_nb, 'ts%d_vdot' % rf: vdot,
+                    'ts%d_adot' % rf: adot, 'ts%d_g' % rf: g})
+        for k, nm in enumerate(('acc', 'gyro', 'vel_dot_n', 'pos_dot_n')):
+            out['ts%d_%s' % (rf, nm)] = np.array([np.asarray(r[k], dtype=np.float64) for r in res])
+    # --- parse_motion_def
+    seg = rs.uniform(-2.0, 2.0, (25, 9))
+    seg[:, 0] = np.tile([1, 2, 3, 4, 5], 5)
+    att, vel = rs.uniform(-1.0, 1.0, (25, 3)), rs.uniform(-10.0, 10.0, (25, 3))
+    pm = [pathgen.parse_motion_def(seg[i], att[i], vel[i]) for i in range(25)]
+    out.update({'pm_seg': seg, 'pm_att': att, 'pm_vel': vel, 'pm_att_com': np.array([np.asarray(p[0], dtype=np.float64) for p in pm]),
+                'pm_vel_com': np.array([np.asarray(p[1], dtype=np.float64) for p in pm])})
+    # --- bias_drift: the drift normals of the accelerometer of run 0 in the reference's own call order
+    n, fs = 3000, 100.0
+    corr, drift = np.array([100.0, np.inf, 0.5]), np.array([3e-4, 2e-4, 5e-4])
+    with injected(RandnShim(SEED, n, corr, corr)):
+        bd = pathgen.bias_drift(corr, drift, n, fs)
+    out.update({'bd_seed': SEED, 'bd_n': n, 'bd_fs': fs, 'bd_corr': corr, 'bd_drift': drift, 'bd_out': bd})
+    # --- array_error
+    mgr = ins_data_manager.InsDataMgr([100.0, 0.0, 0.0], 0)
+    ang_x, ang_r = rs.uniform(-7.0, 7.0, (50, 3)), rs.uniform(-7.0, 7.0, (50, 3))
+    lla_r = np.stack([rs.uniform(-1.3, 1.3, 50), rs.uniform(-3.1, 3.1, 50), rs.uniform(0.0, 3000.0, 50)], 1)
+    lla_x = lla_r + rs.uniform(-1.0, 1.0, (50, 3)) * np.array([1e-5, 1e-5, 30.0])
+    out.update({'ae_ang_x': ang_x, 'ae_ang_r': ang_r, 'ae_ang': mgr.array_error(ang_x, ang_r, angle=True),
+                'ae_lla_x': lla_x, 'ae_lla_r': lla_r, 'ae_ned': mgr.array_error(lla_x, lla_r, lla=1),
+                'ae_ecef': mgr.array_error(lla_x, lla_r, lla=2)})
+    save('leaves', **out)
+
+
 def emit_profiles():
     prof = os.path.join(REPO, 'gnss-ins-sim_amd', 'motion_profiles')
     emit_profile(MOTION + 'motion_def-90deg_turn.csv', prof + '/turn_90deg.csv', '90-degree turn, 10 s')
@@ -575,6 +631,7 @@ CASES = [
     ('truth_mixed_types', 'truth_mixed_types()', ['truth_mixed_types_rf0.npz', 'truth_mixed_types_rf1.npz']),
     ('truth_random_profiles', 'truth_random_profiles()', ['truth_random_profiles.npz']),
     ('t4_reference_statistics', 't4_reference_statistics()', ['t4_c1_reference_stats.npz']),
+    ('leaves', 'leaves_case()', ['leaves.npz']),
 ]
 
 

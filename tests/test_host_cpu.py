@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(raw, s)]
     assert not missing, 'declared in include/ginsim.h but not exported: %s' % missing
     assert set(ginsim.EXPORTS) <= declared
-    assert ginsim.lib.ginsim_abi_version() == 5
+    assert ginsim.lib.ginsim_abi_version() == 6
 
 
 def test_no_gpu_fails_loudly():
@@ -500,3 +500,43 @@ def test_env_strings_parse_like_the_reference_and_bad_ones_raise():
     s2 = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, env={'acc': psd}, algorithm=None)
     with pytest.raises(NotImplementedError, match='PSD'):
         s2.run(1)
+
+
+def test_unconfigured_sim_spreads_large_batches_over_every_gpu(monkeypatch):
+    """The default of Sim(devices=None): every visible GPU for a batch of >= 2^30 sample x run products -- unless something says
+    this process owns ONE GPU (device=, $LOCAL_RANK, a process group) or $GINSIM_DEVICES decides.  The decision is host logic:
+    checked here with a pretended device count (the reference's loop being sharded: ins_sim.py:490-506)."""
+    import ginsim
+    from ginsim import multi
+    from gnss_ins_sim.sim import imu_model, ins_sim
+
+    class FakeSet(object):
+        def __init__(self, devices):
+            self.devices = multi.parse_devices(devices)
+
+    monkeypatch.setattr(ginsim, 'device_count', lambda: 8)
+    monkeypatch.setattr(ginsim.engine, 'device_count', lambda: 8)
+    monkeypatch.setattr(multi, 'device_count', lambda: 8)
+    monkeypatch.setattr(multi, 'DeviceSet', FakeSet)
+    monkeypatch.setattr(ginsim, 'default_context', lambda: 'ctx0')
+    monkeypatch.delenv('LOCAL_RANK', raising=False)
+    monkeypatch.delenv('GINSIM_DEVICES', raising=False)
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=False)
+    mk = lambda **kw: ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, **kw)
+    big, small = 2 ** 30, 65536 * 1000
+    assert mk()._context(small) == 'ctx0'                                   # C2: one GPU is faster than setting up eight
+    assert mk()._context(big).devices == list(range(8))                    # C3 / C4 sized: the whole node
+    assert mk()._context(big, distributed=True) == 'ctx0'                  # one process per GPU: the launcher's split
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    assert mk()._context(big) == 'ctx0'
+    monkeypatch.delenv('LOCAL_RANK')
+    monkeypatch.setenv('GINSIM_DEVICES', 'one')
+    assert mk()._context(big) == 'ctx0'
+    monkeypatch.setenv('GINSIM_DEVICES', '2,5')
+    assert mk()._context(small).devices == [2, 5]
+    monkeypatch.setenv('GINSIM_DEVICES', 'all')
+    assert mk()._context(small).devices == list(range(8))
+    assert mk(devices=[1, 1])._context(small).devices == [1, 1]            # the argument wins over the environment
+    with pytest.raises(ValueError, match='not both'):
+        mk(devices=[0], device=0)._context(small)
