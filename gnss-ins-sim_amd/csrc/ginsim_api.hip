@@ -200,6 +200,13 @@ int ginsim_malloc(ginsim_ctx* c, size_t bytes, void** dptr) {
     return GINSIM_OK;
 }
 
+int ginsim_mem_info(ginsim_ctx* c, size_t* free_bytes, size_t* total_bytes) {
+    REQUIRE(c && free_bytes && total_bytes, "mem_info: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+    return GINSIM_OK;
+}
+
 int ginsim_host_alloc(ginsim_ctx* c, size_t bytes, void** hptr) {
     REQUIRE(c && hptr, "host_alloc: bad arguments");
     HIP_TRY(hipSetDevice(c->device));

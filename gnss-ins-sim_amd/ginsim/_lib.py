@@ -77,6 +77,7 @@ _SIGS = {
     'ginsim_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     'ginsim_destroy': (C.c_int, [C.c_void_p]),
     'ginsim_device_name': (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    'ginsim_mem_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     'ginsim_malloc': (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     'ginsim_free': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ginsim_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

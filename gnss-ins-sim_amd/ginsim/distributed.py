@@ -82,10 +82,13 @@ def init_abi_comm(ctx, group=None, device=None):
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     problem = None
-    try:
-        ctx.comm_probe()
-    except Exception as e:                      # noqa: BLE001
-        problem = repr(e)
+    if getattr(ctx, '_comm_abandoned', None) is not None:      # reduced with the probe verdicts: all ranks go on or all raise
+        problem = 'an earlier communicator bootstrap on this context timed out and was abandoned'
+    else:
+        try:
+            ctx.comm_probe()
+        except Exception as e:                  # noqa: BLE001
+            problem = repr(e)
     if not _all_agree(problem is None, group, device):
         raise RuntimeError('librccl is not usable on every rank%s' % (': ' + problem if problem else ''))
     uid = None
@@ -103,18 +106,25 @@ def init_abi_comm(ctx, group=None, device=None):
     # failure like any other; its thread is abandoned (daemon), the context gets no communicator
     import threading
     limit = float(os.environ.get('GINSIM_COMM_INIT_TIMEOUT', '90'))
-    done = {}
+    done, gave_up = {}, threading.Event()
 
     def work():
         try:
             ctx.comm_init(world, rank, box[0])
             done['ok'] = True
+            if gave_up.is_set():            # the ranks agreed long ago that this communicator does not exist: drop it again
+                ctx.comm_destroy()
         except Exception as e:                  # noqa: BLE001
             done['err'] = repr(e)
     t = threading.Thread(target=work, name='ginsim-comm-init', daemon=True)
     t.start()
     t.join(limit)
     if t.is_alive():
+        # the thread is still inside ncclCommInitRank on this context's handle: the context is poisoned -- it must not be
+        # destroyed under the thread (Context.close() leaks it while the thread lives), and a communicator that appears later
+        # is dropped by the thread itself and never used
+        gave_up.set()
+        ctx._comm_abandoned = t
         problem = 'ncclCommInitRank did not return within %g s' % limit
     elif 'err' in done:
         problem = done['err']

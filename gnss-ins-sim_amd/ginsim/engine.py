@@ -82,9 +82,34 @@ class Context(object):
         self.handle = h.value
         self.device = int(device)
         self.comm_ranks = 0
-        # freed device regions by size (DeviceBuffer): regions of at least POOL_MIN bytes, POOL_LIMIT bytes in total
+        # freed device regions by size (DeviceBuffer): regions of at least POOL_MIN bytes, pool_limit bytes in total -- at most a
+        # third of the device's memory (96 GiB of an MI355X's 288 GB), so that on a smaller GPU the pool cannot sit on most of
+        # the HBM; allocations the LIBRARY makes (scratch regions, gather buffers) and other users of the device are served by
+        # draining the pool when they run out of memory (retry_oom)
         self._pool, self._pool_bytes = {}, 0
-        self.pool_limit = int(os.environ.get('GINSIM_POOL_BYTES', 96 * 2 ** 30))
+        self._comm_abandoned = None         # set when a communicator bootstrap timed out on a helper thread (distributed.py)
+        limit = os.environ.get('GINSIM_POOL_BYTES')
+        if limit is None:
+            total = self.mem_info()[1]
+            limit = min(96 * 2 ** 30, total // 3) if total else 96 * 2 ** 30
+        self.pool_limit = int(limit)
+
+    def mem_info(self):
+        """(free, total) bytes of the device (hipMemGetInfo); (0, 0) if the query fails."""
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        if lib.ginsim_mem_info(self.handle, C.byref(f), C.byref(t)) != 0:
+            return 0, 0
+        return int(f.value), int(t.value)
+
+    def retry_oom(self, call):
+        """call() -> status of a library entry point.  When it fails for lack of device memory while regions are parked in the
+        pool, the pool is given back to the driver and the call is made once more (the library's own allocations -- scratch
+        regions, gather buffers -- do not know about the pool)."""
+        rc = call()
+        if rc != 0 and self._pool_bytes and b'memory' in lib.ginsim_last_error().lower():
+            self.release_pool()
+            rc = call()
+        return rc
 
     def name(self):
         buf = C.create_string_buffer(256)
@@ -172,6 +197,9 @@ class Context(object):
 
     def close(self):
         if self.handle:
+            t = self._comm_abandoned
+            if t is not None and t.is_alive():
+                return          # ncclCommInitRank is still running on this handle (distributed.init_abi_comm timed out): leak it
             self.release_pool()
             lib.ginsim_destroy(self.handle)
             self.handle = None
@@ -557,7 +585,7 @@ class MonteCarloJob(object):
 
     def launch(self):
         """Enqueue the fused kernel on the context's stream (asynchronous)."""
-        check(lib.ginsim_mc_run(self.ctx.handle, C.byref(self.params)))
+        check(self.ctx.retry_oom(lambda: lib.ginsim_mc_run(self.ctx.handle, C.byref(self.params))))
 
     def kernel_name(self):
         """Name of the kernel launch() dispatches for these parameters (as rocprofv3 reports it, without arguments),
@@ -657,8 +685,8 @@ class MonteCarloJob(object):
         ids = np.ascontiguousarray(np.asarray(run_ids, dtype=np.int64).reshape(-1))
         out = np.empty((ids.size, self.n, ncomp))
         fn = lib.ginsim_gather_runs_f32 if self.precision == 'f32' else (lib.ginsim_gather_series if series_major else lib.ginsim_gather_runs)
-        check(fn(self.ctx.handle, ptr, ncomp, self.n, self.runs, ids.ctypes.data_as(C.POINTER(C.c_int64)), ids.size,
-                 dptr(out)))
+        check(self.ctx.retry_oom(lambda: fn(self.ctx.handle, ptr, ncomp, self.n, self.runs, ids.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            ids.size, dptr(out))))
         return out
 
     def sensors(self, name, run_ids):
@@ -738,8 +766,8 @@ class AuxSensorJob(object):
         ids = np.ascontiguousarray(np.asarray(run_ids, dtype=np.int64).reshape(-1))
         ncomp, length = (6, self.m) if name == 'gps' else (3, self.n)
         out = np.empty((ids.size, length, ncomp))
-        check(lib.ginsim_gather_runs(self.ctx.handle, self._bufs[name].ptr, ncomp, length, self.runs,
-                                     ids.ctypes.data_as(C.POINTER(C.c_int64)), ids.size, dptr(out)))
+        check(self.ctx.retry_oom(lambda: lib.ginsim_gather_runs(self.ctx.handle, self._bufs[name].ptr, ncomp, length, self.runs,
+                                                                ids.ctypes.data_as(C.POINTER(C.c_int64)), ids.size, dptr(out))))
         return out
 
     def release(self):
@@ -788,9 +816,9 @@ def free_integration_host(ctx, algo, ref_frame, fs, gyro, accel=None, odo=None, 
     else:
         new = (lambda: pinned_empty(ctx, (R, n, 3))) if pinned_out else (lambda: np.empty((R, n, 3)))
         att, pos, vel = new(), new(), new()
-    check(lib.ginsim_free_integration(ctx.handle, ALGO_BITS[algo], int(ref_frame), float(fs), int(bool(earth_rot)),
-                                      dptr(g), dptr(a), dptr(o), R, n, dptr(table), table.shape[0], int(has_g),
-                                      int(ini_first), dptr(att), dptr(pos), dptr(vel)))
+    check(ctx.retry_oom(lambda: lib.ginsim_free_integration(ctx.handle, ALGO_BITS[algo], int(ref_frame), float(fs), int(bool(earth_rot)),
+                                                            dptr(g), dptr(a), dptr(o), R, n, dptr(table), table.shape[0], int(has_g),
+                                                            int(ini_first), dptr(att), dptr(pos), dptr(vel))))
     if single:
         return att[0], pos[0], vel[0]
     return att, pos, vel
@@ -820,8 +848,8 @@ def allan_var(ctx, x, n, nseries, series_stride, fs, cap=128):
     tau = np.empty(cap)                 # the library writes every entry it reports (ntau of them per series)
     avar = np.empty((nseries, cap))
     nt = C.c_int32(0)
-    check(lib.ginsim_allan(ctx.handle, ptr, int(n), int(nseries), int(series_stride), float(fs), dptr(tau), dptr(avar),
-                           C.byref(nt), cap))
+    check(ctx.retry_oom(lambda: lib.ginsim_allan(ctx.handle, ptr, int(n), int(nseries), int(series_stride), float(fs), dptr(tau),
+                                                 dptr(avar), C.byref(nt), cap)))
     return np.ascontiguousarray(avar[:, :nt.value]), tau[:nt.value].copy()
 
 

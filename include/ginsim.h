@@ -38,6 +38,7 @@ int  ginsim_device_count(int* count);
 int  ginsim_create(int device, ginsim_ctx** out);
 int  ginsim_destroy(ginsim_ctx* ctx);
 int  ginsim_device_name(ginsim_ctx* ctx, char* buf, size_t cap);
+int  ginsim_mem_info(ginsim_ctx* ctx, size_t* free_bytes, size_t* total_bytes);   /* ABI 6: hipMemGetInfo of the context's device */
 int  ginsim_malloc(ginsim_ctx* ctx, size_t bytes, void** dptr);
 int  ginsim_free(ginsim_ctx* ctx, void* dptr);
 int  ginsim_memcpy_h2d(ginsim_ctx* ctx, void* dst, const void* src, size_t bytes);

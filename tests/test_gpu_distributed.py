@@ -273,3 +273,26 @@ def test_more_ranks_than_runs(tmp_path):
     np.testing.assert_array_equal(a[:6], b[:6])
     assert np.all(a[:3] == 0.0) and np.all(a[3:6] > 0.0)       # one run: std 0, max |e| > 0
     assert (a[6], b[6]) == (1, 0)
+
+
+@pytest.mark.parametrize('keep', ['True', 'False'])
+def test_more_ranks_than_runs_with_the_ned_record(tmp_path, keep):
+    """Sim.run(1) under 2 ranks in ref_frame 0 with extra_opt='ned'.  Rank 1 holds no runs; which collective merges
+    the NED record (recomputed from kept trajectories, or the kernel's own NED end-point record of a statistics-only launch) is
+    decided from the Sim configuration -- the same on both ranks -- so neither rank is left alone in a collective."""
+    script = tmp_path / 'wn.py'
+    script.write_text((_SIM_WORKER % {'pkg': PKG, 'repo': REPO, 'port': _port()})
+                      .replace('ref_frame=1', 'ref_frame=0, keep_trajectories=%s' % keep)
+                      .replace('sim.run(1001)', 'sim.run(1)')
+                      .replace("sim.results(err_stats_start=-1)", "sim.results(err_stats_start=-1, extra_opt='ned')")
+                      .replace("sim.err_stats['vel']['std']", "sim.err_stats['pos']['max']")
+                      .replace("keys = list(sim.dmgr.accel.data.keys())", "keys = [0]")
+                      .replace("[keys[0], keys[-1], len(keys)]", "[len(keys)]"))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(tmp_path / ('n%d.npy' % r))], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    a, b = np.load(tmp_path / 'n0.npy'), np.load(tmp_path / 'n1.npy')
+    np.testing.assert_array_equal(a[:6], b[:6])
+    assert np.all(a[:3] > 0.0) and np.all(a[:3] < 10.0)        # NED metres after 10 s of a mid-accuracy IMU, not radians
