@@ -68,9 +68,12 @@ __device__ __forceinline__ void read_a(const double* __restrict__ w, int lane, d
 // at each: ten in a row queue up behind the other wavefronts' pieces at the CU's address unit and the wavefront stands still)
 struct NothingBetween { __device__ __forceinline__ void operator()(int) const {} };
 
+// o4 != nullptr: the lane's four sums of 10 (entries 4 lane .. 4 lane + 3 of the next level's share of this chunk) are ALSO
+// handed back in registers -- the fused kernel below keeps them on the chip instead of writing them out.
 template <bool CHECK, bool RAW, class Between = NothingBetween>
 __device__ __forceinline__ void compute_a(double (&e)[48], int lane, int64_t c, const AllanLevel& lv, double shift,
-                                          double* __restrict__ out_series, double (&acc)[9], const Between& between = Between()) {
+                                          double* __restrict__ out_series, double (&acc)[9], const Between& between = Between(),
+                                          double* __restrict__ o4 = nullptr) {
     {
         if (RAW) {
 #pragma unroll
@@ -116,6 +119,10 @@ __device__ __forceinline__ void compute_a(double (&e)[48], int lane, int64_t c, 
         const double r4 = pair_sq<8, CHECK>(s5, c * (kChunk / 5) + 8 * lane, lv.nb[4]);
         acc[4] += mine ? r4 : 0.0;
         between(9);
+        if (o4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o4[k] = __builtin_fma(10.0, shift, s5[2 * k] + s5[2 * k + 1]);
+        }
         if (lane < 63 && out_series) {                                       // level k+1: sums of 10, unshifted
             const int64_t g = c * (kChunk / 10) + 4 * lane;
 #pragma unroll
@@ -127,10 +134,10 @@ __device__ __forceinline__ void compute_a(double (&e)[48], int lane, int64_t c, 
 
 template <bool CHECK, bool RAW = false>
 __device__ __forceinline__ void pass_a(const double* __restrict__ w, int lane, int64_t c, const AllanLevel& lv, double shift,
-                                       double* __restrict__ out_series, double (&acc)[9]) {
+                                       double* __restrict__ out_series, double (&acc)[9], double* __restrict__ o4 = nullptr) {
     double e[48];
     read_a(w, lane, e);
-    compute_a<CHECK, RAW>(e, lane, c, lv, shift, out_series, acc);
+    compute_a<CHECK, RAW>(e, lane, c, lv, shift, out_series, acc, NothingBetween(), o4);
 }
 
 __device__ __forceinline__ void read_b(const double* __restrict__ w, int lane, double (&e)[72]) {
@@ -474,6 +481,279 @@ allan_pair_kernel(const double* __restrict__ in, double* __restrict__ out, doubl
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Levels k and k+1 in ONE launch (round 5).  What bounds the level kernel above at config 5's size is not its pipeline but the
+// HBM WRITES of the next level's entries -- 0.22 GB between 2.21 GB of reads cost 75 of level 0's 450 us (DESIGN_EXPERIMENTS
+// E4) -- and the next level then costs another launch that reads them back.  Here a workgroup takes exactly TEN chunks of level
+// k = 25 200 entries = ONE chunk of level k+1, bin boundaries of every factor included (2520 = lcm(1..9)), so level k+1 needs no
+// alignment-free formulation (E6.1's prefix-sum form put ~200 instructions and two LDS round trips per chunk on wavefront 0's
+// critical path and lost):
+//   * per chunk wavefront 0 does what it did, except that its four sums of 10 per lane stay in registers (40 doubles over the
+//     ten chunks, selected by a wave-uniform switch: nothing is indexed dynamically);
+//   * after the last chunk both LDS stages are idle: wavefront 0 drops the 2520 entries of the level-k+1 chunk into stage 0 and
+//     the wave pair runs the SAME two passes on it -- one chunk's worth of arithmetic more per ten, no request to wait for -- and
+//     writes the 252 entries of level k+2 (1 % of the input).
+// The pair (last bin of this level-k+1 chunk, first bin of the next) belongs to two workgroups.  Neither computes it: the
+// halo of the staged chunk is its own MIRROR image (entry 2520 + i = entry 2519 - i), so that the first bin of "the next
+// chunk" of every factor equals the last bin of this one and the pair contributes (rounding)^2; each workgroup records the
+// sums of its first and last j entries (relative to its origin) and the finishing launch adds the boundary pairs.
+// Wavefront 0's pass in TWO phases around the barrier that frees the stage, for the fused kernel: it carries 40 doubles of the
+// next level across the chunk loop, and the one-phase form (48 entries live across the barrier) would spill next to them --
+// and a scratch reload is a vector-memory operation: its s_waitcnt waits for every LDS-DMA piece issued before it.
+//   phase 1 (stage still needed): read the 48 entries, subtract the origin, factor 1, the bins of 2; what survives the barrier
+//            are 24 bins of 2 and the nine entries the bins of 5 need
+//   phase 2 (requests in between): bins of 5, 4, 8 and their pair sums, the sums of 10
+// Same operations in the same association as compute_a<false, true>: the level's sums do not change.
+struct PassA2 { double s2[24], eo[9]; };
+
+__device__ __forceinline__ void pass_a2_phase1(const double* __restrict__ w, int lane, double shift, PassA2& st, double& acc0) {
+    double e[48];
+    read_a(w, lane, e);
+#pragma unroll
+    for (int q = 0; q < 48; ++q) e[q] -= shift;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 40; ++q) {
+        const double d = e[q + 1] - e[q];
+        a[q & 3] = __builtin_fma(d, d, a[q & 3]);
+    }
+    acc0 += lane < 63 ? (a[0] + a[1]) + (a[2] + a[3]) : 0.0;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) st.s2[k] = e[2 * k] + e[2 * k + 1];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) st.eo[k] = e[(k & 1) ? 5 * k : 5 * k + 4];
+}
+
+template <class Between>
+__device__ __forceinline__ void pass_a2_phase2(const PassA2& st, int lane, double shift, double (&acc)[9], const Between& between,
+                                               double (&o4)[4]) {
+    const double (&s2)[24] = st.s2;
+    double s4[12], s8[6], s5[9];
+    const bool mine = lane < 63;
+    between(0);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s5[k] = (s2[(5 * k) / 2 + (k & 1)] + s2[(5 * k) / 2 + 1 + (k & 1)]) + st.eo[k];
+    between(1);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s4[k] = s2[2 * k] + s2[2 * k + 1];
+    between(2);
+    {
+        // pair_sq<20> with the requests in between
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 20; ++k) {
+            const double d = s2[k + 1] - s2[k];
+            a[k & 3] = __builtin_fma(d, d, a[k & 3]);
+            if (k == 6) between(3);
+            if (k == 13) between(4);
+        }
+        const double r1 = (a[0] + a[1]) + (a[2] + a[3]);
+        acc[1] += mine ? r1 : 0.0;
+    }
+    between(5);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s8[k] = s4[2 * k] + s4[2 * k + 1];
+    const double r3 = pair_sq<10, false>(s4, 0, 0);
+    acc[3] += mine ? r3 : 0.0;
+    between(6);
+    const double r7 = pair_sq<5, false>(s8, 0, 0);
+    acc[7] += mine ? r7 : 0.0;
+    between(7);
+    const double r4 = pair_sq<8, false>(s5, 0, 0);
+    acc[4] += mine ? r4 : 0.0;
+    between(8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o4[k] = __builtin_fma(10.0, shift, s5[2 * k] + s5[2 * k + 1]);
+    between(9);
+}
+
+constexpr int kFuseChunks = 10;
+constexpr int kFuseRecord = 36;                     // doubles per level-k+1 record: sums[9], first[9], last[9], origin, pad
+
+__global__ void __launch_bounds__(128, 2)
+allan_fused_kernel(const double* __restrict__ in, double* __restrict__ out1, double* __restrict__ out2, double* __restrict__ partial0,
+                   double* __restrict__ partial1, const AllanLevel lv, const AllanLevel lv1) {
+    __shared__ __attribute__((aligned(1024))) double stage[2][kDmaStage];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t s = blockIdx.y, part = blockIdx.x, nparts = gridDim.x;
+    const double* x = in + s * lv.in_stride;
+    const int64_t c_begin = part * kFuseChunks;
+    int64_t c_end = c_begin + kFuseChunks;
+    if (c_end > lv.nchunks) c_end = lv.nchunks;
+    const int64_t c_dma = (lv.n_in - kDmaStage) / kChunk;
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (c_begin < c_end && c_begin <= c_dma) dma_request_half(x + c_begin * kChunk, stage[0], wave, lane);
+    if (c_begin + 1 < c_end && c_begin + 1 <= c_dma) dma_request_half(x + (c_begin + 1) * kChunk, stage[1], wave, lane);
+    // ten whole chunks, every pair of bins in them exists (interior is monotone in c): all workgroups but the last of a series
+    const bool plain = c_end - c_begin == kFuseChunks && c_end - 1 <= c_dma && chunk_is_interior(c_end - 1, lv);
+    const int64_t e_first = part * kChunk;                      // first level-k+1 entry of this workgroup
+    if (plain && wave == 0) {
+        double l1[kFuseChunks][4];
+#pragma unroll
+        for (int q = 0; q < kFuseChunks; ++q) { l1[q][0] = 0.0; l1[q][1] = 0.0; l1[q][2] = 0.0; l1[q][3] = 0.0; }
+        // The chunk loop stays ROLLED and a wave-uniform switch names the registers that keep chunk q's sums.  (Unrolled, the
+        // scheduler stretches live ranges over the ten bodies and spills 3 KB per lane; with plain assignments in the arms the
+        // compiler turns the switch into 80 conditional moves per chunk -- the empty asm keeps every arm a real block of moves.)
+#pragma unroll 1
+        for (int q = 0; q < kFuseChunks; ++q) {
+            const int64_t c = c_begin + q;
+            double* w = stage[q & 1];
+            if (q + 1 < kFuseChunks) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // all but the next chunk's ten pieces
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            block_barrier();
+            const double shift = w[0];
+            PassA2 st;
+            pass_a2_phase1(w, lane, shift, st, acc[0]);
+            block_barrier();
+            const DmaPieceIssue piece{x + (c + 2) * kChunk, w, wave, lane, q + 2 < kFuseChunks};
+            double o4[4];
+            pass_a2_phase2(st, lane, shift, acc, piece, o4);
+            asm volatile("" ::: "memory");
+            switch (q) {
+                case 0: l1[0][0] = o4[0]; l1[0][1] = o4[1]; l1[0][2] = o4[2]; l1[0][3] = o4[3];
+                    asm volatile("" : "+v"(l1[0][0]), "+v"(l1[0][1]), "+v"(l1[0][2]), "+v"(l1[0][3])); break;
+                case 1: l1[1][0] = o4[0]; l1[1][1] = o4[1]; l1[1][2] = o4[2]; l1[1][3] = o4[3];
+                    asm volatile("" : "+v"(l1[1][0]), "+v"(l1[1][1]), "+v"(l1[1][2]), "+v"(l1[1][3])); break;
+                case 2: l1[2][0] = o4[0]; l1[2][1] = o4[1]; l1[2][2] = o4[2]; l1[2][3] = o4[3];
+                    asm volatile("" : "+v"(l1[2][0]), "+v"(l1[2][1]), "+v"(l1[2][2]), "+v"(l1[2][3])); break;
+                case 3: l1[3][0] = o4[0]; l1[3][1] = o4[1]; l1[3][2] = o4[2]; l1[3][3] = o4[3];
+                    asm volatile("" : "+v"(l1[3][0]), "+v"(l1[3][1]), "+v"(l1[3][2]), "+v"(l1[3][3])); break;
+                case 4: l1[4][0] = o4[0]; l1[4][1] = o4[1]; l1[4][2] = o4[2]; l1[4][3] = o4[3];
+                    asm volatile("" : "+v"(l1[4][0]), "+v"(l1[4][1]), "+v"(l1[4][2]), "+v"(l1[4][3])); break;
+                case 5: l1[5][0] = o4[0]; l1[5][1] = o4[1]; l1[5][2] = o4[2]; l1[5][3] = o4[3];
+                    asm volatile("" : "+v"(l1[5][0]), "+v"(l1[5][1]), "+v"(l1[5][2]), "+v"(l1[5][3])); break;
+                case 6: l1[6][0] = o4[0]; l1[6][1] = o4[1]; l1[6][2] = o4[2]; l1[6][3] = o4[3];
+                    asm volatile("" : "+v"(l1[6][0]), "+v"(l1[6][1]), "+v"(l1[6][2]), "+v"(l1[6][3])); break;
+                case 7: l1[7][0] = o4[0]; l1[7][1] = o4[1]; l1[7][2] = o4[2]; l1[7][3] = o4[3];
+                    asm volatile("" : "+v"(l1[7][0]), "+v"(l1[7][1]), "+v"(l1[7][2]), "+v"(l1[7][3])); break;
+                case 8: l1[8][0] = o4[0]; l1[8][1] = o4[1]; l1[8][2] = o4[2]; l1[8][3] = o4[3];
+                    asm volatile("" : "+v"(l1[8][0]), "+v"(l1[8][1]), "+v"(l1[8][2]), "+v"(l1[8][3])); break;
+                default: l1[9][0] = o4[0]; l1[9][1] = o4[1]; l1[9][2] = o4[2]; l1[9][3] = o4[3];
+                    asm volatile("" : "+v"(l1[9][0]), "+v"(l1[9][1]), "+v"(l1[9][2]), "+v"(l1[9][3])); break;
+            }
+        }
+        // both stages are idle now (the last two chunks requested nothing; everybody passed the last chunk's second barrier)
+        double2* w1 = reinterpret_cast<double2*>(stage[0]);
+        if (lane < 63) {
+#pragma unroll
+            for (int q = 0; q < kFuseChunks; ++q) {
+                w1[(252 * q + 4 * lane) / 2] = double2{l1[q][0], l1[q][1]};
+                w1[(252 * q + 4 * lane) / 2 + 1] = double2{l1[q][2], l1[q][3]};
+            }
+        }
+    } else if (plain) {
+#pragma unroll 1
+        for (int q = 0; q < kFuseChunks; ++q) {
+            const int64_t c = c_begin + q;
+            double* w = stage[q & 1];
+            if (q + 1 < kFuseChunks) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            block_barrier();
+            const double shift = w[0];
+            double e[72];
+            read_b_single(w, lane, e);
+            block_barrier();
+            const DmaPieceIssue piece{x + (c + 2) * kChunk, w, wave, lane, q + 2 < kFuseChunks};
+            compute_b<false, true, true>(e, lane, c, lv, shift, acc, piece);
+        }
+    } else {
+        // the last workgroup of a series (a ragged chunk, pairs of bins that do not exist, fewer than ten chunks): the level
+        // kernel's own loop, the sums of 10 through memory (out1) like there -- one workgroup in 58 at config 5's size
+        double* out_series = out1 + s * lv.out_stride;
+        int stores1 = 0, stores2 = 0;
+#pragma unroll 1
+        for (int64_t c = c_begin; c < c_end; ++c) {
+            double* w = stage[(c - c_begin) & 1];
+            if (c > c_dma) {
+                stage_ragged_half(x, w, wave, lane, c, lv.n_in, x[c * kChunk]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                wait_all_but(((c + 1 < c_end && c + 1 <= c_dma) ? kDmaPieces / 2 : 0) + stores1 + stores2);
+            }
+            block_barrier();
+            const bool interior = chunk_is_interior(c, lv);
+            const bool again = c + 2 < c_end && c + 2 <= c_dma;
+            const double shift = w[0];
+            if (wave == 0) pass_a<true, true>(w, lane, c, lv, shift, out_series, acc);
+            else pass_bc<true, true>(w, lane, c, lv, shift, acc);
+            (void)interior;
+            block_barrier();
+            if (again) dma_request_half(x + (c + 2) * kChunk, w, wave, lane);
+            stores2 = stores1;
+            stores1 = 0;
+        }
+        // make the stores visible to the whole workgroup, then stage them like the others
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        block_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int64_t have = lv1.n_in - e_first < kChunk ? lv1.n_in - e_first : kChunk;
+        const double* src = out_series + e_first;
+        for (int i = threadIdx.x; i < kChunk; i += 128)
+            if (i < have) stage[0][i] = src[i];
+    }
+    // ---- the level-k+1 chunk of this workgroup: entries [2520 part, 2520 part + 2520) of the series
+    block_barrier();                                            // the entries are in stage 0
+    double* w1 = stage[0];
+    const bool full1 = e_first + kChunk <= lv1.n_in;
+    if (wave == 0 && lane < 10) w1[kChunk + lane] = w1[kChunk - 1 - lane];      // the mirror halo (see above)
+    if (!full1 && wave == 1) {                                  // the series' last workgroup: nothing beyond its end
+        const double fill = w1[0];
+        for (int i = (int)(lv1.n_in - e_first) + lane; i < kStage; i += 64) w1[i] = fill;
+    }
+    block_barrier();
+    const double shift1 = w1[0];
+    double acc1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double* out2_series = lv1.n_out > 0 ? out2 + s * lv1.out_stride : nullptr;
+    if (full1 && chunk_is_interior(part, lv1)) {
+        // every pair INSIDE the chunk exists; the cross pair vanishes against the mirror halo
+        if (wave == 0) {
+            double e[48];
+            read_a(w1, lane, e);
+            compute_a<false, true>(e, lane, part, lv1, shift1, out2_series, acc1);
+        } else {
+            double e[72];
+            read_b_single(w1, lane, e);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            compute_b<false, true, true>(e, lane, part, lv1, shift1, acc1);
+        }
+    } else {
+        // the last chunk or two of the series: bounds-checked passes; a cross pair that exists is the finishing launch's, so
+        // the bins of "the next chunk" are cut off here
+        AllanLevel lvE = lv1;
+#pragma unroll
+        for (int j = 1; j <= 9; ++j) {
+            const int64_t lim = (part + 1) * (kChunk / j);
+            if (lvE.nb[j - 1] > lim) lvE.nb[j - 1] = lim;
+        }
+        if (wave == 0) pass_a<true, true>(w1, lane, part, lvE, shift1, out2_series, acc1);
+        else pass_bc<true, true>(w1, lane, part, lvE, shift1, acc1);
+    }
+    double* rec = partial1 + (s * nparts + part) * kFuseRecord;
+    if (wave == 0 && lane < 9) {                               // sums of the first / last j entries, j = lane + 1, about the origin
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i <= lane; ++i) {
+            a += w1[i] - shift1;
+            b += w1[kChunk - 1 - lane + i] - shift1;
+        }
+        rec[9 + lane] = a;
+        rec[18 + lane] = b;
+        if (lane == 0) rec[27] = shift1;
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const bool mine = (j == 0 || j == 1 || j == 3 || j == 4 || j == 7) == (wave == 0);
+        double a = acc[j], b = acc1[j];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+        if (lane == 0 && mine) {
+            partial0[(s * nparts + part) * 9 + j] = a;
+            rec[j] = b;
+        }
+    }
+}
+
 // Levels that fit one chunk (n_in <= 2520; for 3600 s @ 400 Hz the levels of 1440, 144 and 14 entries) are finished by
 // ONE wavefront per series in a single launch: the sums of 10 go to a second LDS stage instead of HBM and become
 // the next level in place.  Sums are final (one wavefront saw the whole level): written straight to sums[].
@@ -486,6 +766,29 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ partial
     for (int j = 0; j < 9; ++j) {
         double a = 0.0;
         for (int c = threadIdx.x; c < nparts; c += 64) a += p[c * 9 + j];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+        if (threadIdx.x == 0) sums[((int64_t)k * nseries + s) * 9 + j] = a;
+    }
+}
+
+// The fused kernel's level: sums inside the workgroups' chunks + the pairs (last bin of workgroup c, first bin of workgroup c+1)
+// from the recorded first / last sums, d = (first' - last) + j (origin' - origin).  A pair exists when its second bin does.
+__device__ __forceinline__ void fold_partials_fused(const double* __restrict__ partial, double* __restrict__ sums, const AllanFold& f,
+                                                    int64_t s, int k, int64_t nseries) {
+    const int nparts = f.nparts[k];
+    const double* p = partial + f.offset[k] * 9 + s * nparts * kFuseRecord;
+    for (int j = 0; j < 9; ++j) {
+        double a = 0.0;
+        for (int c = threadIdx.x; c < nparts; c += 64) {
+            a += p[(int64_t)c * kFuseRecord + j];
+            if (c + 1 < nparts && (int64_t)(c + 1) * (kChunk / (j + 1)) < f.fused_nb[j]) {
+                const double* q0 = p + (int64_t)c * kFuseRecord;
+                const double* q1 = q0 + kFuseRecord;
+                const double d = (q1[9 + j] - q0[18 + j]) + (double)(j + 1) * (q1[27] - q0[27]);
+                a = __builtin_fma(d, d, a);
+            }
+        }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
         if (threadIdx.x == 0) sums[((int64_t)k * nseries + s) * 9 + j] = a;
@@ -508,7 +811,9 @@ __global__ void __launch_bounds__(64 * kTailWaves) allan_tail_kernel(const doubl
     if ((int64_t)blockIdx.x >= ntail) {
         if (wave != 0) return;
         const int64_t b = (int64_t)blockIdx.x - ntail;
-        fold_partials(partial, sums, f, b % t.nseries, (int)(b / t.nseries), t.nseries);
+        const int k = (int)(b / t.nseries);
+        if (k == f.fused_level) fold_partials_fused(partial, sums, f, b % t.nseries, k, t.nseries);
+        else fold_partials(partial, sums, f, b % t.nseries, k, t.nseries);
         return;
     }
     const int64_t s = blockIdx.x;
@@ -575,6 +880,20 @@ int allan_pair_parts(const AllanLevel& lv) { return (lv.nchunks + lv.chunks_per_
 
 hipError_t launch_allan_pair(const double* in, double* out, double* partial, const AllanLevel& lv, int64_t nseries, hipStream_t st) {
     hipLaunchKernelGGL(allan_pair_kernel, dim3((unsigned)allan_pair_parts(lv), (unsigned)nseries), dim3(128), 0, st, in, out, partial, lv);
+    return hipGetLastError();
+}
+
+bool allan_fuse_applies(const double* in, const AllanLevel& lv, const AllanLevel& lv1) {
+    static const int on = [] { const char* e = getenv("GINSIM_ALLAN_FUSE"); return e ? atoi(e) : 1; }();
+    return on != 0 && allan_dma_applies(in, lv) && lv.n_out == lv1.n_in && lv1.n_in > kChunk;
+}
+int allan_fuse_parts(const AllanLevel& lv) { return (lv.nchunks + kFuseChunks - 1) / kFuseChunks; }
+int allan_fuse_record() { return kFuseRecord; }
+
+hipError_t launch_allan_fused(const double* in, double* out1, double* out2, double* partial0, double* partial1, const AllanLevel& lv,
+                              const AllanLevel& lv1, int64_t nseries, hipStream_t st) {
+    hipLaunchKernelGGL(allan_fused_kernel, dim3((unsigned)allan_fuse_parts(lv), (unsigned)nseries), dim3(128), 0, st, in, out1, out2,
+                       partial0, partial1, lv, lv1);
     return hipGetLastError();
 }
 

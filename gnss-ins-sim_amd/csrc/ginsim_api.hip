@@ -743,8 +743,11 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
     std::vector<AllanLevel> lvs(levels);
     AllanFold fold;
     fold.nlevels = 0;
+    fold.fused_level = -1;
+    fold.pad = 0;
+    for (int j = 0; j < 9; ++j) fold.fused_nb[j] = 0;
     int64_t records = 0;
-    struct Step { int k; int mode; };      // mode 0: allan_level_kernel, 1: wave-pair LDS-DMA kernel
+    struct Step { int k; int mode; };      // mode 0: allan_level_kernel, 1: wave-pair LDS-DMA kernel, 2: levels k and k+1 fused
     std::vector<Step> steps;
     {
         int64_t n_in = n, stride_in = series_stride, pow10 = 1;
@@ -762,6 +765,20 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
             pow10 *= 10;
         }
         int k = 0;
+        if (levels >= 2 && lvs[0].n_in > allan_chunk_entries() && allan_fuse_applies(x, lvs[0], lvs[1])) {
+            // levels 0 and 1 in one launch: the entries of level 1 never leave the chip (round 5; csrc/allan.hip)
+            const int parts = allan_fuse_parts(lvs[0]);
+            fold.nparts[0] = parts;
+            fold.offset[0] = records;
+            records += (int64_t)parts * nseries;
+            fold.nparts[1] = parts;
+            fold.offset[1] = records;
+            records += (int64_t)parts * nseries * (allan_fuse_record() / 9);
+            fold.fused_level = 1;
+            for (int j = 0; j < 9; ++j) fold.fused_nb[j] = lvs[1].nb[j];
+            steps.push_back(Step{0, 2});
+            k = 2;
+        }
         while (k < levels && lvs[k].n_in > allan_chunk_entries()) {
             REQUIRE(k < 8, "allan: series too long");
             AllanLevel& lv = lvs[k];
@@ -805,8 +822,15 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
     int flip = 0;
     for (const Step& st : steps) {
         // level k+1 (<= n/10 entries per series) goes to ping, k+2 to pong, ...
-        double* out = (flip++ % 2 == 0) ? ping.d() : pong.d();
         const int k = st.k;
+        if (st.mode == 2) {             // level k+1 -> ping (its last workgroup per series only), level k+2 -> pong
+            HIP_TRY(launch_allan_fused(in, ping.d(), pong.d(), partial.d() + 9 * fold.offset[k], partial.d() + 9 * fold.offset[k + 1],
+                                       lvs[k], lvs[k + 1], nseries, c->stream));
+            in = pong.d();
+            flip = 2;
+            continue;
+        }
+        double* out = (flip++ % 2 == 0) ? ping.d() : pong.d();
         if (st.mode == 1)
             HIP_TRY(launch_allan_pair(in, out, partial.d() + 9 * fold.offset[k], lvs[k], nseries, c->stream));
         else
