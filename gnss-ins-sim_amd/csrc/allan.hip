@@ -380,6 +380,24 @@ struct DmaPieceIssue {
     }
 };
 
+// the same with the decision taken at compile time: with a run-time flag that is the same for all ten pieces the compiler merges
+// the ten conditional blocks and sinks the arithmetic behind them -- the pieces then go out in one burst after the barrier,
+// which is exactly what the placement is there to avoid
+template <bool ISSUE>
+struct DmaPieceIssueT {
+    const double* chunk;
+    double* dst;
+    int wave, lane;
+    __device__ __forceinline__ void operator()(int q) const {
+        __builtin_amdgcn_sched_barrier(0);
+        if (ISSUE) {
+            const int piece = wave * (kDmaPieces / 2) + q;
+            __builtin_amdgcn_global_load_lds((global_void_ptr)(chunk + piece * 128 + 2 * lane), (lds_void_ptr)(dst + piece * 128), 16, 0, 2 /* nt */);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
 // a chunk the DMA cannot take, half per wavefront: unshifted, `shift` beyond the end (RAW passes subtract it again)
 __device__ __forceinline__ void stage_ragged_half(const double* __restrict__ x, double* __restrict__ w, int wave, int lane, int64_t c,
                                                   int64_t n_in, double shift) {
@@ -524,18 +542,28 @@ __device__ __forceinline__ void pass_a2_phase1(const double* __restrict__ w, int
     for (int k = 0; k < 9; ++k) st.eo[k] = e[(k & 1) ? 5 * k : 5 * k + 4];
 }
 
+// The empty asm statements pin the arithmetic of a stretch BEFORE the request that follows it: the pieces are volatile, the
+// arithmetic is not, and without the pins the compiler sinks every stretch towards its use at the end -- all ten pieces then go
+// out in one burst right after the barrier (seen in the ISA: a piece every 4 instructions), which is what the placement avoids.
 template <class Between>
 __device__ __forceinline__ void pass_a2_phase2(const PassA2& st, int lane, double shift, double (&acc)[9], const Between& between,
                                                double (&o4)[4]) {
     const double (&s2)[24] = st.s2;
     double s4[12], s8[6], s5[9];
     const bool mine = lane < 63;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s5[k] = (s2[(5 * k) / 2 + (k & 1)] + s2[(5 * k) / 2 + 1 + (k & 1)]) + st.eo[k];
+    asm volatile("" : "+v"(s5[0]), "+v"(s5[1]), "+v"(s5[2]), "+v"(s5[3]), "+v"(s5[4]));
     between(0);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) s5[k] = (s2[(5 * k) / 2 + (k & 1)] + s2[(5 * k) / 2 + 1 + (k & 1)]) + st.eo[k];
+    for (int k = 5; k < 9; ++k) s5[k] = (s2[(5 * k) / 2 + (k & 1)] + s2[(5 * k) / 2 + 1 + (k & 1)]) + st.eo[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s4[k] = s2[2 * k] + s2[2 * k + 1];
+    asm volatile("" : "+v"(s5[5]), "+v"(s5[6]), "+v"(s5[7]), "+v"(s5[8]), "+v"(s4[0]), "+v"(s4[1]), "+v"(s4[2]), "+v"(s4[3]));
     between(1);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) s4[k] = s2[2 * k] + s2[2 * k + 1];
+    for (int k = 4; k < 12; ++k) s4[k] = s2[2 * k] + s2[2 * k + 1];
+    asm volatile("" : "+v"(s4[4]), "+v"(s4[5]), "+v"(s4[6]), "+v"(s4[7]), "+v"(s4[8]), "+v"(s4[9]), "+v"(s4[10]), "+v"(s4[11]));
     between(2);
     {
         // pair_sq<20> with the requests in between
@@ -544,31 +572,67 @@ __device__ __forceinline__ void pass_a2_phase2(const PassA2& st, int lane, doubl
         for (int k = 0; k < 20; ++k) {
             const double d = s2[k + 1] - s2[k];
             a[k & 3] = __builtin_fma(d, d, a[k & 3]);
-            if (k == 6) between(3);
-            if (k == 13) between(4);
+            if (k == 5 || k == 11 || k == 17) {
+                asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+                between(k == 5 ? 3 : (k == 11 ? 4 : 5));
+            }
         }
         const double r1 = (a[0] + a[1]) + (a[2] + a[3]);
         acc[1] += mine ? r1 : 0.0;
     }
-    between(5);
 #pragma unroll
     for (int k = 0; k < 6; ++k) s8[k] = s4[2 * k] + s4[2 * k + 1];
+    asm volatile("" : "+v"(acc[1]), "+v"(s8[0]), "+v"(s8[1]), "+v"(s8[2]), "+v"(s8[3]), "+v"(s8[4]), "+v"(s8[5]));
+    between(6);
     const double r3 = pair_sq<10, false>(s4, 0, 0);
     acc[3] += mine ? r3 : 0.0;
-    between(6);
+    asm volatile("" : "+v"(acc[3]));
+    between(7);
     const double r7 = pair_sq<5, false>(s8, 0, 0);
     acc[7] += mine ? r7 : 0.0;
-    between(7);
+    asm volatile("" : "+v"(acc[7]));
+    between(8);
     const double r4 = pair_sq<8, false>(s5, 0, 0);
     acc[4] += mine ? r4 : 0.0;
-    between(8);
+    asm volatile("" : "+v"(acc[4]));
+    between(9);
 #pragma unroll
     for (int k = 0; k < 4; ++k) o4[k] = __builtin_fma(10.0, shift, s5[2 * k] + s5[2 * k + 1]);
-    between(9);
 }
 
 constexpr int kFuseChunks = 10;
 constexpr int kFuseRecord = 36;                     // doubles per level-k+1 record: sums[9], first[9], last[9], origin, pad
+
+// One chunk of a workgroup whose ten chunks are whole and interior.  ISSUE: request chunk q + 2 (`next`) into the stage that is
+// being read, piece by piece inside the arithmetic; last: nothing younger than this chunk's pieces is in flight.
+template <bool ISSUE>
+__device__ __forceinline__ void fused_step_a(const double* __restrict__ next, double* __restrict__ w, int lane, double (&acc)[9],
+                                             double (&o4)[4], bool last = false) {
+    if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");         // all but the next chunk's ten pieces
+    block_barrier();
+    const double shift = w[0];
+    PassA2 st;
+    pass_a2_phase1(w, lane, shift, st, acc[0]);
+    block_barrier();
+    const DmaPieceIssueT<ISSUE> piece{next, w, 0, lane};
+    pass_a2_phase2(st, lane, shift, acc, piece, o4);
+    asm volatile("" ::: "memory");
+}
+
+template <bool ISSUE>
+__device__ __forceinline__ void fused_step_b(const double* __restrict__ next, double* __restrict__ w, int lane, int64_t c,
+                                             const AllanLevel& lv, double (&acc)[9], bool last = false) {
+    if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    block_barrier();
+    const double shift = w[0];
+    double e[72];
+    read_b_single(w, lane, e);
+    block_barrier();
+    const DmaPieceIssueT<ISSUE> piece{next, w, 1, lane};
+    compute_b<false, true, true>(e, lane, c, lv, shift, acc, piece);
+}
 
 __global__ void __launch_bounds__(128, 2)
 allan_fused_kernel(const double* __restrict__ in, double* __restrict__ out1, double* __restrict__ out2, double* __restrict__ partial0,
@@ -595,21 +659,11 @@ allan_fused_kernel(const double* __restrict__ in, double* __restrict__ out1, dou
         // The chunk loop stays ROLLED and a wave-uniform switch names the registers that keep chunk q's sums.  (Unrolled, the
         // scheduler stretches live ranges over the ten bodies and spills 3 KB per lane; with plain assignments in the arms the
         // compiler turns the switch into 80 conditional moves per chunk -- the empty asm keeps every arm a real block of moves.)
+        // Two loops: chunks 0..7 request chunk q + 2 piece by piece inside their arithmetic, the last two request nothing.
 #pragma unroll 1
-        for (int q = 0; q < kFuseChunks; ++q) {
-            const int64_t c = c_begin + q;
-            double* w = stage[q & 1];
-            if (q + 1 < kFuseChunks) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // all but the next chunk's ten pieces
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            block_barrier();
-            const double shift = w[0];
-            PassA2 st;
-            pass_a2_phase1(w, lane, shift, st, acc[0]);
-            block_barrier();
-            const DmaPieceIssue piece{x + (c + 2) * kChunk, w, wave, lane, q + 2 < kFuseChunks};
+        for (int q = 0; q < kFuseChunks - 2; ++q) {
             double o4[4];
-            pass_a2_phase2(st, lane, shift, acc, piece, o4);
-            asm volatile("" ::: "memory");
+            fused_step_a<true>(x + (c_begin + q + 2) * kChunk, stage[q & 1], lane, acc, o4);
             switch (q) {
                 case 0: l1[0][0] = o4[0]; l1[0][1] = o4[1]; l1[0][2] = o4[2]; l1[0][3] = o4[3];
                     asm volatile("" : "+v"(l1[0][0]), "+v"(l1[0][1]), "+v"(l1[0][2]), "+v"(l1[0][3])); break;
@@ -625,8 +679,15 @@ allan_fused_kernel(const double* __restrict__ in, double* __restrict__ out1, dou
                     asm volatile("" : "+v"(l1[5][0]), "+v"(l1[5][1]), "+v"(l1[5][2]), "+v"(l1[5][3])); break;
                 case 6: l1[6][0] = o4[0]; l1[6][1] = o4[1]; l1[6][2] = o4[2]; l1[6][3] = o4[3];
                     asm volatile("" : "+v"(l1[6][0]), "+v"(l1[6][1]), "+v"(l1[6][2]), "+v"(l1[6][3])); break;
-                case 7: l1[7][0] = o4[0]; l1[7][1] = o4[1]; l1[7][2] = o4[2]; l1[7][3] = o4[3];
+                default: l1[7][0] = o4[0]; l1[7][1] = o4[1]; l1[7][2] = o4[2]; l1[7][3] = o4[3];
                     asm volatile("" : "+v"(l1[7][0]), "+v"(l1[7][1]), "+v"(l1[7][2]), "+v"(l1[7][3])); break;
+            }
+        }
+#pragma unroll 1
+        for (int q = kFuseChunks - 2; q < kFuseChunks; ++q) {       // rolled as well: side by side the two bodies spill
+            double o4[4];
+            fused_step_a<false>(x, stage[q & 1], lane, acc, o4, q == kFuseChunks - 1);
+            switch (q) {
                 case 8: l1[8][0] = o4[0]; l1[8][1] = o4[1]; l1[8][2] = o4[2]; l1[8][3] = o4[3];
                     asm volatile("" : "+v"(l1[8][0]), "+v"(l1[8][1]), "+v"(l1[8][2]), "+v"(l1[8][3])); break;
                 default: l1[9][0] = o4[0]; l1[9][1] = o4[1]; l1[9][2] = o4[2]; l1[9][3] = o4[3];
@@ -644,19 +705,11 @@ allan_fused_kernel(const double* __restrict__ in, double* __restrict__ out1, dou
         }
     } else if (plain) {
 #pragma unroll 1
-        for (int q = 0; q < kFuseChunks; ++q) {
-            const int64_t c = c_begin + q;
-            double* w = stage[q & 1];
-            if (q + 1 < kFuseChunks) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            block_barrier();
-            const double shift = w[0];
-            double e[72];
-            read_b_single(w, lane, e);
-            block_barrier();
-            const DmaPieceIssue piece{x + (c + 2) * kChunk, w, wave, lane, q + 2 < kFuseChunks};
-            compute_b<false, true, true>(e, lane, c, lv, shift, acc, piece);
-        }
+        for (int q = 0; q < kFuseChunks - 2; ++q)
+            fused_step_b<true>(x + (c_begin + q + 2) * kChunk, stage[q & 1], lane, c_begin + q, lv, acc);
+#pragma unroll 1
+        for (int q = kFuseChunks - 2; q < kFuseChunks; ++q)
+            fused_step_b<false>(x, stage[q & 1], lane, c_begin + q, lv, acc, q == kFuseChunks - 1);
     } else {
         // the last workgroup of a series (a ragged chunk, pairs of bins that do not exist, fewer than ten chunks): the level
         // kernel's own loop, the sums of 10 through memory (out1) like there -- one workgroup in 58 at config 5's size
@@ -714,8 +767,7 @@ allan_fused_kernel(const double* __restrict__ in, double* __restrict__ out1, dou
             compute_a<false, true>(e, lane, part, lv1, shift1, out2_series, acc1);
         } else {
             double e[72];
-            read_b_single(w1, lane, e);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            read_b(w1, lane, e);        // compiler-visible reads: nothing orders a use of read_b_single's results behind a wait
             compute_b<false, true, true>(e, lane, part, lv1, shift1, acc1);
         }
     } else {

@@ -168,8 +168,8 @@ def _compare_sims(a, b, runs, tmp_path, capsys):
                 x, y = a.err_stats[dn][stat], b.err_stats[dn][stat]
                 if hasattr(x, 'keys'):
                     assert sorted(x.keys()) == sorted(y.keys())
-                    for k in list(x.keys())[::37]:
-                        np.testing.assert_array_equal(x[k], y[k])
+                    for k in list(x.keys())[::37]:       # per-run process statistics: the reduction over time groups 64 runs
+                        np.testing.assert_allclose(x[k], y[k], rtol=1e-11, atol=1e-18)     # of a launch (Chan merges in LDS)
                 else:
                     np.testing.assert_allclose(x, y, rtol=1e-10, atol=1e-15)
     if 'accel' in a.dmgr.available and len(a.dmgr.accel.data):
