@@ -936,7 +936,8 @@ hipError_t launch_allan_pair(const double* in, double* out, double* partial, con
 }
 
 bool allan_fuse_applies(const double* in, const AllanLevel& lv, const AllanLevel& lv1) {
-    static const int on = [] { const char* e = getenv("GINSIM_ALLAN_FUSE"); return e ? atoi(e) : 1; }();
+    const char* e = getenv("GINSIM_ALLAN_FUSE");        // read per call: the tests run both forms in one process
+    const int on = e ? atoi(e) : 1;
     return on != 0 && allan_dma_applies(in, lv) && lv.n_out == lv1.n_in && lv1.n_in > kChunk;
 }
 int allan_fuse_parts(const AllanLevel& lv) { return (lv.nchunks + kFuseChunks - 1) / kFuseChunks; }

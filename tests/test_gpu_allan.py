@@ -66,6 +66,39 @@ def test_allan_chunk_boundaries_strided_series_and_drift(ctx, n):
         np.testing.assert_allclose(avar[s], ra, rtol=2e-7)
 
 
+@pytest.mark.parametrize('n', [25200 * 3, 25200 * 3 + 2, 25200 * 3 - 2, 25200 * 2 + 2520 * 7 + 8, 25220, 25200 * 6 + 90, 25200 * 4 + 25198,
+                               252000 * 2 + 2520 * 3 + 1234])
+def test_allan_fused_levels_at_their_chunk_boundaries(ctx, n, monkeypatch):
+    """Round 5: levels 0 and 1 in one launch -- a workgroup takes ten chunks of level 0 = one 2520-entry chunk of level 1 and
+    the pairs of level-1 bins across workgroups are added by the finishing launch.  Lengths around multiples of 25 200 (the
+    series' last workgroup ragged, with fewer than ten chunks, or with level-1 bins that do not exist), a level 1 of barely more
+    than one chunk, 16-byte aligned rows with a stride larger than n, bias + ramp a million times the noise; against the
+    oracle, and against the two-launch form of the same library (GINSIM_ALLAN_FUSE=0)."""
+    import ginsim
+    from oracle import ins_np
+    S, stride, fs = 3, n + 14, 100.0
+    t = np.arange(n) / fs
+    rows = [_series(20 + s, n) + 1.0e6 * (s + 1) + 3.0e3 * s * t for s in range(S)]
+    packed = np.full((S, stride), np.nan)
+    for s in range(S):
+        packed[s, :n] = rows[s]
+    buf = ctx.upload(packed)
+    monkeypatch.setenv('GINSIM_ALLAN_FUSE', '1')
+    avar, tau = ginsim.allan_var(ctx, buf, n, S, stride, fs)
+    monkeypatch.setenv('GINSIM_ALLAN_FUSE', '0')
+    avar2, tau2 = ginsim.allan_var(ctx, buf, n, S, stride, fs)
+    np.testing.assert_array_equal(tau, tau2)
+    # level 0 is the same arithmetic; level 1 differs in how the cross-workgroup pairs are formed, later levels in nothing
+    np.testing.assert_allclose(avar, avar2, rtol=1e-11)
+    assert not np.array_equal(avar, avar2) or n < 25200 * 2        # the fused form really ran (its sums associate differently)
+    for s in range(S):
+        ra, rt = ins_np.allan_var(rows[s], fs)
+        assert tau.shape == rt.shape and np.isfinite(avar[s]).all()
+        np.testing.assert_allclose(tau, rt, rtol=1e-15)
+        np.testing.assert_allclose(avar[s], ra, rtol=2e-7)
+    buf.free()
+
+
 def test_allan_plugin_and_module_surface(ctx):
     from gnss_ins_sim.allan import allan
     from demo_algorithms import allan_analysis

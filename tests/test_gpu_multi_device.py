@@ -200,8 +200,10 @@ def test_sim_devices_statistics_only(tmp_path, capsys):
     for s in (one, three):
         s.results(err_stats_start=-1, extra_opt='ned')
     capsys.readouterr()
-    np.testing.assert_allclose(three.err_stats['pos']['std'], one.err_stats['pos']['std'], rtol=1e-10)
-    np.testing.assert_array_equal(three.err_stats['pos']['max'], one.err_stats['pos']['max'])
+    for grp in ('algo0', 'algo1'):                       # two algorithms: one group of end-point statistics each
+        np.testing.assert_allclose(three.err_stats['pos']['std'][grp], one.err_stats['pos']['std'][grp], rtol=1e-10)
+        np.testing.assert_array_equal(three.err_stats['pos']['max'][grp], one.err_stats['pos']['max'][grp])
+        assert np.all(one.err_stats['pos']['max'][grp] < 50.0)       # metres, not radians
 
 
 def test_sim_devices_from_the_environment(capsys):
