@@ -39,6 +39,7 @@ Inputs (truth, parameters) are resident in HBM before every timed region.
 import argparse
 import hashlib
 import json
+import math
 import os
 import shutil
 import subprocess
@@ -229,6 +230,10 @@ def valu_roofline(pmc, kernel, kernel_ms, scale, note):
     c = (pmc or {}).get(kernel, {})
     if 'SQ_ACTIVE_INST_VALU' not in c or 'GRBM_GUI_ACTIVE' not in c:
         return None
+    if kernel_ms is None:                                          # a kernel of a multi-launch call: its own time in the counter pass
+        if not c.get('dur_ns'):
+            return None
+        kernel_ms = c['dur_ns'] * 1e-6
     busy = 4.0 * c['SQ_ACTIVE_INST_VALU']['avg']                   # SIMD cycles, cut launch
     cyc = c['GRBM_GUI_ACTIVE']['avg'] / XCDS                       # shader cycles the cut launch took
     ach = busy * scale / (kernel_ms * 1e-3)
@@ -272,6 +277,8 @@ def leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, reps=
 
 
 PMC_CUT_SAMPLES = 8192      # the C3-shaped launches of the --pmc-child workload are cut to this many samples
+VIB_LEG = dict(vib_accel={'type': 'random', 'x': 0.294, 'y': 0.294, 'z': 0.294},
+               vib_gyro={'type': 'random', 'x': 0.5 * math.pi / 180, 'y': 0.5 * math.pi / 180, 'z': 0.5 * math.pi / 180})
 
 
 def cut_truth(truth, n):
@@ -279,7 +286,7 @@ def cut_truth(truth, n):
 
 
 def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precision, reps, gps=False, pmc=None, traffic=None,
-           cut=None, **job_kw):
+           cut=None, valu_too=False, **job_kw):
     ini, truth, _ = workloads.truth_from_profile(profile, fs, rf, fs_gps=10.0 if gps else 0.0, gps=gps)
     if cut:
         truth = cut_truth(truth, cut)
@@ -295,6 +302,11 @@ def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precisi
     kname = job.kernel_name()
     if keep:
         roof = roofline(alg, avg, kname, (traffic or {}).get(kname, {}).get('hbm_bytes_per_launch'))
+        if valu_too:       # a materialising launch that is nevertheless bound by VALU issue: say so with its own object
+            v = valu_roofline(pmc, kname, avg, 1.0, 'VALU-busy SIMD cycles of this launch (rocprofv3 --pmc pass of `bench.py --pmc-child`, '
+                              'same kernel, same size) against 1024 SIMDs x 2.4 GHz')
+            if v is not None:
+                roof = dict(v, hbm=roof, note=v['note'] + '; the HBM figure of the same launch is under "hbm"')
     else:
         # nothing is written per sample (72 B per RUN): compute-bound by construction -> the VALU roofline
         roof = valu_roofline(pmc, kname, avg, (n - 1.0) / (PMC_CUT_SAMPLES - 1.0),
@@ -310,6 +322,28 @@ def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precisi
            'result': {'att_std_deg': (st.std[:3] * 57.29577951308232).tolist(), 'vel_std_mps': st.std[6:9].tolist(), 'runs': st.count}}
     job.release()
     return out
+
+
+def sensor_generation_roofline(pmc, runs, n, gen_ms):
+    """The three launches of the time-parallel sensor path write 48 B per sample of a run but are bound by VALU issue (VERDICT r04:
+    series_kernel<1> 0.95 of the chip's VALU issue cycles): bound = valu, from the counters of the two big kernels in the --pmc-child
+    pass (each against its own duration there); the HBM figure of the whole generation stays beside it."""
+    hbm = roofline(48.0 * runs * n, gen_ms, 'series_kernel<0> + series_scan_kernel + series_kernel<1>', None,
+                   note='48 B written per sample of a run (accel3 + gyro3 doubles); the three launches of the time-parallel path')
+    parts = {}
+    for k in ('ginsim::series_kernel<0>', 'ginsim::series_kernel<1>'):
+        v = valu_roofline(pmc, k, None, 1.0, 'its own duration in the counter pass')
+        if v is not None:
+            parts[k] = {'frac': v['frac'], 'valu_busy_at_the_clock_it_ran': v['valu_busy_at_the_clock_it_ran'], 'kernel_ms': v['kernel_ms_avg'],
+                        'SQ_ACTIVE_INST_VALU': v['counters_per_cut_launch'].get('SQ_ACTIVE_INST_VALU')}
+    if not parts:
+        return dict(hbm, note=hbm['note'] + '; VALU-bound (profiles/*_pmc_counters.csv), no counter pass in this run')
+    t = sum(p['kernel_ms'] for p in parts.values())
+    frac = sum(p['frac'] * p['kernel_ms'] for p in parts.values()) / t
+    return {'bound': 'valu', 'achieved': frac * SIMDS * SPEC_CLOCK_HZ, 'peak': SIMDS * SPEC_CLOCK_HZ, 'unit': 'VALU-busy SIMD-cycles/s',
+            'frac': frac, 'traffic': None, 'kernel': 'series_kernel<0> (pass A) + series_kernel<1> (pass B), weighted by their time',
+            'kernel_ms_avg': gen_ms, 'per_kernel': parts, 'hbm': hbm,
+            'note': 'the generation is bound by VALU issue, not by its stores; the HBM figure of the same launches is under "hbm"'}
 
 
 def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0, pmc=None, calls=30, warm=40):
@@ -360,8 +394,7 @@ def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0, pmc=Non
                        'of %d series, %d averaging factors' % (seconds, fs, n, runs, S, tau.size),
            'sensor_generation_ms': gen_ms, 'sensor_generation_ms_min': gen_min, 'sensor_kernel': job.kernel_name(),
            'sensor_layout': job.sensor_layout,
-           'sensor_generation_roofline': roofline(48.0 * runs * n, gen_ms, 'series_kernel<0> + series_scan_kernel + series_kernel<1>', None,
-                                                  note='48 B written per sample of a run (accel3 + gyro3 doubles); the three launches of the time-parallel path'),
+           'sensor_generation_roofline': sensor_generation_roofline(pmc, runs, n, gen_ms),
            'relayout_plus_allan_wall_ms': e2e_wall_ms, 'allan_call_ms_min': min(ms),
            'samples_per_s_allan_call': S * n / avg * 1e3,
            'roofline': roofline(8.0 * S * n, avg, 'ginsim_allan (every kernel of the call, up to the synchronisation that returns the sums)',
@@ -384,7 +417,7 @@ def leg_sim_e2e(workloads):
     from demo_algorithms import free_integration
     out = {'name': 'sim_e2e', 'dtype': 'f64', 'workload': 'Sim(...).run(R); Sim.results() through the drop-in package, wall clock'}
     for tag, profile, fs, fs_gps, rf, R, axis, gps in (('C2', 'turn_90deg', 100.0, 0.0, 1, 65536, 6, False),
-                                                      ('C3', 'long_drive', 200.0, 10.0, 0, 262144, 6, True)):
+                                                      ('C3', 'long_drive', 200.0, 10.0, 0, 262144, 9, True)):
         csv = workloads.profile_path(profile)
         ini = np.genfromtxt(csv, delimiter=',', skip_header=1, max_rows=1)
         ini[0:2] *= np.pi / 180
@@ -393,8 +426,12 @@ def leg_sim_e2e(workloads):
         for rep in range(4):                         # the first pass pays the device allocations; later ones find them in the context's pool
             imu = imu_model.IMU(accuracy='mid-accuracy', axis=axis, gps=gps)
             t0 = time.perf_counter()
-            sim = ins_sim.Sim([fs, fs_gps, 0.0], csv, ref_frame=rf, imu=imu, mode=None, env=None,
-                              algorithm=free_integration.FreeIntegration(ini), seed=SEED)
+            # C3 as BASELINE configs[2] names it: 9-axis IMU + GPS error model.  The geomagnetic field at the start is an INPUT
+            # (the WMM model is outside the path: a fixed vector here); keep_runs=2 materialises accel / gyro / mag / GPS series and
+            # trajectories of two runs next to the statistics over all of them (the full series would be 6 TB)
+            extra = dict(geo_mag_n=[33.0, -2.4, 36.5], keep_runs=2) if tag == 'C3' else {}
+            sim = ins_sim.Sim([fs, fs_gps, fs if axis == 9 else 0.0], csv, ref_frame=rf, imu=imu, mode=None, env=None,
+                              algorithm=free_integration.FreeIntegration(ini), seed=SEED, **extra)
             sim.run(R)
             t1 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
@@ -403,7 +440,10 @@ def leg_sim_e2e(workloads):
             n = int(sim.dmgr.time.data.shape[0])
             rec = {'runs': R, 'samples_per_run': n, 'run_wall_s': t1 - t0, 'results_wall_s': t2 - t1,
                    'sample_MC_per_s_end_to_end': R * n / (t2 - t0),
-                   'statistics': 'end point' if tag == 'C2' else 'process error of every run from t = 0 (the reference default), accumulated online'}
+                   'statistics': 'end point' if tag == 'C2' else 'process error of every run from t = 0 (the reference default), accumulated online',
+                   'imu': '%d-axis%s' % (axis, ' + GPS' if gps else ''),
+                   'kept_runs': sorted(int(k) for k in sim.dmgr.accel.data.keys()) if tag == 'C3' else 'all',
+                   'series_available': [k for k in ('accel', 'gyro', 'mag', 'gps', 'pos') if k in sim.dmgr.available]}
             best = rec if best is None or rec['sample_MC_per_s_end_to_end'] > best['sample_MC_per_s_end_to_end'] else best
             walls.append(t2 - t0)
             del sim
@@ -435,6 +475,7 @@ def main():
     ap.add_argument('--precision', choices=['f64', 'f32'], default='f64', help="f32 = BASELINE config 5's single-precision kernel")
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
     ap.add_argument('--no-legs', action='store_true', help='skip the configs[] legs (C3, C4 share, C5, Allan, mechanisation)')
+    ap.add_argument('--no-repeat', action='store_true', help='N = 1: do not time the K steps a second time (headline_again)')
     ap.add_argument('--pmc', choices=['live', 'file', 'off'], default='live',
                     help='roofline.traffic: rocprofv3 PMC passes of this build (live), the stamped profiles/pmc_traffic.json, or null')
     ap.add_argument('--pmc-child', action='store_true', help='internal: the short workload the live PMC passes profile')
@@ -449,7 +490,7 @@ def main():
                     help='TEST ONLY: every rank uses GPU 0 (exercises the N > 1 control flow on a one-GPU box)')
     args = ap.parse_args()
     if args.pmc_child:
-        args.steps, args.warmup, args.cpu_baseline_seconds, args.no_legs, args.pmc = 3, 1, 0.0, True, 'off'
+        args.steps, args.warmup, args.cpu_baseline_seconds, args.no_legs, args.pmc, args.no_repeat = 3, 1, 0.0, True, 'off', True
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -637,6 +678,30 @@ def main():
 
     kern_ms = [ctx.event_elapsed(2 * (s // stride), 2 * (s // stride) + 1) for s in range(args.warmup, nsteps) if s % stride == 0]
     kern_avg_ms = float(np.mean(kern_ms))
+
+    # The same timed region ONCE MORE in this process, a few seconds later (N = 1): how much of the run-to-run spread of this
+    # store-bound kernel is the box and how much is the moment.  `value` stays the first region (the K steps the contract names).
+    again = None
+    if world == 1 and not args.pmc_child and not args.no_repeat:
+        time.sleep(3.0)
+        spent, done = 0.0, 0
+        while spent < WARM_MS and done < 64:
+            ctx.timer_begin()
+            job.launch()
+            spent += ctx.timer_end()
+            done += 1
+        fence()
+        t1 = time.perf_counter()
+        for s in range(args.warmup, nsteps):
+            step(s)
+        merged2 = drain()
+        fence()
+        dt = time.perf_counter() - t1
+        k2 = [ctx.event_elapsed(2 * (s // stride), 2 * (s // stride) + 1) for s in range(args.warmup, nsteps) if s % stride == 0]
+        again = {'value': float(R) * n * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3, 'kernel_ms_avg': float(np.mean(k2)),
+                 'seconds_after_the_first': t1 - t0 - elapsed, 'same_statistics': bool(merged2.count == merged.count and
+                                                                                      np.array_equal(merged2.m2, merged.m2)),
+                 'note': 'the K timed steps repeated in the same process after a 3 s pause and the same time-based pre-warm'}
     per_rank = None
     if use_dist and world > 1:          # the slowest GPU sets the step time: make it visible in the line
         rows = [None] * world
@@ -663,6 +728,7 @@ def main():
                    proc_first=0, end_ned=True)
             leg_mc(ginsim, workloads, ctx, 'c3e', '', 'long_drive', 200.0, 0, 262144, False, 'f64', 2, gps=True, cut=PMC_CUT_SAMPLES)
             leg_allan(ginsim, workloads, ctx, calls=3, warm=1)       # config 5: sensor generation + three Allan calls
+            leg_mc(ginsim, workloads, ctx, 'vib', '', 'turn_90deg', 100.0, 1, 65536, True, 'f64', 2, **VIB_LEG)     # the vibration leg's kernel
         if job is not None:
             job.release()
         ctx.close()
@@ -713,6 +779,11 @@ def main():
             'result': {'att_std_deg': (merged.std[:3] * r2d).tolist(), 'vel_std_mps': merged.std[6:9].tolist(),
                        'runs': merged.count},
         }
+        if again is not None:
+            out['headline_again'] = again
+            out['roofline']['frac_again'] = alg_bytes / (again['kernel_ms_avg'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if world > 1:
+            out['cpu_baseline_note'] = 'omitted at N > 1: the CPU baseline is timed on rank 0 at N = 1 only (bench contract)'
         if single is not None:
             out['per_gpu_single'] = single
         if per_rank is not None:
@@ -742,8 +813,7 @@ def main():
             legs.append(leg_mc(ginsim, workloads, ctx, 'C2_vibration_random', 'the C2 launch with Sim(env={acc: [0.03 0.03 0.03]g-random, '
                                'gyro: [0.5 0.5 0.5]d-random}): the vibration variant of the plain general-model kernel', 'turn_90deg',
                                100.0, 1, 65536, True, 'f64', 10,
-                               vib_accel={'type': 'random', 'x': 0.294, 'y': 0.294, 'z': 0.294},
-                               vib_gyro={'type': 'random', 'x': 0.5 * np.pi / 180, 'y': 0.5 * np.pi / 180, 'z': 0.5 * np.pi / 180}))
+                               pmc=pmc, valu_too=True, **VIB_LEG))
             legs.append(leg_allan(ginsim, workloads, ctx, pmc=pmc))
             legs.append(leg_sim_e2e(workloads))
             out['configs'] = legs

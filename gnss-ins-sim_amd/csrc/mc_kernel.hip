@@ -201,7 +201,8 @@ __device__ __forceinline__ double angle_range_pi_mul(double x) {
 // sum e^2 / n - mean^2 with a relative rounding error of ~ 2^-53 (1 + mean^2 / var) sqrt(n) -- 1e-12 for mean^2 / var up
 // to 1e3 at n = 2e5.  process_stats_kernel (stats.hip), which reads kept trajectories, keeps the Welford / Chan-merge form
 // and is the checker: the two agree to 1e-9 relative (tests/test_process_stats.py), the online form to 1e-7 with the oracle.
-// The floor of the raw form: an error that is (nearly) CONSTANT over the window -- a noise-free or ideal IMU with an initial
+// The floor of the raw form (still what the ref_frame 0 free-integration and the vibration variants run; every other variant
+// shifts the sums, see Proc): an error that is (nearly) CONSTANT over the window -- a noise-free or ideal IMU with an initial
 // offset, a deterministic bias -- has var << mean^2, and what sum e^2 / n - mean^2 leaves of a std below ~1.5e-8 |mean| is
 // rounding (clamped at 0 here).  The kept-trajectory path has no such floor; a shift about the first sample's error would
 // remove it at the price of 18 more registers, which the ref_frame 0 variants (251 VGPRs) do not have
@@ -216,15 +217,24 @@ __device__ __forceinline__ void wrap_pi3(double (&e)[9]) {
     }
 }
 
+// SHIFT (round 5): the sums are kept about the FIRST in-window error of the run (sum (e - e0), sum (e - e0)^2): a (nearly)
+// constant error then leaves var = sum d^2 / n - (sum d / n)^2 with d of the size of the error's VARIATION, and the floor of the
+// raw form (~1.5e-8 |mean| on the std) is gone.  Nine more doubles per lane: every process-statistics variant takes them except
+// the ref_frame 0 free-integration ones (251 VGPRs without them: C3's kernel keeps the raw sums, documented and pinned by
+// tests/test_process_stats.py) and the vibration variants (already at the register limit).
+template <bool SHIFT>
 struct Proc {
-    double s1[9], s2[9], mx[9];
+    double s1[9], s2[9], mx[9], e0[SHIFT ? 9 : 1];
     __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int c = 0; c < 9; ++c) { s1[c] = 0.0; s2[c] = 0.0; mx[c] = 0.0; }
+#pragma unroll
+        for (int c = 0; c < (SHIFT ? 9 : 1); ++c) e0[c] = 0.0;
     }
-    // t = truth att3, pos3, vel3 of this sample (wave-uniform); NED: position error in local NED metres (:542-552)
+    // t = truth att3, pos3, vel3 of this sample (wave-uniform); NED: position error in local NED metres (:542-552);
+    // first (wave-uniform): this is the first sample of the window
     template <bool NED>
-    __device__ __forceinline__ void add(const Nav& s, const double (&t)[9]) {
+    __device__ __forceinline__ void add(const Nav& s, const double (&t)[9], bool first) {
         double e[9];
         e[0] = s.att.yaw - t[0]; e[1] = s.att.pit - t[1]; e[2] = s.att.rol - t[2];
         wrap_pi3(e);
@@ -235,20 +245,25 @@ struct Proc {
             e[3] = s.pos.x - t[3]; e[4] = s.pos.y - t[4]; e[5] = s.pos.z - t[5];
         }
         e[6] = s.vel.x - t[6]; e[7] = s.vel.y - t[7]; e[8] = s.vel.z - t[8];
+        if (SHIFT && first) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) e0[c] = e[c];
+        }
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
-            s1[c] += e[c];
-            s2[c] = __builtin_fma(e[c], e[c], s2[c]);
+            const double d = SHIFT ? e[c] - e0[c] : e[c];
+            s1[c] += d;
+            s2[c] = __builtin_fma(d, d, s2[c]);
             mx[c] = fmax(mx[c], fabs(e[c]));
         }
     }
     __device__ __forceinline__ void store(double* __restrict__ out, int64_t runs, int64_t r, double cnt) const {
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
-            const double mean = cnt > 0.0 ? s1[c] / cnt : 0.0;
-            const double var = cnt > 0.0 ? s2[c] / cnt - mean * mean : 0.0;
+            const double md = cnt > 0.0 ? s1[c] / cnt : 0.0;
+            const double var = cnt > 0.0 ? s2[c] / cnt - md * md : 0.0;
             out[(0 * 9 + c) * runs + r] = mx[c];
-            out[(1 * 9 + c) * runs + r] = mean;
+            out[(1 * 9 + c) * runs + r] = SHIFT ? e0[c] + md : md;
             out[(2 * 9 + c) * runs + r] = var > 0.0 ? sqrt(var) : 0.0;
         }
     }
@@ -386,14 +401,16 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
 
     if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
     if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
-    Proc ps;
+    // the shifted sums wherever the registers are there (see Proc)
+    constexpr bool PSHIFT = PS != 0 && !VIB && !(RF == 0 && ALGOS == GINSIM_ALGO_FREE);
+    Proc<PSHIFT> ps;
     const uniform_ptr nav_truth = as_uniform(a.ref_nav);
     if (PS) {
         ps.clear();
         if (a.proc_first <= 0) {                    // sample 0 is the initial state (free_integration.py:96-102)
             const double t[9] = {nav_truth[0], nav_truth[1], nav_truth[2], nav_truth[3], nav_truth[4], nav_truth[5],
                                  nav_truth[6], nav_truth[7], nav_truth[8]};
-            ps.template add<PS == 2>(FREE ? fi : od, t);
+            ps.template add<PS == 2>(FREE ? fi : od, t, true);
         }
     }
 
@@ -459,7 +476,7 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
             if (j + 1 >= a.proc_first) {            // wave-uniform
                 const uniform_ptr q = nav_truth + 9 * (j + 1);
                 const double t[9] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
-                ps.template add<PS == 2>(FREE ? fi : od, t);
+                ps.template add<PS == 2>(FREE ? fi : od, t, a.proc_first > 0 && j + 1 == a.proc_first);
             }
         }
     }

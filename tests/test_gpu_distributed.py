@@ -47,7 +47,7 @@ def test_bench_two_ranks_share_the_work():
     assert two['result']['runs'] == 16384 and one['result']['runs'] == 8192
     # merged statistics of 16 384 runs vs 8 192 runs of the same distribution
     np.testing.assert_allclose(two['result']['att_std_deg'], one['result']['att_std_deg'], rtol=0.05)
-    assert two['value'] > 0 and 'roofline' in two and 'cpu_baseline' not in two
+    assert two['value'] > 0 and 'roofline' in two and 'cpu_baseline' not in two and 'N = 1 only' in two['cpu_baseline_note']
 
 
 def test_bench_starts_itself_for_n_gt_1():
@@ -99,6 +99,10 @@ def test_bench_line_contract():
     np.testing.assert_allclose(r['achieved'], r['algorithmic_bytes_per_launch'] / (r['kernel_ms_avg'] * 1e-3) / 1e9, rtol=1e-9)
     np.testing.assert_allclose(r['frac'], r['achieved'] / r['peak'], rtol=1e-12)
     assert 0.3 < r['frac'] < 0.95 and r['kernel_ms_avg'] < d['ms_per_step'] and 'mc_kernel' in r['kernel']
+    # the same K steps once more, a few seconds later, in the same process: same statistics, its own clock
+    h = d['headline_again']
+    assert h['same_statistics'] is True and h['seconds_after_the_first'] >= 3.0 and 0.5 < h['value'] / d['value'] < 2.0
+    np.testing.assert_allclose(r['frac_again'], r['algorithmic_bytes_per_launch'] / (h['kernel_ms_avg'] * 1e-3) / 1e9 / r['peak'], rtol=1e-9)
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'sample*MC/s' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
     assert c['reference_python']['kind'] in ('quoted', 'reference') and c['reference_python']['cores'] == 1
