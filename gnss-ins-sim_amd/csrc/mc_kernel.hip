@@ -518,16 +518,8 @@ constexpr size_t kSplitLds = kSplitRing > 100 * 1024 ? kSplitRing : 100 * 1024;
 // steps of a tile alternate between the two producer groups.
 // KEEP = false: a statistics-only launch (no series pointer set): the store code and its address registers are compiled out,
 // which is what lets the ref_frame 0 consumer fit the 168 registers of three wavefronts per SIMD.
-// PS = 1 (round 5, C3): the online process-error statistics of mc_kernel<..., PS = 1> in the consumer.  The 27 accumulators of a
-// run (sum e, sum e^2, max |e| of nine components) do NOT fit the 168 registers of three wavefronts per SIMD next to the
-// ref_frame 0 mechanisation (149), so they live in LDS behind the ring, [27][256 runs] doubles = 54 KB, every lane reading and
-// writing only its own column (no synchronisation, 8-byte lane stride: conflict free); the ring shrinks to tiles of TILE = 4
-// steps to make room (2 x 4 x 12 KB + 54 KB + the tables = 154 KB).  Same operations on the same values in the same order as
-// Proc<false>::add -- the raw-sum form the ref_frame 0 free-integration kernel runs -- so the results are bit-identical.
-template <int RF, int ALGOS, bool WD, int PROD = 1, bool KEEP = true, int PS = 0, int TILE = kSplitTile>
+template <int RF, int ALGOS, bool WD, int PROD = 1, bool KEEP = true>
 __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim_mc_params a_in) {
-    static_assert(PS == 0 || (PS == 1 && ALGOS == GINSIM_ALGO_FREE && !KEEP), "split kernel statistics: free integration, nothing kept");
-    constexpr int kSplitTile = TILE;
     ginsim_mc_params a = a_in;
     if (!KEEP) {
         a.out_accel = a.out_gyro = a.out_odo = nullptr;
@@ -590,33 +582,6 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim
         if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
         if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
     }
-    // online statistics: this lane's column of the [27][256] accumulator block behind the ring
-    double* const pacc = reinterpret_cast<double*>(zring + 2 * kSplitTile * kStepFloats) + lane;
-    const uniform_ptr nav_truth = as_uniform(a.ref_nav);
-    auto ps_add = [&](const Nav& s, const double (&t)[9]) {
-        double e[9];
-        e[0] = s.att.yaw - t[0]; e[1] = s.att.pit - t[1]; e[2] = s.att.rol - t[2];
-        wrap_pi3(e);
-        e[3] = s.pos.x - t[3]; e[4] = s.pos.y - t[4]; e[5] = s.pos.z - t[5];
-        e[6] = s.vel.x - t[6]; e[7] = s.vel.y - t[7]; e[8] = s.vel.z - t[8];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            double s1 = pacc[c * kSplitRuns], s2 = pacc[(9 + c) * kSplitRuns], mx = pacc[(18 + c) * kSplitRuns];
-            s1 += e[c];
-            s2 = __builtin_fma(e[c], e[c], s2);
-            mx = fmax(mx, fabs(e[c]));
-            pacc[c * kSplitRuns] = s1; pacc[(9 + c) * kSplitRuns] = s2; pacc[(18 + c) * kSplitRuns] = mx;
-        }
-    };
-    if (PS) {
-#pragma unroll
-        for (int c = 0; c < 27; ++c) pacc[c * kSplitRuns] = 0.0;
-        if (a.proc_first <= 0) {                    // sample 0 is the initial state (free_integration.py:96-102)
-            const double t[9] = {nav_truth[0], nav_truth[1], nav_truth[2], nav_truth[3], nav_truth[4], nav_truth[5],
-                                 nav_truth[6], nav_truth[7], nav_truth[8]};
-            ps_add(fi, t);
-        }
-    }
     for (int64_t i = 0; i <= ntiles; ++i) {
         if (i >= 1 && active) {
             const float* stage = zring + ((i - 1) & 1) * (kSplitTile * kStepFloats);
@@ -657,29 +622,9 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim
                     nav_step<RF, true>(od, gyr, acc, odo, dt, a.earth_rot, resync, mk);
                     if (a.out_traj[1]) store9(a.out_traj[1], plane, off + runs, od);
                 }
-                if (PS) {
-                    if (j + 1 >= a.proc_first) {        // wave-uniform
-                        const uniform_ptr q = nav_truth + 9 * (j + 1);
-                        const double t[9] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
-                        ps_add(fi, t);
-                    }
-                }
             }
         }
         __syncthreads();
-    }
-    if (PS && active) {                             // Proc<false>::store
-        const double cnt = (double)(n - (a.proc_first > 0 ? a.proc_first : 0));
-        double* out = a.out_proc[0];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            const double s1 = pacc[c * kSplitRuns], s2 = pacc[(9 + c) * kSplitRuns], mx = pacc[(18 + c) * kSplitRuns];
-            const double mean = cnt > 0.0 ? s1 / cnt : 0.0;
-            const double var = cnt > 0.0 ? s2 / cnt - mean * mean : 0.0;
-            out[(0 * 9 + c) * runs + r] = mx;
-            out[(1 * 9 + c) * runs + r] = mean;
-            out[(2 * 9 + c) * runs + r] = var > 0.0 ? sqrt(var) : 0.0;
-        }
     }
     if (active) {
         if (FREE && a.out_end[0]) store_end(a.out_end[0], runs, r, fi);
@@ -712,15 +657,7 @@ static bool any_vibration(const ginsim_mc_params& p) { return p.vib_accel.type !
 int mc_variant(const ginsim_mc_params& p) {
     if (any_vibration(p)) return 0;                     // the vibration term lives in the plain kernel (general sensor model)
     if (!(p.algo_mask & GINSIM_ALGO_FREE) || p.given_sensors || p.block_threads != 0 || p.wave_trace || p.n < 2) return 0;
-    if (p.out_proc[0] || p.out_proc[1]) {
-        // online process statistics live in the plain kernel, except C3's launch: ref_frame 0 free integration, nothing kept,
-        // LLA position errors -- there the wave-specialised kernel carries them in LDS (mc_kernel_split<..., PS = 1>)
-        const char* env = getenv("GINSIM_SPLIT_PS");       // read per call: the tests run both kernels in one process
-        const int ps_split = env ? atoi(env) : 1;
-        const bool keep = p.out_accel || p.out_gyro || p.out_odo || p.out_traj[0] || p.out_traj[1];
-        return ps_split != 0 && split_policy() != 0 && p.algo_mask == GINSIM_ALGO_FREE && p.ref_frame == 0 && p.out_proc[0] && !p.proc_pos_ned &&
-               !keep && !p.given_sensors && p.block_threads == 0 && !p.wave_trace && p.n >= 2;
-    }
+    if (p.out_proc[0] || p.out_proc[1]) return 0;      // online process statistics live in the plain kernel
     const int pol = split_policy();
     if (pol >= 0) return pol != 0;
     // one algorithm: three wavefronts per SIMD (a consumer and two producers) beat the plain kernel's two at every size
@@ -758,24 +695,10 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
             constexpr int PROD = (ALGOS == GINSIM_ALGO_FREE && RF == 1) ? 2 : 1;
             static const int prod = [] { const char* e = getenv("GINSIM_SPLIT_PROD"); return e ? atoi(e) : PROD; }();
             const dim3 sgrid((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns));
-            if constexpr (ALGOS == GINSIM_ALGO_FREE && RF == 0 && WD) {
-                if (p.out_proc[0]) {            // C3: statistics in LDS behind a ring of 4-step tiles (mc_variant admitted the launch)
-                    constexpr int TILE = 4;
-                    constexpr size_t lds = (size_t)2 * TILE * kSplitStep * kSplitRuns + (size_t)27 * kSplitRuns * sizeof(double);
-                    GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, 2, false, 1, %d>", RF, ALGOS, tf(WD), TILE)
-                    static PerDeviceOnce once3;
-                    once3.run([] {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 2, false, 1, TILE>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    });
-                    hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD, 2, false, 1, TILE>), sgrid, dim3(768), lds, stream, p);
-                    return hipGetLastError();
-                }
-            }
             if constexpr (ALGOS == GINSIM_ALGO_FREE && RF == 0) {     // nothing kept: two producer groups fit here too
                 const bool keep = p.out_accel || p.out_gyro || p.out_odo || p.out_traj[0] || p.out_traj[1];
                 if (!keep && prod != 1) {
-                    GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, 2, false, 0, %d>", RF, ALGOS, tf(WD), kSplitTile)
+                    GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, 2, false>", RF, ALGOS, tf(WD))
                     static PerDeviceOnce once2;
                     once2.run([] {
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 2, false>),
@@ -786,7 +709,7 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
                 }
             }
             const bool two = prod == PROD && PROD > 1;
-            GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, %d, true, 0, %d>", RF, ALGOS, tf(WD), two ? PROD : 1, kSplitTile)
+            GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, %d, true>", RF, ALGOS, tf(WD), two ? PROD : 1)
             static PerDeviceOnce once;
             once.run([] {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 1>),

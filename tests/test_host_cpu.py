@@ -260,7 +260,7 @@ def test_hot_kernels_keep_two_wavefronts_per_simd():
         assert occ >= 2, '%s: %d wavefront(s) per SIMD' % (name, occ)
         if '15mc_kernel_splitI' in name or '19mc_kernel_f32_splitI' in name:
             # <RF, ALGOS, WD, PROD, KEEP>: 256 consumer + PROD x 256 producer threads, 1 + PROD wavefronts per SIMD
-            m = re.search(r'ELi(\d)ELb[01]E(?:Li\dELi\dE)?EEv', name)       # fp64: <..., PROD, KEEP, PS, TILE>
+            m = re.search(r'ELi(\d)ELb[01]EEEv', name)
             assert m, name
             prod = int(m.group(1))
             split_seen[prod] = split_seen.get(prod, 0) + 1
@@ -445,7 +445,7 @@ def test_dispatch_queries_and_sensor_layout_rules_without_a_gpu():
         _lib.check(_lib.lib.ginsim_mc_kernel_name(C.byref(p), buf, 256))
         return v.value, buf.value.decode()
 
-    assert query(params()) == (1, 'ginsim::mc_kernel_split<1, 1, false, 2, true, 0, 6>')                    # C2: the wave-specialised kernel
+    assert query(params()) == (1, 'ginsim::mc_kernel_split<1, 1, false, 2, true>')                    # C2: the wave-specialised kernel
     assert query(params(given_sensors=1, in_gyro=4096, in_accel=4096)) == (0, 'ginsim::mc_kernel<1, 1, true, false, 0, false>')
     assert query(params(precision=1))[1].startswith('ginsim::f32::mc_kernel_f32_split<1, 1, false, 3,')
     # sensors only, few runs, long series: the time-parallel kernels -- with the series-major layout, or with one run (same thing)

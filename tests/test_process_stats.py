@@ -288,36 +288,3 @@ def test_online_statistics_floor_for_a_constant_error(rf, algo):
             assert np.any(b[:, 2] < 1e-4 * np.abs(b[:, 1]))             # (the raw form is off by ~1.5e-8 |mean| here: >> 1e-7 std)
         online.release()
         kept.release()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('runs,first', [(700, 0), (256, 1234), (1, 0)])
-def test_c3_statistics_in_the_wave_specialised_kernel_are_bit_identical(runs, first, monkeypatch):
-    """Round 5: C3's launch -- ref_frame 0 free integration, nothing kept, online process statistics in LLA --
-    runs on the wave-specialised kernel with the 27 accumulators of a run in LDS (mc_kernel_split<0, 1, true, 2, false, 1, 4>).
-    Same operations in the same order as the plain kernel's Proc<false>: per-run statistics, end-point errors and the NED
-    end-point record equal to the bit (InsDataMgr.__process_error_stats, ins_data_manager.py:761-795)."""
-    import ginsim
-    from ginsim import workloads
-    fs, rf = 200.0, 0
-    ini, truth, _ = workloads.truth_from_profile('long_drive', fs, rf)
-    truth = {k: (v[:5000] if hasattr(v, 'shape') else v) for k, v in truth.items()}
-    acc, gyr = workloads.imu_grade('mid-accuracy')
-    ctx = ginsim.default_context()
-    got = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('GINSIM_SPLIT_PS', flag)
-        job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=runs, seed=77, run_offset=3, proc_first=first, end_ned=True)
-        name = job.kernel_name()
-        job.run()
-        got[flag] = (name, job.process_stats_online('free').copy(), job.end_errors('free'), job.end_errors('free', ned=True))
-        job.release()
-    assert got['1'][0] == 'ginsim::mc_kernel_split<0, 1, true, 2, false, 1, 4>' and got['0'][0] == 'ginsim::mc_kernel<0, 1, false, true, 1, false>'
-    for a, b in zip(got['1'][1:], got['0'][1:]):
-        np.testing.assert_array_equal(a, b)
-    assert np.all(got['1'][1][:, 0] > 0.0)          # max |e| of every component of every run
-    # the NED statistics (PS = 2) stay on the plain kernel
-    monkeypatch.setenv('GINSIM_SPLIT_PS', '1')
-    ned = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=runs, seed=77, proc_first=first, proc_ned=True)
-    assert ned.kernel_name() == 'ginsim::mc_kernel<0, 1, false, true, 2, false>'
-    ned.release()
