@@ -195,18 +195,7 @@ class Context(object):
             check(lib.ginsim_comm_destroy(self.handle))
         self.comm_ranks = 0
 
-    def sibling(self):
-        """A second context (its own stream) on the same device, created on first use and closed with this one: work enqueued
-        there runs CONCURRENTLY with this context's -- e.g. the one-workgroup launch that materialises a few kept runs of a
-        long profile (a sequential chain of n steps) next to the statistics-only launch over all runs."""
-        if getattr(self, '_sibling', None) is None or self._sibling.handle is None:
-            self._sibling = Context(self.device)
-        return self._sibling
-
     def close(self):
-        if getattr(self, '_sibling', None) is not None:
-            self._sibling.close()
-            self._sibling = None
         if self.handle:
             t = self._comm_abandoned
             if t is not None and t.is_alive():

@@ -320,10 +320,6 @@ class Sim(object):
             raise ValueError('Sim(devices=...) spreads the runs of ONE process over several GPUs; under torch.distributed the '
                              'split is one process per GPU (drop devices=, or do not initialise a process group)')
         new_job = (lambda *a, **kw: multi.JobSet(ctx, *a, **kw)) if spread else (lambda *a, **kw: ginsim.MonteCarloJob(ctx, *a, **kw))
-        # statistics-only run with a few kept runs: their launch is ONE workgroup walking the whole profile (a sequential chain:
-        # 0.2 s for long_drive @200 Hz) -- on a second stream of the same GPU it runs underneath the launch over all runs
-        side = None if spread else ctx.sibling()
-        new_kept_job = new_job if spread else (lambda *a, **kw: ginsim.MonteCarloJob(side, *a, **kw))
         per_sample = 48 + (8 if self.imu.odo else 0) + 72 * len(fused) + (24 if self.imu.magnetometer else 0) + \
             (48.0 * raw['gps'].shape[0] / n if self.imu.gps else 0)
         keep = self.keep_trajectories
@@ -357,8 +353,8 @@ class Sim(object):
             hit = np.where(t_axis >= max(float(start_s), 0.0))[0]
             return int(hit[0]) if hit.shape[0] else 0
 
-        def make_job(g, kinds_, runs_, keep_sens, keep_traj, on_side=False, **kw):
-            return (new_kept_job if on_side else new_job)(fs_imu, self.ref_frame, truth, self.imu.accel_err, self.imu.gyro_err,
+        def make_job(g, kinds_, runs_, keep_sens, keep_traj, **kw):
+            return new_job(fs_imu, self.ref_frame, truth, self.imu.accel_err, self.imu.gyro_err,
                            g['ini'], runs=runs_, algos=tuple(kinds_), odo_err=self.imu.odo_err,
                            earth_rot=g['earth_rot'], seed=seed, run_offset=first,
                            ini_first=g['first'] + first, keep_sensors=keep_sens, keep_traj=keep_traj,
@@ -380,8 +376,8 @@ class Sim(object):
                     for i in g['idx']:
                         stats_jobs[i] = kept_jobs[i] = job
                     continue
-                if kcount > 0:  # first, so that its one workgroup has its CU before the launch over all runs fills the chip
-                    kj = make_job(g, g['kinds'], kcount, sensor_job is None, True, on_side=True)
+                if kcount > 0:  # the kept runs: one small launch (a second stream does not help: DESIGN_EXPERIMENTS E7.4)
+                    kj = make_job(g, g['kinds'], kcount, sensor_job is None, True)
                     kj.launch()
                     sensor_job = sensor_job or kj
                     for i in g['idx']:
@@ -402,8 +398,6 @@ class Sim(object):
                                      seed=seed, run_offset=first, keep_sensors=True, **vib)
                 sensor_job.launch()
             ctx.sync()
-            if side is not None and not keep and kcount > 0:
-                side.sync()
         for i in fused:                         # FreeIntegration.run_times accounting (free_integration.py:69)
             algos[i].run_times += self.sim_count
 

@@ -34,6 +34,8 @@ timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --kernel-trace -d $OUT/prof_pmc_mix -o bench -- $B > $OUT/prof_pmc_mix.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace -d $OUT/prof_pmc_lds -o bench -- $B > $OUT/prof_pmc_lds.log 2>&1
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace -d $OUT/prof_pmc_grbm -o bench -- $B > $OUT/prof_pmc_grbm.log 2>&1
+# round 5: where the waves of the Allan kernels wait (SQ_WAIT_ANY next to the LDS side)
+timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM --kernel-trace -d $OUT/prof_pmc_wait -o bench -- $B > $OUT/prof_pmc_wait.log 2>&1
 # round 4: where the store-bound launches wait (SQ side of the vector-memory path)
 timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL --kernel-trace -d $OUT/prof_pmc_store -o bench -- $B > $OUT/prof_pmc_store.log 2>&1
 # (TA_* / TCP_* / TCC_* stall counters: the rocprofv3 of this image aborts on a TA_* pass and then hangs in its signal handler --

@@ -162,3 +162,40 @@ for kn, c in pmc.items():
         print('%s: VALU per step and 64 runs = %.1f' % (name, valu[name]['valu_per_step_and_64_runs']))
 with open(os.path.join(DST, tag + '_valu_per_step.json'), 'w') as f:
     json.dump({'raw_run': 'gpurun_out/round_' + tag, 'libginsim_sha256': sha, 'kernels': valu}, f, indent=1)
+
+# --- round 5: per-unit utilisation of the dominant Allan kernel (levels 0 + 1 fused), VERDICT r04 item 1
+units = {}
+dur = {}
+for d in sorted(os.listdir(SRC)):
+    if d.startswith('prof_pmc'):
+        con = db(d)
+        if con:
+            for kn, n, avg in con.execute("select name, count(*), avg(end - start) from kernels where name like '%allan%' group by name"):
+                dur.setdefault(kn, []).append(avg)
+for kn, c in pmc.items():
+    if 'ginsim::allan_' not in kn or not dur.get(kn):
+        continue
+    t = sum(dur[kn]) / len(dur[kn]) * 1e-9                      # seconds per dispatch, averaged over the counter passes
+    name = kn[len('void '):kn.index('(')] if kn.startswith('void ') else kn[:kn.index('(')] if '(' in kn else kn
+    u = {'dispatch_us_under_the_counter_passes': t * 1e6}
+    if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+        u['hbm_bytes'] = (2.0 * c['FETCH_SIZE'][1] + c['WRITE_SIZE'][1]) * 1024
+        u['hbm_frac_of_8TBps'] = u['hbm_bytes'] / t / 8e12
+    if 'SQ_ACTIVE_INST_VALU' in c:
+        u['valu_busy_frac_of_1024_simds_at_2.4GHz'] = 4.0 * c['SQ_ACTIVE_INST_VALU'][1] / (SIMDS * 2.4e9 * t)
+    if 'SQ_LDS_IDX_ACTIVE' in c:
+        u['lds_active_frac_of_256_cus_at_2.4GHz'] = c['SQ_LDS_IDX_ACTIVE'][1] / (256 * 2.4e9 * t)
+        if 'SQ_LDS_BANK_CONFLICT' in c:
+            u['lds_bank_conflict_over_active'] = c['SQ_LDS_BANK_CONFLICT'][1] / c['SQ_LDS_IDX_ACTIVE'][1]
+    if 'SQ_WAVE_CYCLES' in c:
+        for k in ('SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY'):
+            if k in c:
+                u[k.lower() + '_over_wave_cycles'] = c[k][1] / c['SQ_WAVE_CYCLES'][1]
+    units[name] = u
+if units:
+    with open(os.path.join(DST, tag + '_allan_units.json'), 'w') as f:
+        json.dump({'raw_run': 'gpurun_out/round_' + tag, 'libginsim_sha256': sha,
+                   'what': 'per-unit utilisation of the Allan kernels of config 5 (192 x 1 440 000): HBM bytes from FETCH_SIZE x 2 + WRITE_SIZE, '
+                           'VALU-busy SIMD cycles (4 x SQ_ACTIVE_INST_VALU), LDS-array cycles (SQ_LDS_IDX_ACTIVE) and the wave-cycle split, each '
+                           'against the dispatch time under the counter passes', 'kernels': units}, f, indent=1)
+    print(json.dumps(units, indent=1))
