@@ -927,35 +927,38 @@ __global__ void __launch_bounds__(64 * kTailWaves) allan_tail_kernel(const doubl
 // own sums are folded across the wavefronts in a fixed order), wavefronts 6 and 7 fold the records of the levels before
 // meanwhile; after one barrier the single-chunk levels run as in allan_tail_kernel, from LDS.
 constexpr int kWideChunks = 6;
-constexpr int kWideWaves = 8;
+constexpr int kWideWaves = 4;       // one per SIMD: the bounds-checked passes want more than 256 registers
 
 __global__ void __launch_bounds__(64 * kWideWaves) allan_wide_kernel(const double* __restrict__ in, const double* __restrict__ partial,
                                                                      double* __restrict__ sums, const AllanLevel lvm, const int level,
                                                                      const AllanTail t, const AllanFold f) {
-    __shared__ __attribute__((aligned(16))) double stage[kWideChunks][kStage];
+    __shared__ __attribute__((aligned(16))) double stage[kWideWaves][kStage];
     __shared__ double nxt[kWideChunks * (kChunk / 10) + 8];     // the first single-chunk level: sums of 10 of this one
     __shared__ double lev_store[256 + 32 + 8];
     __shared__ double red[kWideChunks][9];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t s = blockIdx.x;
-    if (wave < kWideChunks) {
+    const double* x = in + s * lvm.in_stride;
+    double* w = stage[wave];
+    // wavefront w takes chunks w, w + 4 (six chunks: two wavefronts take two); the two with one chunk fold the records of the levels
+    // before -- the fused pair of config 5 -- behind it
+#pragma unroll 1
+    for (int64_t c = wave; c < kWideChunks; c += kWideWaves) {
         double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (wave < lvm.nchunks) {
-            const double* x = in + s * lvm.in_stride;
-            double* w = stage[wave];
-            const int64_t c = wave, base = c * kChunk;
+        if (c < lvm.nchunks) {
+            const int64_t base = c * kChunk;
             const double shift = x[base];
 #pragma unroll 1
-            for (int q0 = 0; q0 < kLoads; q0 += 10) {       // 4 x 10 independent wave loads, unshifted, the origin beyond the end
-                double v[10];
+            for (int q0 = 0; q0 < kLoads; q0 += 20) {       // 2 x 20 independent wave loads; zero beyond the end (entries are shifted)
+                double v[20];
 #pragma unroll
-                for (int q = 0; q < 10; ++q) {
+                for (int q = 0; q < 20; ++q) {
                     const int64_t g = base + (q0 + q) * 64 + lane;
                     v[q] = x[g < lvm.n_in ? g : lvm.n_in - 1];
                 }
 #pragma unroll
-                for (int q = 0; q < 10; ++q) {
+                for (int q = 0; q < 20; ++q) {
                     const int i = (q0 + q) * 64 + lane;
                     if (i < kStage) w[i] = (base + i < lvm.n_in) ? v[q] - shift : 0.0;
                 }
@@ -963,16 +966,18 @@ __global__ void __launch_bounds__(64 * kWideWaves) allan_wide_kernel(const doubl
             wave_sync();
             if (chunk_is_interior(c, lvm)) chunk_passes<false>(w, lane, c, lvm, shift, nxt, acc);
             else chunk_passes<true>(w, lane, c, lvm, shift, nxt, acc);
+            wave_sync();
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             double a = acc[j];
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
-            if (lane == 0) red[wave][j] = a;
+            if (lane == 0) red[c][j] = a;
         }
-    } else {
-        for (int k = wave - kWideChunks; k < f.nlevels; k += kWideWaves - kWideChunks) {
+    }
+    if (wave >= kWideChunks - kWideWaves) {
+        for (int k = wave - (kWideChunks - kWideWaves); k < f.nlevels; k += 2 * kWideWaves - kWideChunks) {
             if (k == f.fused_level) fold_partials_fused(partial, sums, f, s, k, t.nseries, lane);
             else fold_partials(partial, sums, f, s, k, t.nseries, lane);
         }
