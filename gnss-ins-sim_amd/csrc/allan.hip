@@ -812,27 +812,27 @@ allan_fused_kernel(const double* __restrict__ in, double* __restrict__ out1, dou
 // Workgroups beyond the first t.nseries * (t.nlevels > 0) fold the per-workgroup partial records of the levels before: one
 // 64-lane workgroup per (series, level), lanes stride over the records of each factor, then a fixed butterfly.
 __device__ __forceinline__ void fold_partials(const double* __restrict__ partial, double* __restrict__ sums, const AllanFold& f,
-                                              int64_t s, int k, int64_t nseries, int lane) {
+                                              int64_t s, int k, int64_t nseries) {
     const int nparts = f.nparts[k];
     const double* p = partial + (f.offset[k] + s * nparts) * 9;
     for (int j = 0; j < 9; ++j) {
         double a = 0.0;
-        for (int c = lane; c < nparts; c += 64) a += p[c * 9 + j];
+        for (int c = threadIdx.x; c < nparts; c += 64) a += p[c * 9 + j];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
-        if (lane == 0) sums[((int64_t)k * nseries + s) * 9 + j] = a;
+        if (threadIdx.x == 0) sums[((int64_t)k * nseries + s) * 9 + j] = a;
     }
 }
 
 // The fused kernel's level: sums inside the workgroups' chunks + the pairs (last bin of workgroup c, first bin of workgroup c+1)
 // from the recorded first / last sums, d = (first' - last) + j (origin' - origin).  A pair exists when its second bin does.
 __device__ __forceinline__ void fold_partials_fused(const double* __restrict__ partial, double* __restrict__ sums, const AllanFold& f,
-                                                    int64_t s, int k, int64_t nseries, int lane) {
+                                                    int64_t s, int k, int64_t nseries) {
     const int nparts = f.nparts[k];
     const double* p = partial + f.offset[k] * 9 + s * nparts * kFuseRecord;
     for (int j = 0; j < 9; ++j) {
         double a = 0.0;
-        for (int c = lane; c < nparts; c += 64) {
+        for (int c = threadIdx.x; c < nparts; c += 64) {
             a += p[(int64_t)c * kFuseRecord + j];
             if (c + 1 < nparts && (int64_t)(c + 1) * (kChunk / (j + 1)) < f.fused_nb[j]) {
                 const double* q0 = p + (int64_t)c * kFuseRecord;
@@ -843,7 +843,7 @@ __device__ __forceinline__ void fold_partials_fused(const double* __restrict__ p
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
-        if (lane == 0) sums[((int64_t)k * nseries + s) * 9 + j] = a;
+        if (threadIdx.x == 0) sums[((int64_t)k * nseries + s) * 9 + j] = a;
     }
 }
 
@@ -852,12 +852,24 @@ __device__ __forceinline__ void fold_partials_fused(const double* __restrict__ p
 // passes of its own level(s) at the same time -- wavefront w level w, wavefront 2 also the tiny fourth one.  (One wavefront
 // doing the levels one after the other, each producing the next, took 30 us for 1440 / 144 / 14 entries.)
 constexpr int kTailWaves = 3;
-
-// the tail levels of ONE series by the first `nwaves` wavefronts of a workgroup (all of them pass the barrier); x = entries of
-// the first tail level (memory or LDS), stage = one kStage region per wavefront, lev_store = 256 + 32 + 8 doubles
-__device__ __forceinline__ void tail_levels(const double* __restrict__ x, double (*stage)[kStage], double* __restrict__ lev_store,
-                                            double* __restrict__ sums, const AllanTail& t, int64_t s, int wave, int lane, int nwaves) {
+__global__ void __launch_bounds__(64 * kTailWaves) allan_tail_kernel(const double* __restrict__ in, const double* __restrict__ partial,
+                                                                     double* __restrict__ sums, const AllanTail t, const AllanFold f) {
+    __shared__ __attribute__((aligned(16))) double stage[kTailWaves][kStage];
+    __shared__ double lev_store[256 + 32 + 8];          // entries of the second, third and fourth tail level (<= 252, 25, 2)
     auto lev = [&](int l) -> double* { return lev_store + (l == 0 ? 0 : (l == 1 ? 256 : 288)); };
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t ntail = t.nlevels > 0 ? t.nseries : 0;
+    if ((int64_t)blockIdx.x >= ntail) {
+        if (wave != 0) return;
+        const int64_t b = (int64_t)blockIdx.x - ntail;
+        const int k = (int)(b / t.nseries);
+        if (k == f.fused_level) fold_partials_fused(partial, sums, f, b % t.nseries, k, t.nseries);
+        else fold_partials(partial, sums, f, b % t.nseries, k, t.nseries);
+        return;
+    }
+    const int64_t s = blockIdx.x;
+    const double* x = in + s * t.in_stride;
     if (wave == 0) {
         // level l+1 entry i = 10 sh + sum_t (E_l[10 i + t] - sh), sh = E_l[0]: the same value the level passes hand on
         const double* src = x;
@@ -875,8 +887,7 @@ __device__ __forceinline__ void tail_levels(const double* __restrict__ x, double
         }
     }
     __syncthreads();
-    if (wave >= nwaves) return;
-    for (int l = wave; l < t.nlevels; l += nwaves) {
+    for (int l = wave; l < t.nlevels; l += kTailWaves) {
         const double* src = l == 0 ? x : lev(l - 1);
         AllanLevel lv;
         lv.n_in = t.n_in[l];
@@ -898,108 +909,6 @@ __device__ __forceinline__ void tail_levels(const double* __restrict__ x, double
             if (lane == 0) sums[((int64_t)(t.first + l) * t.nseries + s) * 9 + j] = a;
         }
     }
-}
-
-__global__ void __launch_bounds__(64 * kTailWaves) allan_tail_kernel(const double* __restrict__ in, const double* __restrict__ partial,
-                                                                     double* __restrict__ sums, const AllanTail t, const AllanFold f) {
-    __shared__ __attribute__((aligned(16))) double stage[kTailWaves][kStage];
-    __shared__ double lev_store[256 + 32 + 8];          // entries of the second, third and fourth tail level (<= 252, 25, 2)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t ntail = t.nlevels > 0 ? t.nseries : 0;
-    if ((int64_t)blockIdx.x >= ntail) {
-        if (wave != 0) return;
-        const int64_t b = (int64_t)blockIdx.x - ntail;
-        const int k = (int)(b / t.nseries);
-        if (k == f.fused_level) fold_partials_fused(partial, sums, f, b % t.nseries, k, t.nseries, lane);
-        else fold_partials(partial, sums, f, b % t.nseries, k, t.nseries, lane);
-        return;
-    }
-    const int64_t s = blockIdx.x;
-    tail_levels(in + s * t.in_stride, stage, lev_store, sums, t, s, wave, lane, kTailWaves);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5: ONE launch behind the fused kernel instead of two.  What is left of config 5 after levels 0 + 1 is latency, not
-// work: level 2 (14 400 entries per series = 5.7 chunks; 14-24 us as a launch of its own), the fold of the records and the
-// three single-chunk levels (21-29 us).  Here a workgroup of eight wavefronts takes ONE series: wavefronts 0..5 each stage and
-// pass one chunk of the last multi-chunk level at the same time (its sums of 10 -- the first single-chunk level -- go to LDS, its
-// own sums are folded across the wavefronts in a fixed order), wavefronts 6 and 7 fold the records of the levels before
-// meanwhile; after one barrier the single-chunk levels run as in allan_tail_kernel, from LDS.
-constexpr int kWideChunks = 6;
-constexpr int kWideWaves = 4;       // one per SIMD: the bounds-checked passes want more than 256 registers
-
-__global__ void __launch_bounds__(64 * kWideWaves) allan_wide_kernel(const double* __restrict__ in, const double* __restrict__ partial,
-                                                                     double* __restrict__ sums, const AllanLevel lvm, const int level,
-                                                                     const AllanTail t, const AllanFold f) {
-    __shared__ __attribute__((aligned(16))) double stage[kWideWaves][kStage];
-    __shared__ double nxt[kWideChunks * (kChunk / 10) + 8];     // the first single-chunk level: sums of 10 of this one
-    __shared__ double lev_store[256 + 32 + 8];
-    __shared__ double red[kWideChunks][9];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t s = blockIdx.x;
-    const double* x = in + s * lvm.in_stride;
-    double* w = stage[wave];
-    // wavefront w takes chunks w, w + 4 (six chunks: two wavefronts take two); the two with one chunk fold the records of the levels
-    // before -- the fused pair of config 5 -- behind it
-#pragma unroll 1
-    for (int64_t c = wave; c < kWideChunks; c += kWideWaves) {
-        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (c < lvm.nchunks) {
-            const int64_t base = c * kChunk;
-            const double shift = x[base];
-#pragma unroll 1
-            for (int q0 = 0; q0 < kLoads; q0 += 20) {       // 2 x 20 independent wave loads; zero beyond the end (entries are shifted)
-                double v[20];
-#pragma unroll
-                for (int q = 0; q < 20; ++q) {
-                    const int64_t g = base + (q0 + q) * 64 + lane;
-                    v[q] = x[g < lvm.n_in ? g : lvm.n_in - 1];
-                }
-#pragma unroll
-                for (int q = 0; q < 20; ++q) {
-                    const int i = (q0 + q) * 64 + lane;
-                    if (i < kStage) w[i] = (base + i < lvm.n_in) ? v[q] - shift : 0.0;
-                }
-            }
-            wave_sync();
-            if (chunk_is_interior(c, lvm)) chunk_passes<false>(w, lane, c, lvm, shift, nxt, acc);
-            else chunk_passes<true>(w, lane, c, lvm, shift, nxt, acc);
-            wave_sync();
-        }
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            double a = acc[j];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
-            if (lane == 0) red[c][j] = a;
-        }
-    }
-    if (wave >= kWideChunks - kWideWaves) {
-        for (int k = wave - (kWideChunks - kWideWaves); k < f.nlevels; k += 2 * kWideWaves - kWideChunks) {
-            if (k == f.fused_level) fold_partials_fused(partial, sums, f, s, k, t.nseries, lane);
-            else fold_partials(partial, sums, f, s, k, t.nseries, lane);
-        }
-    }
-    __syncthreads();
-    if (wave == kWideWaves - 1 && lane < 9) {           // this level's sums: the chunks in order
-        double a = 0.0;
-        for (int c = 0; c < kWideChunks; ++c) a += red[c][lane];
-        sums[((int64_t)level * t.nseries + s) * 9 + lane] = a;
-    }
-    tail_levels(nxt, stage, lev_store, sums, t, s, wave, lane, kTailWaves);
-}
-
-bool allan_wide_applies(const AllanLevel& lvm, const AllanTail& t) {
-    const char* e = getenv("GINSIM_ALLAN_WIDE");        // read per call: the tests run both forms in one process
-    return (e ? atoi(e) : 1) != 0 && lvm.nchunks <= kWideChunks && lvm.n_out == t.n_in[0] && t.nlevels >= 1 && t.nlevels <= 4;
-}
-
-hipError_t launch_allan_wide(const double* in, const double* partial, double* sums, const AllanLevel& lvm, int level, const AllanTail& t,
-                             const AllanFold& f, int64_t nseries, hipStream_t st) {
-    hipLaunchKernelGGL(allan_wide_kernel, dim3((unsigned)nseries), dim3(64 * kWideWaves), 0, st, in, partial, sums, lvm, level, t, f);
-    return hipGetLastError();
 }
 
 int allan_parts(const AllanLevel& lv) {

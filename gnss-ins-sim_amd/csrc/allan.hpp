@@ -48,10 +48,6 @@ int allan_fuse_parts(const AllanLevel& lv);
 int allan_fuse_record();        // doubles per level-k+1 record (a multiple of 9)
 hipError_t launch_allan_fused(const double* in, double* out1, double* out2, double* partial0, double* partial1, const AllanLevel& lv,
                               const AllanLevel& lv1, int64_t nseries, hipStream_t st);
-// the last multi-chunk level (at most six chunks) + the fold + the single-chunk levels, one workgroup per series, in ONE launch
-bool allan_wide_applies(const AllanLevel& lvm, const AllanTail& t);
-hipError_t launch_allan_wide(const double* in, const double* partial, double* sums, const AllanLevel& lvm, int level, const AllanTail& t,
-                             const AllanFold& f, int64_t nseries, hipStream_t st);
 // ONE launch finishes the call: workgroups 0 .. nseries-1 run the levels that fit a chunk, the others fold the partial records
 // of the levels before (either part may be empty)
 hipError_t launch_allan_finish(const double* in, const double* partial, double* sums, const AllanTail& t, const AllanFold& f,

@@ -809,22 +809,7 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
         }
         fold.nlevels = k;
     }
-    // the last multi-chunk level, when it is short (at most six chunks: 14 400 entries at config 5), is not a launch of its own:
-    // the finishing launch takes it, one workgroup per series (allan_wide_kernel)
-    int wide_level = -1;
-    if (!steps.empty() && steps.back().mode != 2 && steps.back().k == fold.nlevels - 1 && levels - fold.nlevels >= 1 &&
-        levels - fold.nlevels <= 4) {
-        const int k = steps.back().k;
-        AllanTail probe;
-        probe.nlevels = levels - fold.nlevels;
-        probe.n_in[0] = lvs[k + 1].n_in;
-        if (allan_wide_applies(lvs[k], probe)) {
-            wide_level = k;
-            steps.pop_back();
-            fold.nlevels = k;
-        }
-    }
-    REQUIRE(levels - fold.nlevels - (wide_level >= 0 ? 1 : 0) <= 4, "allan: internal level plan");
+    REQUIRE(levels - fold.nlevels <= 4, "allan: internal level plan");
     struct Region { void* p; double* d() const { return reinterpret_cast<double*>(p); } } ping, pong, partial;
     const size_t b_ping = sizeof(double) * (size_t)nseries * (n1 + 1), b_pong = sizeof(double) * (size_t)nseries * (n1 / 10 + 1);
     const size_t b_part = sizeof(double) * 9 * (size_t)(records + 1), b_sums = 0;
@@ -853,8 +838,8 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
         in = out;
     }
     AllanTail t;
-    t.first = fold.nlevels + (wide_level >= 0 ? 1 : 0);
-    t.nlevels = levels - t.first;
+    t.first = fold.nlevels;
+    t.nlevels = levels - fold.nlevels;
     t.in_stride = t.nlevels > 0 ? lvs[t.first].in_stride : 0;
     t.nseries = nseries;
     for (int l = 0; l < t.nlevels; ++l) {
@@ -868,8 +853,7 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->allan_host), sizeof(double) * (nsums + nsums / 4 + 64), hipHostMallocDefault));
         c->allan_host_doubles = nsums + nsums / 4 + 64;
     }
-    if (wide_level >= 0) HIP_TRY(launch_allan_wide(in, partial.d(), c->allan_host, lvs[wide_level], wide_level, t, fold, nseries, c->stream));
-    else HIP_TRY(launch_allan_finish(in, partial.d(), c->allan_host, t, fold, nseries, c->stream));
+    HIP_TRY(launch_allan_finish(in, partial.d(), c->allan_host, t, fold, nseries, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const double* h = c->allan_host;
     for (int i = 0; i < nt; ++i) {
