@@ -98,22 +98,6 @@ static hipError_t scratch(ginsim_ctx* c, int slot, size_t bytes, void** out) {
     return hipSuccess;
 }
 
-// Wait for the context's stream with the host thread SPINNING on hipStreamQuery for up to ~2 ms before it falls back to the
-// blocking hipStreamSynchronize: the calls that end with a synchronisation and return a few hundred bytes (ginsim_allan: 0.5 ms of
-// kernels) otherwise pay the wake-up latency of a blocked thread, which is box dependent (measured: 32 us of host time around the
-// kernels of an Allan call on one box, 70 us on another).  GINSIM_SPIN_WAIT=0 switches it off (read per call).
-static hipError_t wait_stream(ginsim_ctx* c) {
-    const char* e = getenv("GINSIM_SPIN_WAIT");
-    if (!e || atoi(e) != 0) {
-        for (int i = 0; i < 4000; ++i) {
-            const hipError_t q = hipStreamQuery(c->stream);
-            if (q == hipSuccess) return hipSuccess;
-            if (q != hipErrorNotReady) return q;
-        }
-    }
-    return hipStreamSynchronize(c->stream);
-}
-
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -870,7 +854,7 @@ int ginsim_allan(ginsim_ctx* c, const double* x, int64_t n, int32_t nseries, int
         c->allan_host_doubles = nsums + nsums / 4 + 64;
     }
     HIP_TRY(launch_allan_finish(in, partial.d(), c->allan_host, t, fold, nseries, c->stream));
-    HIP_TRY(wait_stream(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     const double* h = c->allan_host;
     for (int i = 0; i < nt; ++i) {
         const int64_t m = mult[i];
