@@ -108,6 +108,8 @@ class _Parts(object):
         ids = np.asarray(run_ids, dtype=np.int64).reshape(-1)
         if ids.size and (ids.min() < 0 or ids.max() >= self.runs):
             raise ValueError('run id out of range [0, %d)' % self.runs)
+        if ids.size == 0:                       # nothing asked for: the (empty) answer of any device that holds runs
+            return fetch(next(j for j in self.parts if j is not None), ids)
         owner = np.searchsorted(self._bounds, ids, side='right') - 1
         chunks = {}
         for d in np.unique(owner):
