@@ -381,6 +381,23 @@ def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0, pmc=Non
         ctx.timer_begin()
         ginsim.allan_var(ctx, x, n, S, n, fs)
         ms.append(ctx.timer_end())
+    # The same series from ANOTHER allocation of this process: the call's time is bimodal by where a buffer landed (the backing, not
+    # the address: profiles/r05_allan_buffer_placement.json), +-4 % on one box.  The roofline below stays the job's own buffer.
+    other = None
+    if calls >= 10:
+        cp = ctx.malloc(8 * S * n + 4096)
+        check(ginsim.lib.ginsim_runs_to_series(ctx.handle, x.ptr, 1, S * n, 1, cp.ptr))        # C = 1, R = 1: a plain device copy
+        for _ in range(warm // 2):
+            ginsim.allan_var(ctx, cp, n, S, n, fs)
+        ms2 = []
+        for _ in range(calls):
+            ctx.timer_begin()
+            ginsim.allan_var(ctx, cp, n, S, n, fs)
+            ms2.append(ctx.timer_end())
+        a2 = sum(ms2) / len(ms2)
+        other = {'kernel_ms_avg': a2, 'ms_min': min(ms2), 'frac': 8.0 * S * n / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 'note': 'a device copy of the same series in a buffer allocated for this measurement'}
+        cp.free()
     if tmp is not None:
         tmp.free()
     avg = sum(ms) / len(ms)
@@ -401,6 +418,8 @@ def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0, pmc=Non
                                 (call_traffic or {}).get('hbm_bytes_per_call'), traffic_detail=call_traffic,
                                 traffic_over_algorithmic=(call_traffic['hbm_bytes_per_call'] / (8.0 * S * n)) if call_traffic else None),
            'result': {'ad_gyro_x_at_1s_over_arw': float(ad['gyro'][:, k1, 0].mean() / arw * np.sqrt(tau[k1]))}}
+    if other is not None:
+        out['same_series_in_another_allocation'] = other
     job.release()
     return out
 

@@ -192,6 +192,25 @@ def test_sim_devices_equals_sim_on_one_context(tmp_path, capsys):
     _compare_sims(two, one, 300, tmp_path, capsys)
 
 
+def test_sim_devices_writes_the_same_files(tmp_path, capsys):
+    """results(data_dir) of a Sim spread over two contexts: the CSV files of the saved runs and the summary are byte-identical
+    to the single-context Sim's (Sim_data.save_to_file, sim_data.py:117-165; the views route every run to the device that holds it)."""
+    import filecmp
+    one, two = _sim(None, runs=40), _sim([0, 0], runs=40)
+    da, db = tmp_path / 'one', tmp_path / 'two'
+    one.results(str(da), err_stats_start=-1, max_saved_runs=40)
+    two.results(str(db), err_stats_start=-1, max_saved_runs=40)
+    capsys.readouterr()
+    files = sorted(os.listdir(da))
+    assert files == sorted(os.listdir(db)) and len(files) > 200 and 'accel-39.csv' in files and 'pos-algo1_21.csv' in files
+    for f in files:
+        if f == 'summary.txt':          # the two summaries name their own directories
+            a, b = open(da / f).read().replace(str(da), ''), open(db / f).read().replace(str(db), '')
+            assert a == b
+        else:
+            assert filecmp.cmp(da / f, db / f, shallow=False), f
+
+
 def test_sim_devices_statistics_only(tmp_path, capsys):
     """The statistics-only launches (online process statistics, NED end-point record, a few kept runs) spread the same way."""
     one = _sim(None, runs=1001, keep=False, rf=0, keep_runs=5)

@@ -21,6 +21,9 @@ for l in d.get('configs', []):
         print('    generation %.4f ms (min %.4f) bound %s frac %.3f %s; allan wall %.4f ms, call min %.4f ms, traffic/alg %s' % (
             l['sensor_generation_ms'], l['sensor_generation_ms_min'], g['bound'], g['frac'], ('hbm %.3f' % g['hbm']['frac']) if 'hbm' in g else '',
             l['relayout_plus_allan_wall_ms'], l['allan_call_ms_min'], ro.get('traffic_over_algorithmic')))
+        if 'same_series_in_another_allocation' in l:
+            o = l['same_series_in_another_allocation']
+            print('    another allocation of the same series: %.4f ms avg (min %.4f) frac %.3f' % (o['kernel_ms_avg'], o['ms_min'], o['frac']))
     if l['name'] == 'sim_e2e':
         for t in ('C2', 'C3'):
             print('    sim %s run %.4f s results %.4f s  %.4g sample*MC/s  walls %s %s' % (t, l[t]['run_wall_s'], l[t]['results_wall_s'], l[t]['sample_MC_per_s_end_to_end'],
