@@ -321,6 +321,31 @@ __device__ __forceinline__ Vec3 vibration_phase(vib_ptr v, const RngKey& key) {
     return Vec3{((double)w.x * 0x1p-32 * 2.0) * kPi, ((double)w.y * 0x1p-32 * 2.0) * kPi, ((double)w.z * 0x1p-32 * 2.0) * kPi};
 }
 
+// the term itself, the three normals of a 'random' vibration given (zx, zy, zz: whoever generated them -- this wavefront, or the
+// producers of the wave-specialised kernel through the LDS ring)
+__device__ __forceinline__ Vec3 vibration_term(const Vec3& o, vib_ptr v, double zx, double zy, double zz, uint32_t j, const Vec3& phase) {
+    Vec3 r = o;
+    if (v->type == GINSIM_VIB_RANDOM) {
+        r.x = o.x + v->amp[0] * zx;
+        r.y = o.y + v->amp[1] * zy;
+        r.z = o.z + v->amp[2] * zz;
+    } else if (v->type == GINSIM_VIB_SINUSOIDAL) {
+        const double cj = v->omega_dt * (double)j;          // (2 pi f dt) * arange(n), rounded before the phase is added
+        if (v->random_phase) {
+            const double ax = cj + phase.x, ay = cj + phase.y, az = cj + phase.z;
+            r.x = o.x + v->amp[0] * sin(ax);
+            r.y = o.y + v->amp[1] * sin(ay);
+            r.z = o.z + v->amp[2] * sin(az);
+        } else {
+            const double s = sin(cj);
+            r.x = o.x + v->amp[0] * s;
+            r.y = o.y + v->amp[1] * s;
+            r.z = o.z + v->amp[2] * s;
+        }
+    }
+    return r;
+}
+
 template <uint32_t STREAM>
 __device__ __forceinline__ Vec3 add_vibration(const Vec3& o, vib_ptr v, const RngKey& key, uint32_t j, const NormalTables& tab,
                                               const Vec3& phase) {
@@ -518,8 +543,15 @@ constexpr size_t kSplitLds = kSplitRing > 100 * 1024 ? kSplitRing : 100 * 1024;
 // steps of a tile alternate between the two producer groups.
 // KEEP = false: a statistics-only launch (no series pointer set): the store code and its address registers are compiled out,
 // which is what lets the ref_frame 0 consumer fit the 168 registers of three wavefronts per SIMD.
-template <int RF, int ALGOS, bool WD, int PROD = 1, bool KEEP = true>
+// VIB (round 5): the vibration term of Sim(env=...) in the wave-specialised kernel, for the batches where the plain vibration kernel
+// runs with ONE wavefront per SIMD (<= 1024 wavefronts of runs: C2).  The three normals per sensor of a 'random' vibration are one
+// more Philox block each and come from the producers -- the ring carries 18 floats per step and run instead of 12, in tiles of 4
+// steps instead of 6 (the same 144 KB) --, a sinusoidal term is evaluated by the consumer; same operations on the same values as
+// mc_kernel<..., VIB = true> (vibration_term), so the two kernels agree to the bit.
+template <int RF, int ALGOS, bool WD, int PROD = 1, bool KEEP = true, bool VIB = false>
 __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim_mc_params a_in) {
+    static_assert(!VIB || WD, "vibration: general sensor model");
+    constexpr int kSplitTile = VIB ? 4 : ginsim::kSplitTile;
     ginsim_mc_params a = a_in;
     if (!KEEP) {
         a.out_accel = a.out_gyro = a.out_odo = nullptr;
@@ -528,7 +560,7 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim
     extern __shared__ float zring[];                    // [2 stages][T steps][12 normals][256 runs]
     constexpr bool FREE = (ALGOS & GINSIM_ALGO_FREE) != 0;
     constexpr bool ODO = (ALGOS & GINSIM_ALGO_ODO) != 0;
-    constexpr int kStepFloats = kSplitStep * kSplitRuns / 4;           // 3072 floats per step
+    constexpr int kStepFloats = (VIB ? 18 : 12) * kSplitRuns;          // 3072 (4608) floats per step
     const int lane = threadIdx.x & (kSplitRuns - 1);
     const bool producer = threadIdx.x >= kSplitRuns;
     const int pgroup = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) - 1;     // which producer group (wave-uniform)
@@ -563,6 +595,19 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim
                             zb[(2 * k) * kSplitRuns] = z0[k];
                             zb[(2 * k + 1) * kSplitRuns] = z1[k];
                         }
+                        if (VIB) {              // streams 10-13: one block per sensor with a 'random' vibration (wave-uniform)
+                            const params_ptr kv = kernarg_params();
+                            if (kv->vib_accel.type == GINSIM_VIB_RANDOM) {
+                                float v0[2], v1[2];
+                                normal_pairs_f32<S_ACC_VIB_XY, 2>(key, (uint32_t)j, v0, v1, tab);
+                                zb[12 * kSplitRuns] = v0[0]; zb[13 * kSplitRuns] = v1[0]; zb[14 * kSplitRuns] = v0[1];
+                            }
+                            if (kv->vib_gyro.type == GINSIM_VIB_RANDOM) {
+                                float v0[2], v1[2];
+                                normal_pairs_f32<S_GYR_VIB_XY, 2>(key, (uint32_t)j, v0, v1, tab);
+                                zb[15 * kSplitRuns] = v0[0]; zb[16 * kSplitRuns] = v1[0]; zb[17 * kSplitRuns] = v0[1];
+                            }
+                        }
                     }
                 }
             }
@@ -578,6 +623,11 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim
     if (FREE) nav_init<RF>(fi, ini, a.ini_has_g);
     if (ODO) nav_init<RF>(od, ini, a.ini_has_g);
     Vec3 da{0.0, 0.0, 0.0}, dg{0.0, 0.0, 0.0};
+    Vec3 vpa{0.0, 0.0, 0.0}, vpg{0.0, 0.0, 0.0};
+    if (VIB) {
+        vpa = vibration_phase<S_ACC_VIB_PHASE>(&kernarg_params()->vib_accel, key);
+        vpg = vibration_phase<S_GYR_VIB_PHASE>(&kernarg_params()->vib_gyro, key);
+    }
     if (active) {
         if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
         if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
@@ -600,8 +650,20 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim
                     p1[k] = (double)zb[(2 * k + 1) * kSplitRuns];
                 }
                 const params_ptr kp = kernarg_params();
-                const Vec3 acc = sense3<WD>(cur_a, &kp->accel, da, Vec3{p0[0], p1[0], p0[1]}, Vec3{p1[1], p0[2], p1[2]});
-                const Vec3 gyr = sense3<WD>(cur_g, &kp->gyro, dg, Vec3{p0[3], p1[3], p0[4]}, Vec3{p1[4], p0[5], p1[5]});
+                Vec3 acc = sense3<WD>(cur_a, &kp->accel, da, Vec3{p0[0], p1[0], p0[1]}, Vec3{p1[1], p0[2], p1[2]});
+                Vec3 gyr = sense3<WD>(cur_g, &kp->gyro, dg, Vec3{p0[3], p1[3], p0[4]}, Vec3{p1[4], p0[5], p1[5]});
+                if (VIB) {              // added last, as pathgen.py:500, 562 do
+                    const params_ptr kv = kernarg_params();
+                    double va[3] = {0.0, 0.0, 0.0}, vg[3] = {0.0, 0.0, 0.0};
+                    if (kv->vib_accel.type == GINSIM_VIB_RANDOM) {
+                        va[0] = (double)zb[12 * kSplitRuns]; va[1] = (double)zb[13 * kSplitRuns]; va[2] = (double)zb[14 * kSplitRuns];
+                    }
+                    if (kv->vib_gyro.type == GINSIM_VIB_RANDOM) {
+                        vg[0] = (double)zb[15 * kSplitRuns]; vg[1] = (double)zb[16 * kSplitRuns]; vg[2] = (double)zb[17 * kSplitRuns];
+                    }
+                    acc = vibration_term(acc, &kv->vib_accel, va[0], va[1], va[2], (uint32_t)j, vpa);
+                    gyr = vibration_term(gyr, &kv->vib_gyro, vg[0], vg[1], vg[2], (uint32_t)j, vpg);
+                }
                 if (a.out_accel) store3(a.out_accel, plane, off, acc);
                 if (a.out_gyro) store3(a.out_gyro, plane, off, gyr);
                 double odo = 0.0;
@@ -655,7 +717,13 @@ static int split_policy() {        // GINSIM_SPLIT=0 / 1 forces the plain / wave
 static bool any_vibration(const ginsim_mc_params& p) { return p.vib_accel.type != GINSIM_VIB_NONE || p.vib_gyro.type != GINSIM_VIB_NONE; }
 
 int mc_variant(const ginsim_mc_params& p) {
-    if (any_vibration(p)) return 0;                     // the vibration term lives in the plain kernel (general sensor model)
+    if (any_vibration(p)) {
+        // the vibration term lives in the plain kernels, except where they would run with one wavefront per SIMD: a single free
+        // integration, generated sensors, at most 1024 wavefronts of runs (C2's shape) -> mc_kernel_split<..., VIB = true>
+        const char* env = getenv("GINSIM_SPLIT_VIB");        // read per call: the tests run both kernels in one process
+        return (env ? atoi(env) : 1) != 0 && split_policy() != 0 && p.algo_mask == GINSIM_ALGO_FREE && !p.given_sensors && p.block_threads == 0 &&
+               !p.wave_trace && p.n >= 2 && !(p.out_proc[0] || p.out_proc[1]) && (p.runs + kWave - 1) / kWave <= 1024;
+    }
     if (!(p.algo_mask & GINSIM_ALGO_FREE) || p.given_sensors || p.block_threads != 0 || p.wave_trace || p.n < 2) return 0;
     if (p.out_proc[0] || p.out_proc[1]) return 0;      // online process statistics live in the plain kernel
     const int pol = split_policy();
@@ -695,6 +763,19 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
             constexpr int PROD = (ALGOS == GINSIM_ALGO_FREE && RF == 1) ? 2 : 1;
             static const int prod = [] { const char* e = getenv("GINSIM_SPLIT_PROD"); return e ? atoi(e) : PROD; }();
             const dim3 sgrid((unsigned)((p.runs + kSplitRuns - 1) / kSplitRuns));
+            if constexpr (ALGOS == GINSIM_ALGO_FREE && WD) {
+                if (any_vibration(p)) {         // one producer group: the consumer with the vibration term wants more than 168 registers
+                    constexpr size_t lds = (size_t)2 * 4 * 18 * 4 * kSplitRuns;
+                    GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, 1, true, true>", RF, ALGOS, tf(WD))
+                    static PerDeviceOnce oncev;
+                    oncev.run([] {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 1, true, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    });
+                    hipLaunchKernelGGL((mc_kernel_split<RF, ALGOS, WD, 1, true, true>), sgrid, dim3(512), lds, stream, p);
+                    return hipGetLastError();
+                }
+            }
             if constexpr (ALGOS == GINSIM_ALGO_FREE && RF == 0) {     // nothing kept: two producer groups fit here too
                 const bool keep = p.out_accel || p.out_gyro || p.out_odo || p.out_traj[0] || p.out_traj[1];
                 if (!keep && prod != 1) {

@@ -486,3 +486,35 @@ def test_vibration_is_refused_where_it_does_not_live(ctx, turn):
     with pytest.raises(ValueError, match='finite'):
         job.launch()
     job.release()
+
+
+@pytest.mark.parametrize('rf', [0, 1])
+def test_vibration_in_the_wave_specialised_kernel_is_bit_identical(rf, monkeypatch):
+    """Round 5: batches of at most 1024 wavefronts of runs (C2's shape) with a vibration environment run on
+    mc_kernel_split<RF, 1, true, 1, true, VIB = true> -- the 'random' normals from the producers through the LDS ring, a sinusoidal
+    term in the consumer -- instead of the plain vibration kernel with one wavefront per SIMD.  Same operations on the same values
+    (pathgen.py:476-492, 538-556 restated once, vibration_term): sensors, trajectories and end-point errors equal to the bit."""
+    import ginsim
+    from ginsim import workloads
+    fs = 100.0
+    ini, truth, _ = workloads.truth_from_profile('turn_90deg', fs, rf)
+    acc, gyr = workloads.imu_grade('low-accuracy')
+    ctx = ginsim.default_context()
+    envs = [({'type': 'random', 'x': 0.3, 'y': 0.1, 'z': 0.2}, {'type': 'random', 'x': 0.01, 'y': 0.02, 'z': 0.03}),
+            ({'type': 'sinusoidal', 'x': 0.3, 'y': 0.1, 'z': 0.2, 'freq': 2.5}, {'type': 'sinusoidal', 'x': 0.01, 'y': 0.02, 'z': 0.03, 'freq': 0.7}),
+            ({'type': 'sinusoidal', 'x': 0.5, 'y': 0.1, 'z': 0.2, 'freq': 12.0}, {'type': 'random', 'x': 0.002, 'y': 0.001, 'z': 0.003}),
+            (None, {'type': 'random', 'x': 0.002, 'y': 0.001, 'z': 0.003})]
+    ids = np.array([0, 63, 64, 700, 1336])
+    for va, vg in envs:
+        got = {}
+        for flag in ('1', '0'):
+            monkeypatch.setenv('GINSIM_SPLIT_VIB', flag)
+            job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=1337, seed=99, run_offset=11, keep_sensors=True, keep_traj=True,
+                                       vib_accel=va, vib_gyro=vg)
+            name = job.kernel_name()
+            job.run()
+            got[flag] = (name, job.sensors('accel', ids), job.sensors('gyro', ids)) + job.trajectories('free', ids) + (job.end_errors('free'),)
+            job.release()
+        assert got['1'][0] == 'ginsim::mc_kernel_split<%d, 1, true, 1, true, true>' % rf and got['0'][0] == 'ginsim::mc_kernel<%d, 1, false, true, 0, true>' % rf
+        for a, b in zip(got['1'][1:], got['0'][1:]):
+            np.testing.assert_array_equal(a, b)

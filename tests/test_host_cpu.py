@@ -259,8 +259,8 @@ def test_hot_kernels_keep_two_wavefronts_per_simd():
         two_algos = 'ILi0ELi3E' in name or 'ILi1ELi3E' in name
         assert occ >= 2, '%s: %d wavefront(s) per SIMD' % (name, occ)
         if '15mc_kernel_splitI' in name or '19mc_kernel_f32_splitI' in name:
-            # <RF, ALGOS, WD, PROD, KEEP>: 256 consumer + PROD x 256 producer threads, 1 + PROD wavefronts per SIMD
-            m = re.search(r'ELi(\d)ELb[01]EEEv', name)
+            # <RF, ALGOS, WD, PROD, KEEP[, VIB]>: 256 consumer + PROD x 256 producer threads, 1 + PROD wavefronts per SIMD
+            m = re.search(r'ELi(\d)ELb[01]E(?:Lb[01]E)?EEv', name)
             assert m, name
             prod = int(m.group(1))
             split_seen[prod] = split_seen.get(prod, 0) + 1
@@ -462,7 +462,8 @@ def test_dispatch_queries_and_sensor_layout_rules_without_a_gpu():
     v = ginsim.vibration({'type': 'random', 'x': 0.1, 'y': 0.1, 'z': 0.1}, 100.0, False)
     s = ginsim.vibration({'type': 'sinusoidal', 'x': 0.1, 'y': 0.1, 'z': 0.1, 'freq': 2.0}, 100.0, True)
     assert (s.type, s.random_phase) == (2, 1) and s.omega_dt == 2.0 * np.pi * 2.0 * (1.0 / 100.0) and v.type == 1
-    assert query(params(vib_accel=v)) == (0, 'ginsim::mc_kernel<1, 1, false, true, 0, true>')
+    assert query(params(vib_accel=v)) == (1, 'ginsim::mc_kernel_split<1, 1, true, 1, true, true>')        # C2's shape: one wavefront per SIMD otherwise
+    assert query(params(vib_accel=v, runs=65537)) == (0, 'ginsim::mc_kernel<1, 1, false, true, 0, true>')     # larger batches: the plain kernel
     assert query(params(vib_gyro=s, ref_frame=0, algo_mask=3, ref_odo=4096)) == (0, 'ginsim::mc_kernel<0, 3, false, true, 0, true>')
     assert query(params(vib_gyro=s, ref_frame=0, ref_nav=4096, out_proc=(C.c_void_p * 2)(4096, None), proc_pos_ned=1)) == \
         (0, 'ginsim::mc_kernel<0, 1, false, true, 2, true>')
