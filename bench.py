@@ -830,7 +830,7 @@ def main():
                                262144, True, 'f32', 10))
             # Sim(env=...) (beyond BASELINE's configurations, all of which use env=None): the C2 launch in a vibration environment
             legs.append(leg_mc(ginsim, workloads, ctx, 'C2_vibration_random', 'the C2 launch with Sim(env={acc: [0.03 0.03 0.03]g-random, '
-                               'gyro: [0.5 0.5 0.5]d-random}): the vibration variant of the plain general-model kernel', 'turn_90deg',
+                               'gyro: [0.5 0.5 0.5]d-random}): the vibration variant of the wave-specialised kernel (round 5; round 4: the plain kernel, one wavefront per SIMD)', 'turn_90deg',
                                100.0, 1, 65536, True, 'f64', 10,
                                pmc=pmc, valu_too=True, **VIB_LEG))
             legs.append(leg_allan(ginsim, workloads, ctx, pmc=pmc))

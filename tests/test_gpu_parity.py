@@ -185,11 +185,17 @@ def _golden_algo_order(name):
     return [x.strip("' ") for x in m.group(1).strip('[]').split(',')]
 
 
-@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'] + T3_VIB)
-def test_t3_injected_noise_vs_reference(ctx, name):
+@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'] + T3_VIB +
+                         [n + ':plain' for n in T3_VIB])
+def test_t3_injected_noise_vs_reference(ctx, name, monkeypatch):
     """Unmodified reference Sim.run(R) fed the engine's Philox normals == fused kernel, per sample.  T3_VIB: the reference ran
-    with Sim(env=...) -- random / sinusoidal vibration on either sensor (pathgen.py:476-492, 538-556)."""
+    with Sim(env=...) -- random / sinusoidal vibration on either sensor (pathgen.py:476-492, 538-556); both kernels that carry the
+    term are held to it: the wave-specialised one a single free integration of a small batch runs on (round 5) and, ':plain', the
+    vibration variant of the plain kernel (GINSIM_SPLIT_VIB=0)."""
     import ginsim
+    name, _, plain = name.partition(':')
+    if plain:
+        monkeypatch.setenv('GINSIM_SPLIT_VIB', '0')
     g = load_golden(name)
     R, k, fs, rf = int(g['R']), g['rows'], float(g['fs']), int(g['ref_frame'])
     acc_err, gyr_err = _errs(g)
@@ -204,7 +210,8 @@ def test_t3_injected_noise_vs_reference(ctx, name):
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc_err, gyr_err, g['ini'], runs=R, algos=algos, odo_err=odo_err,
                                seed=int(g['seed']), keep_sensors=True, keep_traj=True, vib_accel=vib_acc, vib_gyro=vib_gyro).run()
     if name in T3_VIB:
-        assert job.kernel_name().endswith(', true>') and job.kernel_name().startswith('ginsim::mc_kernel<'), job.kernel_name()
+        split = not plain and algos == ('free',)
+        assert job.kernel_name().endswith(', true>') and job.kernel_name().startswith('ginsim::mc_kernel_split<' if split else 'ginsim::mc_kernel<'), job.kernel_name()
     runs = np.arange(R)
     np.testing.assert_allclose(job.sensors('accel', runs)[:, k], g['accel'], rtol=0, atol=1e-12)
     np.testing.assert_allclose(job.sensors('gyro', runs)[:, k], g['gyro'], rtol=0, atol=1e-14)
