@@ -779,7 +779,7 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
             if constexpr (ALGOS == GINSIM_ALGO_FREE && RF == 0) {     // nothing kept: two producer groups fit here too
                 const bool keep = p.out_accel || p.out_gyro || p.out_odo || p.out_traj[0] || p.out_traj[1];
                 if (!keep && prod != 1) {
-                    GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, 2, false>", RF, ALGOS, tf(WD))
+                    GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, 2, false, false>", RF, ALGOS, tf(WD))
                     static PerDeviceOnce once2;
                     once2.run([] {
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 2, false>),
@@ -790,7 +790,7 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
                 }
             }
             const bool two = prod == PROD && PROD > 1;
-            GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, %d, true>", RF, ALGOS, tf(WD), two ? PROD : 1)
+            GINSIM_NAME_OR("ginsim::mc_kernel_split<%d, %d, %s, %d, true, false>", RF, ALGOS, tf(WD), two ? PROD : 1)
             static PerDeviceOnce once;
             once.run([] {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mc_kernel_split<RF, ALGOS, WD, 1>),

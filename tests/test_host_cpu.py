@@ -445,7 +445,7 @@ def test_dispatch_queries_and_sensor_layout_rules_without_a_gpu():
         _lib.check(_lib.lib.ginsim_mc_kernel_name(C.byref(p), buf, 256))
         return v.value, buf.value.decode()
 
-    assert query(params()) == (1, 'ginsim::mc_kernel_split<1, 1, false, 2, true>')                    # C2: the wave-specialised kernel
+    assert query(params()) == (1, 'ginsim::mc_kernel_split<1, 1, false, 2, true, false>')                    # C2: the wave-specialised kernel
     assert query(params(given_sensors=1, in_gyro=4096, in_accel=4096)) == (0, 'ginsim::mc_kernel<1, 1, true, false, 0, false>')
     assert query(params(precision=1))[1].startswith('ginsim::f32::mc_kernel_f32_split<1, 1, false, 3,')
     # sensors only, few runs, long series: the time-parallel kernels -- with the series-major layout, or with one run (same thing)
@@ -541,3 +541,48 @@ def test_unconfigured_sim_spreads_large_batches_over_every_gpu(monkeypatch):
     assert mk(devices=[1, 1])._context(small).devices == [1, 1]            # the argument wins over the environment
     with pytest.raises(ValueError, match='not both'):
         mk(devices=[0], device=0)._context(small)
+
+
+def test_reported_kernel_names_are_the_compiled_kernels():
+    """ginsim_mc_kernel_name is what the bench and the profiles use to find a launch's counters in rocprofv3's output, so the name it
+    reports must be the (demangled) name of a kernel the library really contains -- a template parameter added to a kernel without its
+    name string silently detaches the PMC traffic from the roofline (round 5: `traffic: null` in one bench run)."""
+    import ctypes as C
+    import shutil
+    import ginsim
+    from ginsim import _lib
+    if not shutil.which('c++filt'):
+        pytest.skip('no c++filt to demangle the build\'s kernel list')
+    mangled = []
+    for fn in ('mc_kernel', 'mc_kernel_f32'):
+        for line in open(os.path.join(PKG, 'build', fn + '.resources.txt')):
+            if line.startswith('Function Name:'):
+                mangled.append(line.split(':', 1)[1].strip())
+    out = subprocess.run(['c++filt'], input='\n'.join(mangled), stdout=subprocess.PIPE, universal_newlines=True, check=True).stdout
+    compiled = {re.sub(r'\(.*$', '', l.replace('void ', '')).strip() for l in out.splitlines()}
+
+    def name(**kw):
+        p = _lib.McParams()
+        p.n, p.runs, p.fs, p.ref_frame, p.algo_mask, p.n_ini = 1000, 65536, 100.0, 1, 1, 1
+        for k in ('ini', 'ref_accel', 'ref_gyro', 'out_accel', 'out_gyro', 'ref_odo', 'ref_nav'):
+            setattr(p, k, 4096)
+        p.out_traj[0] = 4096
+        for k, v in kw.items():
+            setattr(p, k, v)
+        buf = C.create_string_buffer(256)
+        _lib.check(_lib.lib.ginsim_mc_kernel_name(C.byref(p), buf, 256))
+        return buf.value.decode()
+
+    v = ginsim.vibration({'type': 'random', 'x': 0.1, 'y': 0.1, 'z': 0.1}, 100.0, False)
+    none = C.c_void_p * 2
+    cases = [dict(), dict(ref_frame=0), dict(runs=262144), dict(precision=1), dict(precision=1, runs=262144), dict(algo_mask=3),
+             dict(algo_mask=2), dict(given_sensors=1, in_gyro=4096, in_accel=4096), dict(vib_accel=v), dict(vib_accel=v, runs=262144),
+             dict(vib_accel=v, ref_frame=0), dict(out_accel=None, out_gyro=None, out_traj=none(None, None)),
+             dict(ref_frame=0, out_accel=None, out_gyro=None, out_traj=none(None, None)),
+             dict(ref_frame=0, runs=262144, out_accel=None, out_gyro=None, out_traj=none(None, None), out_proc=none(4096, None)),
+             dict(ref_frame=0, runs=262144, out_accel=None, out_gyro=None, out_traj=none(None, None), out_proc=none(4096, None), proc_pos_ned=1),
+             dict(out_accel=None, out_gyro=None, out_traj=none(None, None), out_proc=none(4096, None)),
+             dict(precision=1, out_accel=None, out_gyro=None, out_traj=none(None, None))]
+    for kw in cases:
+        k = name(**kw)
+        assert k in compiled, 'ginsim_mc_kernel_name reports %r for %r, which is not a compiled kernel' % (k, kw)
