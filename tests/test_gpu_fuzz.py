@@ -2,7 +2,8 @@
 the pitch fold and the +-2 pi wraps of attitude.euler_update_zyx are exercised), random IMU error models (finite / infinite
 correlation times, constant biases, zero axes), random vibration environments, both frames, every algorithm set, ragged run
 counts, 64-bit run offsets -- device against the C restatement (oracle/c/ginsim_oracle.c) and against itself under sharding
-(fp64: to 1e-8 up to the Euler singularity, see the comment in the test; fp32: bit for bit, singularity or not).
+(fp64: to SURVEY 8(c)'s 1e-9 for runs that stay away from the Euler singularity, 1e-8 up to it for those that approach it, see the
+comment in the test; fp32: bit for bit, singularity or not).
 The truth comes from the native path generator (pinned against the reference by tests/test_host_cpu.py); sizes are small, the
 whole file takes seconds."""
 import numpy as np
@@ -75,6 +76,9 @@ def _random_case(i):
                 off=int(rng.choice([0, 12345, 2 ** 40 + 17])), seed=int(rng.randint(0, 2 ** 62)), earth_rot=bool(rng.randint(0, 2)))
 
 
+_WORST = {}
+
+
 @pytest.mark.parametrize('i', range(40))
 def test_random_configuration_against_the_c_oracle(ctx, i):
     import ginsim
@@ -97,17 +101,25 @@ def test_random_configuration_against_the_c_oracle(ctx, i):
         # singularity amplifies rounding differences without bound (the NumPy and the C restatement then differ from EACH OTHER:
         # 5e-4 rad in case 23, min |cos pitch| 8e-5) and may take the pitch fold on one side only.  Such a run is compared up to
         # the sample where |cos pitch| first drops below 0.02; what follows is as (in)accurate in every implementation.
-        tol = 1e-8 * max(1.0, n / 1000.0)
+        # Tolerance: SURVEY 8(c)'s 1e-9 max(1, |x|) per 1000 steps for a run that stays away from the singularity (|cos pitch| >= 0.2
+        # over the compared samples: the division amplifies rounding by at most 5 per step there); 1e-8 for one that comes closer.
         for r in range(keep):
             near = np.where(np.abs(np.cos(traj[r, :, 1])) < 0.02)[0]
             upto = int(near[0]) if near.size else n
             if upto < 2:
                 continue
+            benign = np.abs(np.cos(traj[r, :upto, 1])).min() >= 0.2
+            tol = (1e-9 if benign else 1e-8) * max(1.0, n / 1000.0)
             d = np.mod(att[r, :upto] - traj[r, :upto, 0:3] + np.pi, 2 * np.pi) - np.pi
             assert np.abs(d).max() < tol, 'case %d %s run %d attitude %.3e (compared %d of %d samples)' % (i, a, r, np.abs(d).max(), upto, n)
             scale = np.maximum(1.0, np.abs(traj[r, :upto, 3:9]))
             err = np.abs(np.concatenate([pos[r, :upto], vel[r, :upto]], axis=1) - traj[r, :upto, 3:9]) / scale
             assert err.max() < tol, 'case %d %s run %d pos/vel %.3e (compared %d of %d samples)' % (i, a, r, err.max(), upto, n)
+            key = 'benign' if benign else 'near_singular'
+            _WORST[key] = max(_WORST.get(key, 0.0), float(max(np.abs(d).max(), err.max()) / max(1.0, n / 1000.0)))
+            _WORST['runs_' + key] = _WORST.get('runs_' + key, 0) + 1
+        from test_gpu_full_size import _record
+        _record('fuzz_fp64_vs_c_oracle_per_1000_steps', **_WORST)
     # sharding: the same global runs as two launches, nothing kept -> the same end-point errors to the bit
     if R >= 2:
         cut = R // 3 + 1
