@@ -258,12 +258,13 @@ def pmc_traffic_file(build):
 
 
 # --------------------------------------------------------------------------------------------- legs (N = 1)
-def leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, reps=10):
+def leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, reps=10, place=False):
     """FreeIntegration.run alone for the whole batch: the given-sensors kernel reads the accel/gyro series the last step
     materialised (48 B) and writes att/pos/vel (72 B) per sample*MC -- the HBM-bound piece of the path."""
     rep = ginsim.MonteCarloJob(ctx, fs, rf, truth, None, None, ini, runs=R, keep_traj=True,
                                given={'gyro': job.buffer('gyro'), 'accel': job.buffer('accel')})
     rep.run()
+    placed = rep.spread_outputs() if place else None
     avg, mn = time_launches(ctx, rep.launch, reps)
     same = bool((rep.end_errors('free') == job.end_errors('free')).all())
     name = rep.kernel_name()
@@ -273,7 +274,7 @@ def leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, reps=
             '(%d runs x %d samples; 48 B read + 72 B written per sample*MC)' % (R, n), 'dtype': 'f64',
             'sample_MC_per_s': R * n / avg * 1e3, 'kernel_ms_min': mn,
             'roofline': roofline(b, avg, name, (traffic or {}).get(name, {}).get('hbm_bytes_per_launch')),
-            'bit_identical_to_fused_kernel': same}
+            'bit_identical_to_fused_kernel': same, 'placement': placed}
 
 
 PMC_CUT_SAMPLES = 8192      # the C3-shaped launches of the --pmc-child workload are cut to this many samples
@@ -286,7 +287,7 @@ def cut_truth(truth, n):
 
 
 def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precision, reps, gps=False, pmc=None, traffic=None,
-           cut=None, valu_too=False, **job_kw):
+           cut=None, valu_too=False, place=False, **job_kw):
     ini, truth, _ = workloads.truth_from_profile(profile, fs, rf, fs_gps=10.0 if gps else 0.0, gps=gps)
     if cut:
         truth = cut_truth(truth, cut)
@@ -295,6 +296,7 @@ def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precisi
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, seed=SEED, keep_sensors=keep, keep_traj=keep,
                                precision=precision, **job_kw)
     job.run()
+    placed = job.spread_outputs() if (place and keep) else None
     avg, mn = time_launches(ctx, job.launch, reps, warm=2 if reps > 2 else 0)
     st = job.stats('free')
     unit = (BYTES_PER_SAMPLE_MC if precision == 'f64' else BYTES_PER_SAMPLE_MC // 2) if keep else 0
@@ -320,6 +322,8 @@ def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precisi
            'sample_MC_per_s': R * n / avg * 1e3, 'kernel_ms_min': mn,
            'roofline': roof,
            'result': {'att_std_deg': (st.std[:3] * 57.29577951308232).tolist(), 'vel_std_mps': st.std[6:9].tolist(), 'runs': st.count}}
+    if placed is not None:
+        out['placement'] = placed
     job.release()
     return out
 
@@ -494,6 +498,9 @@ def main():
     ap.add_argument('--precision', choices=['f64', 'f32'], default='f64', help="f32 = BASELINE config 5's single-precision kernel")
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
     ap.add_argument('--no-legs', action='store_true', help='skip the configs[] legs (C3, C4 share, C5, Allan, mechanisation)')
+    ap.add_argument('--placement', choices=['spread', 'asis'], default='spread',
+                    help="spread: MonteCarloJob.spread_outputs() before anything is timed (the output planes in two of the device "
+                         "memory's three 96 GB thirds, found by timing); asis: wherever hipMalloc put them")
     ap.add_argument('--no-repeat', action='store_true', help='N = 1: do not time the K steps a second time (headline_again)')
     ap.add_argument('--pmc', choices=['live', 'file', 'off'], default='live',
                     help='roofline.traffic: rocprofv3 PMC passes of this build (live), the stamped profiles/pmc_traffic.json, or null')
@@ -553,6 +560,9 @@ def main():
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, algos=('free',), seed=SEED,
                                keep_sensors=keep, keep_traj=keep, precision=args.precision)
     unit_bytes = BYTES_PER_SAMPLE_MC if args.precision == 'f64' else BYTES_PER_SAMPLE_MC // 2
+    placement = None
+    if keep and args.placement == 'spread' and not args.pmc_child:
+        placement = job.spread_outputs()            # set-up, like the warm-up: nothing of it is inside the timed region
     group = dist.group.WORLD if use_dist else None
     device = torch.device('cuda', local_rank) if args.backend == 'nccl' else torch.device('cpu')
     nsteps = args.warmup + args.steps
@@ -798,6 +808,10 @@ def main():
             'result': {'att_std_deg': (merged.std[:3] * r2d).tolist(), 'vel_std_mps': merged.std[6:9].tolist(),
                        'runs': merged.count},
         }
+        if placement is not None:
+            out['config']['placement'] = dict(placement, note='MonteCarloJob.spread_outputs() before the warm-up: the launch is ~8 % '
+                                              'slower when all 15 output planes lie in ONE of the three 96 GB thirds of the device memory '
+                                              '(profiles/r05_hbm_thirds.json); --placement asis times them where hipMalloc put them')
         if again is not None:
             out['headline_again'] = again
             out['roofline']['frac_again'] = alg_bytes / (again['kernel_ms_avg'] * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -809,13 +823,15 @@ def main():
             out['per_rank'] = per_rank
         if world == 1 and not args.no_legs:
             legs = []
+            place = args.placement == 'spread'
+
             if keep and args.precision == 'f64':
-                legs.append(leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic))
+                legs.append(leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, place=place))
                 out['mechanisation_only'] = legs[-1]
             job.release()
             job = None
             legs.append(leg_mc(ginsim, workloads, ctx, 'C4_per_gpu_share', 'BASELINE configs[3] per-GPU share: turn_90deg @100 Hz, '
-                               '131 072 runs, fp64, materialised', 'turn_90deg', 100.0, 1, 131072, True, 'f64', 10))
+                               '131 072 runs, fp64, materialised', 'turn_90deg', 100.0, 1, 131072, True, 'f64', 10, place=place))
             c3 = dict(pmc=pmc)
             legs.append(leg_mc(ginsim, workloads, ctx, 'C3', 'BASELINE configs[2]: long_drive @200 Hz (n = 193 036), ref_frame 0, 262 144 '
                                'runs, fp64; trajectories would be 6 TB, so the kernel accumulates the per-run process-error statistics '
@@ -825,14 +841,14 @@ def main():
             legs.append(leg_mc(ginsim, workloads, ctx, 'C3_end_point_only', 'the same launch with end-point statistics only (r01 form)',
                                'long_drive', 200.0, 0, 262144, False, 'f64', 2, gps=True, **c3))
             legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32', 'BASELINE configs[4]: fp32 kernel on the C2 workload, 65 536 runs, '
-                               'materialised (60 B/sample*MC)', 'turn_90deg', 100.0, 1, 65536, True, 'f32', 20, traffic=traffic))
+                               'materialised (60 B/sample*MC)', 'turn_90deg', 100.0, 1, 65536, True, 'f32', 20, traffic=traffic, place=place))
             legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32_262144', 'fp32 kernel, 262 144 runs, materialised', 'turn_90deg', 100.0, 1,
-                               262144, True, 'f32', 10))
+                               262144, True, 'f32', 10, place=place))
             # Sim(env=...) (beyond BASELINE's configurations, all of which use env=None): the C2 launch in a vibration environment
             legs.append(leg_mc(ginsim, workloads, ctx, 'C2_vibration_random', 'the C2 launch with Sim(env={acc: [0.03 0.03 0.03]g-random, '
                                'gyro: [0.5 0.5 0.5]d-random}): the vibration variant of the wave-specialised kernel (round 5; round 4: the plain kernel, one wavefront per SIMD)', 'turn_90deg',
                                100.0, 1, 65536, True, 'f64', 10,
-                               pmc=pmc, valu_too=True, **VIB_LEG))
+                               pmc=pmc, valu_too=True, place=place, **VIB_LEG))
             legs.append(leg_allan(ginsim, workloads, ctx, pmc=pmc))
             legs.append(leg_sim_e2e(workloads))
             out['configs'] = legs

@@ -42,21 +42,33 @@ struct MathConsts {
     }
 };
 
-// The normal generator's coefficient table (fp32, 3968 B), copied into LDS by every workgroup from the committed constants:
+// The normal generator's coefficient table (fp32, 3968 B of committed constants), copied into LDS by every workgroup:
 //   q[seg] = {c0, c1, c2, c3}, seg = (lz - 1) 8 + sub: the cubic that inverts the upper tail probability on the sub-th
 //            eighth of the octave [2^-(lz+1), 2^-lz) of t (tools/gen_normal_tables.py says how it was fitted).
+// In LDS the eight cubics of octave lz sit in the UPPER half of the 256-byte block lz (8 KB in all, half of it unused), so
+// that the byte offset of a segment is the top of the 64-bit value {lz, y} -- (lz << 8) | (y >> 24), one v_alignbit_b32 --
+// with its low four bits cleared: bit 7 of y >> 24 is the leading one of the shifted magnitude (the upper half), bits 6..4
+// are the eighth.  Two instructions per normal instead of three (shift, shift, and-or) with the dense table of round 2.
 constexpr int kNormalOctaves = 31, kNormalSubs = 8;
-constexpr int kNormalTableWords = 4 * kNormalOctaves * kNormalSubs;
+constexpr int kNormalTableWords = 4 * kNormalOctaves * kNormalSubs;         // the committed constants
+constexpr int kNormalLdsWords = 64 * (kNormalOctaves + 1);                   // their copy in LDS: blocks 0 .. 31 of 256 bytes
 static __device__ const uint32_t kNormalTableBits[kNormalTableWords] = {
 #include "normal_tables.inc"
 };
 struct NormalTables {
-    const float4* q;
+    const char* base;
 };
 
 GINSIM_FM NormalTables fill_normal_tables(uint32_t* lds, int tid, int nthreads) {
-    for (int k = tid; k < kNormalTableWords; k += nthreads) lds[k] = kNormalTableBits[k];
-    return NormalTables{reinterpret_cast<const float4*>(lds)};
+    for (int k = tid; k < kNormalTableWords; k += nthreads) lds[((k >> 5) + 1) * 64 + 32 + (k & 31)] = kNormalTableBits[k];
+    return NormalTables{reinterpret_cast<const char*>(lds)};
+}
+
+// (z & 0x7fffffff) | (w & 0x80000000) in one v_bfi_b32 (the compiler emits v_and_b32 + v_and_or_b32 for the expression)
+GINSIM_FM float with_sign_of(float z, uint32_t w) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0x7fffffffu), "v"(z), "v"(w));
+    return __uint_as_float(r);
 }
 
 // One standard normal from ONE 32-bit word by inversion, DEFINED operation by operation (the oracles repeat it to the bit:
@@ -73,10 +85,10 @@ GINSIM_FM float normal_icdf(uint32_t w, const NormalTables& tab) {
     const uint32_t m = (w & 0x7fffffffu) | 1u;
     const int lz = __builtin_clz(m);                                    // 1 .. 31
     const uint32_t y = m << lz;
-    const float4 c = tab.q[(lz - 1) * kNormalSubs + (int)((y >> 28) & 7u)];
+    const float4 c = *reinterpret_cast<const float4*>(tab.base + (__builtin_amdgcn_alignbit((uint32_t)lz, y, 24) & ~15u));
     const float x = __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, y << 4, 9));      // 0x3f800000 | ((y << 4) >> 9)
     const float z = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c.w, x, c.z), x, c.y), x, c.x);
-    return __uint_as_float((__float_as_uint(z) & 0x7fffffffu) | (w & 0x80000000u));
+    return with_sign_of(z, w);
 }
 
 // 1/x to ~1 ulp: hardware v_rcp_f64 estimate + two Newton steps.

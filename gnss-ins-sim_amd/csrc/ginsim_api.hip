@@ -196,7 +196,10 @@ int ginsim_device_name(ginsim_ctx* c, char* buf, size_t cap) {
 int ginsim_malloc(ginsim_ctx* c, size_t bytes, void** dptr) {
     REQUIRE(c && dptr, "malloc: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 8));
+    const char* e = getenv("GINSIM_MALLOC_FLAGS");          // experiment (tools/exp_r05p.sh)
+    const unsigned flags = e ? (unsigned)atoi(e) : 0u;
+    if (flags) HIP_TRY(hipExtMallocWithFlags(dptr, bytes ? bytes : 8, flags));
+    else HIP_TRY(hipMalloc(dptr, bytes ? bytes : 8));
     return GINSIM_OK;
 }
 

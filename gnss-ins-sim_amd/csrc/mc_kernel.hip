@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "ginsim.h"
 #include "ins_math.hpp"
 #include "philox.hpp"
@@ -391,7 +392,7 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
         trace[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
         trace[2] = __builtin_amdgcn_s_memtime();
     }
-    __shared__ uint32_t ntab[GIVEN ? 4 : kNormalTableWords];
+    __shared__ uint32_t ntab[GIVEN ? 4 : kNormalLdsWords];
     NormalTables tab{};
     if (!GIVEN) {
         tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
@@ -574,7 +575,7 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_split(const ginsim
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
     MathConsts mk;
     mk.init<(ALGOS != (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO))>();     // the two-algorithm consumer would spill
-    __shared__ uint32_t ntab[kNormalTableWords];
+    __shared__ uint32_t ntab[kNormalLdsWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
 
@@ -874,17 +875,20 @@ hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream, char* name, 
 // ---------------------------------------------------------------------------------------------------
 // Sensor series for FEW runs (Sim.run(1) as a data generator, the Allan flow of BASELINE config 5): with one lane per
 // run the time loop of mc_kernel is a single sequential chain (n = 1 440 000 samples -> 2.8 s on one lane), and there are
-// no runs to fill the chip with.  Here the TIME axis is the parallel one: a lane is a SAMPLE, a wavefront covers 64
-// consecutive samples of one run per step and walks a chunk of L samples, so
+// no runs to fill the chip with.  Here the TIME axis is the parallel one: a lane holds TWO CONSECUTIVE samples (kSpan), a
+// wavefront covers 128 consecutive samples of one run per step and walks a chunk of L samples, so
 //   * the Philox counter (sample, block, run) makes the twelve normals of a sample a per-lane computation;
-//   * every store instruction of a wavefront writes 512 contiguous bytes of ONE series -- in the series-major layout
+//   * a lane writes 16 contiguous bytes of ONE series per step, a wavefront 1 KB -- in the series-major layout
 //     [run][axis][n] (sensor_layout 1), which is what ginsim_allan reads: the Allan flow needs no re-layout;
 //   * the one sequential thing, the Gauss-Markov recurrence d[j+1] = a d[j] + b w[j] (pathgen.py:583-590), is linear:
-//     inside a wavefront it is a weighted inclusive scan over the lanes (Hillis-Steele in DPP: row_shr 1/2/4/8 with the
-//     wave-uniform weights a^1, a^2, a^4, a^8, then row_bcast:15 / :31 with the per-lane weights a^(p+1)), the carry of
-//     the previous 64 samples enters at lane 0, and across chunks it is three launches:
+//     inside a lane it is evaluated as written, across the lanes of a step it is a weighted inclusive scan of the lanes'
+//     two-sample sums with ratio a^2 (Hillis-Steele in DPP: row_shr 1/2/4/8 with the wave-uniform weights a^2, a^4, a^8,
+//     a^16, then row_bcast:15 / :31 with the per-lane weights), ONE scan per 128 samples and axis (round 4 had a lane = a
+//     sample and scanned every 64: 166 of the 560 vector instructions of a step went into it; the kernels are bound by
+//     instruction issue, 1.24 ns per instruction and wave-step in either form), the carry of the previous 128 samples enters
+//     at lane 0, and across chunks it is three launches:
 //       pass A  chunk-end value of every chunk integrated from zero (drift normals only; a lane accumulates its
-//               samples j, j+64, ... with weight a^64, one weighted wave reduction at the end of the chunk)
+//               steps with weight a^128, one weighted wave reduction at the end of the chunk)
 //       pass S  chunk-end values -> chunk-START values, start[k+1] = a^L start[k] + end[k]: the same scan, one
 //               wavefront per (run, axis)
 //       pass B  regenerates the normals (counter-based RNG: no state to carry) and emits
@@ -902,13 +906,13 @@ struct SeriesPlan {
     double* carry;          // [runs][nchunks][6]: pass A chunk-end values, pass S overwrites them with chunk-start values
     double a_pow[6];        // gm_a ^ L for accel xyz, gyro xyz
     int64_t nchunks;
-    int64_t sr, sc, sj;     // element (run r, axis c, sample j) of a 3-axis sensor lives at r sr + c sc + j sj
-    int64_t odo_sr, odo_sj; // and of the odometer at r odo_sr + j odo_sj
-    int32_t L;              // samples per chunk, a multiple of 64
+    int64_t sr, sc;         // element (run r, axis c, sample j) of a 3-axis sensor lives at r sr + c sc + j
+    int64_t odo_sr;         // and of the odometer at r odo_sr + j
+    int32_t L;              // samples per chunk, a multiple of 64 kSpan (one step of a wavefront)
     int32_t pad;
-    ScanQ   qa[6];          // powers of gm_a (the scans inside a chunk)
+    ScanQ   qs[6];          // powers of gm_a ^ kSpan (the scan over the lanes of a step: a lane holds kSpan consecutive samples)
     ScanQ   qL[6];          // powers of gm_a ^ L (pass S)
-    double  a64[6];         // gm_a ^ 64 (pass A)
+    double  a_step[6];      // gm_a ^ (64 kSpan) (pass A: the same lane, one step later)
 };
 typedef const SeriesPlan __attribute__((address_space(4))) * plan_ptr;
 // the plan is the second kernel argument: it follows the parameter block in the kernarg segment
@@ -974,12 +978,28 @@ static void scanq_host(double q, ScanQ* out) {
 }
 
 constexpr int kSeriesBlock = 256;       // four wavefronts = four chunks per workgroup
+// Samples per lane: measured on config 5 (32 x 1 440 000; pass B alone, rocprofv3): 1 -> 601 us, 2 -> 516 us, 4 -> 673 us.  Four halve
+// the scan's share again (335 vector instructions per 64 samples against 410) but need 168 registers (three wavefronts per
+// SIMD) and read the truth rows with 96-byte lane strides: 48 cache lines per load instruction.
+constexpr int kSpan = 2;                // consecutive samples of a lane
+constexpr int kSeriesWaves = 4;         // wavefronts per SIMD the register allocator is held to (128 registers; the vibration
+                                        // variant, with its sines: three)
+constexpr int kGroup = 64 * kSpan;      // samples of one step of a wavefront
+
+// the consecutive doubles of a lane in one series: 16-byte streaming stores (a series starts on an 8-byte boundary only)
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef f64x2 f64x2_a8 __attribute__((aligned(8)));
+__device__ __forceinline__ void st_span(double* p, const double (&v)[kSpan]) {
+    if (kSpan == 1) st(p, v[0]);
+#pragma unroll
+    for (int i = 0; i + 1 < kSpan; i += 2) __builtin_nontemporal_store(f64x2{v[i], v[i + 1]}, reinterpret_cast<f64x2_a8*>(p + i));
+}
 
 // PASS 0: pass A; 1: pass B; 2: pass B with the vibration term of Sim(env=...) (a per-sample term: nothing to scan)
 template <int PASS>
-__global__ void __launch_bounds__(kSeriesBlock) series_kernel(const ginsim_mc_params a, const SeriesPlan pl) {
+__global__ void __launch_bounds__(kSeriesBlock, PASS == 2 ? kSeriesWaves - 1 : kSeriesWaves) series_kernel(const ginsim_mc_params a, const SeriesPlan pl) {
     constexpr bool VIB = PASS == 2;
-    __shared__ uint32_t ntab[kNormalTableWords];
+    __shared__ uint32_t ntab[kNormalLdsWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
 
@@ -1000,29 +1020,37 @@ __global__ void __launch_bounds__(kSeriesBlock) series_kernel(const ginsim_mc_pa
         ga[3 + k] = kp->gyro.gm_a[k]; gb[3 + k] = kp->gyro.gm_b[k];
     }
     const plan_ptr kq = kernarg_plan(sizeof(ginsim_mc_params));
-    ScanWeights sw[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) sw[k].init(&kq->qa[k], lane);
-
     if (PASS == 0) {
-        // chunk-end value from zero: lane l folds its samples j0 + l, j0 + 64 + l, ... with weight a^64, then one scan
+        // chunk-end value from zero: a lane folds its samples of every step (weight a), its steps with weight a^(64 kSpan),
+        // then one scan over the lanes
         double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int64_t jb = j0; jb < j1; jb += 64) {
-            const int64_t j = jb + lane;
-            const bool on = j < j1;
-            double z0[6], z1[6];
-            normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)(on ? j : j1 - 1), z0, z1, tab);
-            const double zd[6] = {z0[0], z1[0], z0[1], z0[3], z1[3], z0[4]};
+        for (int64_t jg = j0; jg < j1; jg += kGroup) {
+            double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < 6; ++k) acc[k] = __builtin_fma(kernarg_plan(sizeof(ginsim_mc_params))->a64[k], acc[k], on ? gb[k] * zd[k] : 0.0);
+            for (int i = 0; i < kSpan; ++i) {
+                const int64_t j = jg + kSpan * lane + i;
+                const bool on = j < j1;
+                double z0[6], z1[6];
+                normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)(on ? j : j1 - 1), z0, z1, tab);
+                const double zd[6] = {z0[0], z1[0], z0[1], z0[3], z1[3], z0[4]};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) e[k] = __builtin_fma(ga[k], e[k], on ? gb[k] * zd[k] : 0.0);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] = __builtin_fma(kernarg_plan(sizeof(ginsim_mc_params))->a_step[k], acc[k], e[k]);
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const double e = sw[k].inclusive(acc[k], &kq->qa[k]);
+            ScanWeights sw;                     // of the scan over the LANES: ratio a^kSpan
+            sw.init(&kq->qs[k], lane);
+            const double e = sw.inclusive(acc[k], &kq->qs[k]);
             if (lane == 63) cb[k] = e;
         }
         return;
     }
+    ScanWeights sw[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sw[k].init(&kq->qs[k], lane);
 
     // ---- pass B
     const model_ptr ma = &kp->accel, mg = &kp->gyro;
@@ -1037,50 +1065,97 @@ __global__ void __launch_bounds__(kSeriesBlock) series_kernel(const ginsim_mc_pa
         vpa = vibration_phase<S_ACC_VIB_PHASE>(&kp->vib_accel, key);
         vpg = vibration_phase<S_GYR_VIB_PHASE>(&kp->vib_gyro, key);
     }
-    for (int64_t jb = j0; jb < j1; jb += 64) {
-        const int64_t j = jb + lane;
-        const bool on = j < j1;
-        const int64_t jc = on ? j : j1 - 1;
-        const Vec3 ta{a.ref_accel[3 * jc], a.ref_accel[3 * jc + 1], a.ref_accel[3 * jc + 2]};
-        const Vec3 tg{a.ref_gyro[3 * jc], a.ref_gyro[3 * jc + 1], a.ref_gyro[3 * jc + 2]};
-        double z0[6], z1[6];
-        normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)jc, z0, z1, tab);
-        const double zd[6] = {z0[0], z1[0], z0[1], z0[3], z1[3], z0[4]};
-        const double zw[6] = {z1[1], z0[2], z1[2], z1[4], z0[5], z1[5]};
-        double bx[6], d[6];
+    // one step = 64 kSpan consecutive samples; FULL: all of them inside the series (every step but the last of a ragged series).
+    // The words of the three Philox blocks of the lane's samples first (12 registers each), then one sensor after the other:
+    // transform, recurrence, sums, stores -- the scheduling barriers keep the two sensors' working sets apart.
+    auto step = [&](const int64_t jg, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int64_t jl = jg + kSpan * lane;
+        bool on[kSpan];
+        uint32_t wa[kSpan][6], wb[kSpan][6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            bx[k] = gb[k] * zd[k];
-            double u = on ? bx[k] : 0.0;
-            u = lane == 0 ? __builtin_fma(ga[k], carry[k], bx[k]) : u;     // the drift at the step's first sample enters here
-            const double e = sw[k].inclusive(u, &kernarg_plan(sizeof(ginsim_mc_params))->qa[k]);     // e[l] = drift at sample j + 1
-            d[k] = wave_shift_up(e, carry[k]);                             // drift at sample j
-            carry[k] = wave_lane63(e);
+        for (int i = 0; i < kSpan; ++i) {
+            const int64_t j = jl + i;
+            on[i] = FULL || j < j1;
+            draw_streams<S_ACC_D_XY, 6>(key, (uint32_t)(on[i] ? j : j1 - 1), wa[i], wb[i]);
         }
-        if (on) {
-            // the sums of sense3 (pathgen.py:500, 562), same order of operations
-            double o[6];
+        __builtin_amdgcn_sched_barrier(0);
+        auto sensor = [&](auto sensor_tag) {
+            constexpr int S = decltype(sensor_tag)::value;          // 0: accelerometer (streams 0..2), 1: gyroscope (3..5)
+            const model_ptr m = S ? mg : ma;
+            const double* const truth = S ? a.ref_gyro : a.ref_accel;
+            double* const out = S ? og : oa;
+            // the recurrence d[j+1] = a d[j] + b w[j]: inside a lane as written, across the lanes the weighted scan of the
+            // lanes' sums (ratio a^kSpan); the drift at the step's first sample enters at lane 0
+            double u[kSpan][3], d[kSpan][3], o[kSpan][3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double ua = ma->white_drift[k] ? bx[k] : d[k], ug = mg->white_drift[k] ? bx[3 + k] : d[3 + k];
-                const double tak = k == 0 ? ta.x : (k == 1 ? ta.y : ta.z), tgk = k == 0 ? tg.x : (k == 1 ? tg.y : tg.z);
-                o[k] = tak + ma->bias[k] + ua + ma->white[k] * zw[k];
-                o[3 + k] = tgk + mg->bias[k] + ug + mg->white[k] * zw[3 + k];
+                const int K = 3 * S + k;
+#pragma unroll
+                for (int i = 0; i < kSpan; ++i) {
+                    const uint32_t w = k == 0 ? wa[i][3 * S] : (k == 1 ? wb[i][3 * S] : wa[i][3 * S + 1]);
+                    u[i][k] = on[i] ? gb[K] * (double)normal_icdf(w, tab) : 0.0;
+                }
+                double e = u[0][k];
+#pragma unroll
+                for (int i = 1; i < kSpan; ++i) e = __builtin_fma(ga[K], e, u[i][k]);
+                e = lane == 0 ? __builtin_fma(kernarg_plan(sizeof(ginsim_mc_params))->qs[K].q1, carry[K], e) : e;
+                const double inc = sw[K].inclusive(e, &kernarg_plan(sizeof(ginsim_mc_params))->qs[K]);   // drift at the next lane's first sample
+                d[0][k] = wave_shift_up(inc, carry[K]);                                                    // at this lane's
+                carry[K] = wave_lane63(inc);
+#pragma unroll
+                for (int i = 1; i < kSpan; ++i) d[i][k] = __builtin_fma(ga[K], d[i - 1][k], u[i - 1][k]);
             }
-            if (VIB) {          // added last, as pathgen.py:500, 562 do
-                const Vec3 va = add_vibration<S_ACC_VIB_XY>(Vec3{o[0], o[1], o[2]}, &kernarg_params()->vib_accel, key, (uint32_t)j, tab, vpa);
-                const Vec3 vg = add_vibration<S_GYR_VIB_XY>(Vec3{o[3], o[4], o[5]}, &kernarg_params()->vib_gyro, key, (uint32_t)j, tab, vpg);
-                o[0] = va.x; o[1] = va.y; o[2] = va.z; o[3] = vg.x; o[4] = vg.y; o[5] = vg.z;
+            // the sums of sense3 (pathgen.py:500, 562), same order of operations
+#pragma unroll
+            for (int i = 0; i < kSpan; ++i) {
+                if (FULL || on[i]) {
+                    const int64_t j = jl + i;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const uint32_t w = k == 0 ? wb[i][3 * S + 1] : (k == 1 ? wa[i][3 * S + 2] : wb[i][3 * S + 2]);
+                        const double ud = m->white_drift[k] ? u[i][k] : d[i][k];
+                        o[i][k] = truth[3 * j + k] + m->bias[k] + ud + m->white[k] * (double)normal_icdf(w, tab);
+                    }
+                    if (VIB) {          // added last, as pathgen.py:500, 562 do
+                        const Vec3 v = S ? add_vibration<S_GYR_VIB_XY>(Vec3{o[i][0], o[i][1], o[i][2]}, &kernarg_params()->vib_gyro, key, (uint32_t)j, tab, vpg)
+                                         : add_vibration<S_ACC_VIB_XY>(Vec3{o[i][0], o[i][1], o[i][2]}, &kernarg_params()->vib_accel, key, (uint32_t)j, tab, vpa);
+                        o[i][0] = v.x; o[i][1] = v.y; o[i][2] = v.z;
+                    }
+                    if (!FULL && out) { st(out + j, o[i][0]); st(out + pl.sc + j, o[i][1]); st(out + 2 * pl.sc + j, o[i][2]); }
+                }
             }
-            if (oa) { st(oa + j * pl.sj, o[0]); st(oa + pl.sc + j * pl.sj, o[1]); st(oa + 2 * pl.sc + j * pl.sj, o[2]); }
-            if (og) { st(og + j * pl.sj, o[3]); st(og + pl.sc + j * pl.sj, o[4]); st(og + 2 * pl.sc + j * pl.sj, o[5]); }
-            if (oo) {
-                double y0, y1;
-                normal_pair(key, S_ODO, (uint32_t)j, y0, y1, tab);
-                st(oo + j * pl.odo_sj, kp->odo_scale * a.ref_odo[j] + kp->odo_stdv * y0);     // pathgen.py:639-640
+            if (FULL && out) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double v[kSpan];
+#pragma unroll
+                    for (int i = 0; i < kSpan; ++i) v[i] = o[i][k];
+                    st_span(out + k * pl.sc + jl, v);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        sensor(std::integral_constant<int, 0>{});
+        sensor(std::integral_constant<int, 1>{});
+        if (oo) {
+            double od[kSpan];
+#pragma unroll
+            for (int i = 0; i < kSpan; ++i) {
+                if (FULL || on[i]) {
+                    const int64_t j = jl + i;
+                    double y0, y1;
+                    normal_pair(key, S_ODO, (uint32_t)j, y0, y1, tab);
+                    od[i] = kp->odo_scale * a.ref_odo[j] + kp->odo_stdv * y0;     // pathgen.py:639-640
+                    if (!FULL) st(oo + j, od[i]);
+                }
+            }
+            if (FULL) st_span(oo + jl, od);
         }
-    }
+    };
+    int64_t jg = j0;
+    for (; jg + kGroup <= j1; jg += kGroup) step(jg, std::true_type{});
+    if (jg < j1) step(jg, std::false_type{});
 }
 
 // chunk-end values -> chunk-start values, one wavefront per (run, axis): start[0] = 0, start[k+1] = a^L start[k] + end[k]
@@ -1116,13 +1191,13 @@ bool series_path_applies(const ginsim_mc_params& p) {
 
 int64_t series_chunks(const ginsim_mc_params& p, int32_t* L_out) {
     // ~16 384 wavefronts over the chip (1024 SIMDs, several rounds of a few wavefronts each), chunks of 256 .. 8192 samples in
-    // whole wave-steps, and at most 1024 chunks per run (pass S walks them 64 at a time)
+    // whole wave-steps, and at most 1024 chunks per run where that fits (pass S walks them 64 at a time)
     int64_t L = (p.n * p.runs + 16383) / 16384;
     const int64_t lmin = (p.n + 1023) / 1024;
     if (L < lmin) L = lmin;
     if (L < 256) L = 256;
     if (L > 8192) L = 8192;
-    L = (L + 63) / 64 * 64;
+    L = (L + kGroup - 1) / kGroup * kGroup;
     *L_out = (int32_t)L;
     return (p.n + L - 1) / L;
 }
@@ -1136,13 +1211,16 @@ hipError_t launch_series(const ginsim_mc_params& p, double* carry, hipStream_t s
         double v = 1.0;
         for (int i = 0; i < pl.L; ++i) v *= aa;
         pl.a_pow[k] = v;
-        scanq_host(aa, &pl.qa[k]);
+        static_assert(kSpan == 2, "the host's powers of gm_a");
+        scanq_host(aa * aa, &pl.qs[k]);
         scanq_host(v, &pl.qL[k]);
-        pl.a64[k] = pl.qa[k].q16 * pl.qa[k].q16 * pl.qa[k].q16 * pl.qa[k].q16;
+        const double a16s = pl.qs[k].q16, a32s = a16s * a16s;     // gm_a ^ (16 span), ^ (32 span)
+        pl.a_step[k] = a32s * a32s;                                  // gm_a ^ (64 span): one step of a wavefront
     }
     pl.pad = 0;
-    if (p.sensor_layout == 1) { pl.sr = 3 * p.n; pl.sc = p.n; pl.sj = 1; pl.odo_sr = p.n; pl.odo_sj = 1; }
-    else { pl.sr = 1; pl.sc = p.n * p.runs; pl.sj = p.runs; pl.odo_sr = 1; pl.odo_sj = p.runs; }     // runs == 1: the same thing
+    // the sample index is the contiguous one in both layouts the path serves (series_path_applies: layout 1, or one run)
+    if (p.sensor_layout == 1) { pl.sr = 3 * p.n; pl.sc = p.n; pl.odo_sr = p.n; }
+    else { pl.sr = 0; pl.sc = p.n; pl.odo_sr = 0; }
     const dim3 grid((unsigned)((pl.nchunks + kSeriesBlock / 64 - 1) / (kSeriesBlock / 64)), (unsigned)p.runs), block(kSeriesBlock);
     hipLaunchKernelGGL((series_kernel<0>), grid, block, 0, stream, p, pl);
     hipLaunchKernelGGL(series_scan_kernel, dim3((unsigned)(p.runs * 6)), dim3(64), 0, stream, pl, p.runs);
@@ -1154,7 +1232,7 @@ hipError_t launch_series(const ginsim_mc_params& p, double* carry, hipStream_t s
 // ---------------------------------------------------------------------------------------------------
 // Auxiliary sensors: one thread per (sample, run), run fastest.  gps_gen: pathgen.py:621-624; mag_gen: :658-661.
 __global__ void __launch_bounds__(256) aux_gps_kernel(const ginsim_aux_params a) {
-    __shared__ uint32_t ntab[kNormalTableWords];
+    __shared__ uint32_t ntab[kNormalLdsWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
 
@@ -1174,7 +1252,7 @@ __global__ void __launch_bounds__(256) aux_gps_kernel(const ginsim_aux_params a)
 }
 
 __global__ void __launch_bounds__(256) aux_mag_kernel(const ginsim_aux_params a) {
-    __shared__ uint32_t ntab[kNormalTableWords];
+    __shared__ uint32_t ntab[kNormalLdsWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
 
@@ -1207,7 +1285,7 @@ hipError_t launch_aux(const ginsim_aux_params& p, hipStream_t s) {
 // RNG self-test: normals (and raw Philox words) of one (seed, run, stream), sample index = global lane.
 __global__ void rng_probe_kernel(uint64_t seed, uint64_t run, uint32_t stream, int64_t count,
                                  double* __restrict__ z0, double* __restrict__ z1, uint32_t* __restrict__ words) {
-    __shared__ uint32_t ntab[kNormalTableWords];
+    __shared__ uint32_t ntab[kNormalLdsWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
 
@@ -1275,7 +1353,7 @@ hipError_t launch_gather_series(const double* series, int C, int64_t n, const in
 // The normal transform on given words (test hook): words 0-1 are taken as one half block -- z0 from word 0, z1 from
 // word 1 (words 2-3 unused).
 __global__ void normal_transform_kernel(const uint32_t* __restrict__ words, int64_t count, double* __restrict__ z0, double* __restrict__ z1) {
-    __shared__ uint32_t ntab[kNormalTableWords];
+    __shared__ uint32_t ntab[kNormalLdsWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
 

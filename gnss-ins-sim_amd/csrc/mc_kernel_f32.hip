@@ -386,7 +386,7 @@ F32_FM float odo_normal(const RngKey& key, uint32_t j, const NormalTables& tab) 
 template <int RF, int ALGOS, bool GIVEN, bool WD, bool VIB = false>
 __global__ void __launch_bounds__(256, 2) mc_kernel_f32(const ginsim_mc_params a) {
     static_assert(!VIB || (!GIVEN && WD), "vibration: generate mode, general sensor model");
-    __shared__ uint32_t ntab[GIVEN ? 4 : kNormalTableWords];
+    __shared__ uint32_t ntab[GIVEN ? 4 : kNormalLdsWords];
     NormalTables tab{};
     if (!GIVEN) {
         tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(256 * (1 + PROD)) mc_kernel_f32_split(const gi
     const uint32_t ntiles = (n_noise + kSplitTileF - 1) / kSplitTileF;
     const uint64_t grun = a.run_offset + (uint64_t)r;
     const RngKey key{(uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)grun, (uint32_t)(grun >> 32)};
-    __shared__ uint32_t ntab[kNormalTableWords];
+    __shared__ uint32_t ntab[kNormalLdsWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
 #ifdef GINSIM_EXPERIMENT
@@ -781,7 +781,7 @@ static hipError_t launch3_f32(const ginsim_mc_params& p, const float* truth32, h
     }
     // exactly k workgroups per CU (k + 1 do not fit the LDS reservation)
     const int per_cu = waves <= 1024 ? 1 : (waves <= 2048 ? 2 : 3);
-    const size_t lds = (160 * 1024) / (per_cu + 1) + 1024 - sizeof(uint32_t) * kNormalTableWords;
+    const size_t lds = (160 * 1024) / (per_cu + 1) + 1024 - sizeof(uint32_t) * kNormalLdsWords;
     if constexpr (WD) {
         if (vib) {
             hipLaunchKernelGGL((f32::mc_kernel_f32<RF, ALGOS, false, true, true>), dim3((unsigned)((p.runs + tb - 1) / tb)), dim3(tb), lds, stream, p);

@@ -168,6 +168,10 @@ class JobSet(_Parts):
     def release(self):
         self._each_part(lambda j: j.release())
 
+    def spread_outputs(self, **kw):
+        """MonteCarloJob.spread_outputs on every device at the same time: the per-device reports, device order."""
+        return self._each_part(lambda j: j.spread_outputs(**kw))
+
     # ---- statistics: per-device records folded with the library's Chan merge, device order
     def _merged(self, fn):
         return StatsResult.merge([s.pack() for s in self._each_part(fn) if s is not None])

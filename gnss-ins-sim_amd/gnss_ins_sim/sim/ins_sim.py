@@ -33,6 +33,10 @@ Keyword-only extras (defaults keep the reference behaviour):
                        (sim_count x samples >= 2^30, e.g. BASELINE configs 3 and 4) and nothing says this process owns one
                        GPU only (no device=, no $LOCAL_RANK, no initialised process group) -- so that an UNCHANGED
                        demo_free_integration.py uses the whole node.
+    spread_outputs     True: before a materialising launch, look (by timing) for a placement of its output planes in the device
+                       memory that spans two of the GPU's three 96 GB thirds (ginsim.MonteCarloJob.spread_outputs: C2's launch
+                       1.33 -> 1.23 ms).  Costs a few allocations and launches, pays for a Sim whose run() repeats; default:
+                       $GINSIM_SPREAD_OUTPUTS == '1', else off.
     geo_mag_n          geomagnetic field [uT] in the N frame at the initial position, needed for a 9-axis IMU.  The
                        reference evaluates the WMM model once per run for this vector (pathgen.py:164-168,
                        date = today); that model is outside the accelerated path: either the caller supplies the vector, or
@@ -161,7 +165,7 @@ class _McResults(object):
 class Sim(object):
     def __init__(self, fs, motion_def, ref_frame=0, imu=None, mode=None, env=None, algorithm=None, *,
                  seed=None, keep_trajectories='auto', max_device_bytes=64 * 2 ** 30, device=None, geo_mag_n=None, precision='f64',
-                 keep_runs=0, stats_start=0, geo_mag_date=None, devices=None):
+                 keep_runs=0, stats_start=0, geo_mag_date=None, devices=None, spread_outputs=None):
         self.name, self.version = NAME, VERSION
         self.fs, self.imu, self.mode, self.env = fs, imu, mode, env
         self.ref_frame = ref_frame if ref_frame in (0, 1) else 0
@@ -178,6 +182,7 @@ class Sim(object):
         self.geo_mag_n, self.geo_mag_date = geo_mag_n, geo_mag_date
         self.precision = precision      # 'f32': single-precision kernel (tolerances: tests/test_gpu_fp32.py)
         self.keep_runs, self.stats_start = max(int(keep_runs), 0), stats_start
+        self.spread_outputs = (os.environ.get('GINSIM_SPREAD_OUTPUTS', '') == '1') if spread_outputs is None else bool(spread_outputs)
         self._auto_devices = False
         if devices is None and device is None:
             env = os.environ.get('GINSIM_DEVICES', '').strip()
@@ -371,6 +376,8 @@ class Sim(object):
                     group_of[i] = g
                 if keep:
                     job = make_job(g, g['kinds'], count, sensor_job is None, True)
+                    if self.spread_outputs:
+                        job.spread_outputs()
                     job.launch()
                     sensor_job = sensor_job or job
                     for i in g['idx']:
