@@ -650,7 +650,10 @@ class MonteCarloJob(object):
         for t in range(int(tries)):
             if (t + 1) * size > min(max_hold, free_now // 2):
                 break
-            cand = DeviceBuffer(self.ctx, size)
+            try:
+                cand = DeviceBuffer(self.ctx, size)
+            except RuntimeError:                # out of memory (another process took it meanwhile): keep what we have
+                break
             if layout is not None:
                 cand.layout = layout
             bind(cand)
