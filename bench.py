@@ -328,14 +328,15 @@ def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precisi
     return out
 
 
-def sensor_generation_roofline(pmc, runs, n, gen_ms):
+def sensor_generation_roofline(pmc, runs, n, gen_ms, pass_b='ginsim::series_kernel<3>'):
     """The three launches of the time-parallel sensor path write 48 B per sample of a run but are bound by VALU issue (VERDICT r04:
-    series_kernel<1> 0.95 of the chip's VALU issue cycles): bound = valu, from the counters of the two big kernels in the --pmc-child
+    pass B 0.95 of the chip's VALU issue cycles): bound = valu, from the counters of the two big kernels in the --pmc-child
     pass (each against its own duration there); the HBM figure of the whole generation stays beside it."""
-    hbm = roofline(48.0 * runs * n, gen_ms, 'series_kernel<0> + series_scan_kernel + series_kernel<1>', None,
+    short = pass_b.replace('ginsim::', '')
+    hbm = roofline(48.0 * runs * n, gen_ms, 'series_kernel<0> + series_scan_kernel + ' + short, None,
                    note='48 B written per sample of a run (accel3 + gyro3 doubles); the three launches of the time-parallel path')
     parts = {}
-    for k in ('ginsim::series_kernel<0>', 'ginsim::series_kernel<1>'):
+    for k in ('ginsim::series_kernel<0>', pass_b):
         v = valu_roofline(pmc, k, None, 1.0, 'its own duration in the counter pass')
         if v is not None:
             parts[k] = {'frac': v['frac'], 'valu_busy_at_the_clock_it_ran': v['valu_busy_at_the_clock_it_ran'], 'kernel_ms': v['kernel_ms_avg'],
@@ -345,7 +346,7 @@ def sensor_generation_roofline(pmc, runs, n, gen_ms):
     t = sum(p['kernel_ms'] for p in parts.values())
     frac = sum(p['frac'] * p['kernel_ms'] for p in parts.values()) / t
     return {'bound': 'valu', 'achieved': frac * SIMDS * SPEC_CLOCK_HZ, 'peak': SIMDS * SPEC_CLOCK_HZ, 'unit': 'VALU-busy SIMD-cycles/s',
-            'frac': frac, 'traffic': None, 'kernel': 'series_kernel<0> (pass A) + series_kernel<1> (pass B), weighted by their time',
+            'frac': frac, 'traffic': None, 'kernel': 'series_kernel<0> (pass A) + ' + short + ' (pass B), weighted by their time',
             'kernel_ms_avg': gen_ms, 'per_kernel': parts, 'hbm': hbm,
             'note': 'the generation is bound by VALU issue, not by its stores; the HBM figure of the same launches is under "hbm"'}
 
@@ -415,7 +416,7 @@ def leg_allan(ginsim, workloads, ctx, runs=32, seconds=3600.0, fs=400.0, pmc=Non
                        'of %d series, %d averaging factors' % (seconds, fs, n, runs, S, tau.size),
            'sensor_generation_ms': gen_ms, 'sensor_generation_ms_min': gen_min, 'sensor_kernel': job.kernel_name(),
            'sensor_layout': job.sensor_layout,
-           'sensor_generation_roofline': sensor_generation_roofline(pmc, runs, n, gen_ms),
+           'sensor_generation_roofline': sensor_generation_roofline(pmc, runs, n, gen_ms, job.kernel_name()),
            'relayout_plus_allan_wall_ms': e2e_wall_ms, 'allan_call_ms_min': min(ms),
            'samples_per_s_allan_call': S * n / avg * 1e3,
            'roofline': roofline(8.0 * S * n, avg, 'ginsim_allan (every kernel of the call, up to the synchronisation that returns the sums)',

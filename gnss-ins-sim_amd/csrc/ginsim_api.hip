@@ -31,6 +31,7 @@ hipError_t launch_mc_f32(const ginsim_mc_params& p, float* truth32, hipStream_t 
 size_t mc_f32_truth_bytes(const ginsim_mc_params& p);
 int mc_variant(const ginsim_mc_params& p);
 bool series_path_applies(const ginsim_mc_params& p);
+int series_pass_b(const ginsim_mc_params& p);
 int64_t series_chunks(const ginsim_mc_params& p, int32_t* L_out);
 hipError_t launch_series(const ginsim_mc_params& p, double* carry, hipStream_t stream);
 int mc_variant_f32(const ginsim_mc_params& p);
@@ -325,7 +326,7 @@ int ginsim_mc_kernel_name(const ginsim_mc_params* p, char* buf, size_t cap) {
     buf[0] = 0;
     if (p->precision == 1) (void)launch_mc_f32(*p, nullptr, nullptr, buf, cap);
     else if (series_path_applies(*p))       // the dominant one of series_kernel<0>, series_scan_kernel, series_kernel<1 | 2>
-        snprintf(buf, cap, (p->vib_accel.type || p->vib_gyro.type) ? "ginsim::series_kernel<2>" : "ginsim::series_kernel<1>");
+        snprintf(buf, cap, "ginsim::series_kernel<%d>", series_pass_b(*p));
     else (void)launch_mc(*p, nullptr, buf, cap);
     REQUIRE(buf[0], "mc_kernel_name: no kernel serves these parameters");
     return GINSIM_OK;

@@ -995,10 +995,13 @@ __device__ __forceinline__ void st_span(double* p, const double (&v)[kSpan]) {
     for (int i = 0; i + 1 < kSpan; i += 2) __builtin_nontemporal_store(f64x2{v[i], v[i + 1]}, reinterpret_cast<f64x2_a8*>(p + i));
 }
 
-// PASS 0: pass A; 1: pass B; 2: pass B with the vibration term of Sim(env=...) (a per-sample term: nothing to scan)
+// PASS 0: pass A; 1: pass B; 2: pass B with the vibration term of Sim(env=...) (a per-sample term: nothing to scan); 3: pass B for
+// the simple sensor model (no white-drift axis, no constant bias -- every standard IMU grade of imu_model.py: the six wave-uniform
+// selects and the bias additions are compiled out, x + 0.0 == x)
 template <int PASS>
 __global__ void __launch_bounds__(kSeriesBlock, PASS == 2 ? kSeriesWaves - 1 : kSeriesWaves) series_kernel(const ginsim_mc_params a, const SeriesPlan pl) {
     constexpr bool VIB = PASS == 2;
+    constexpr bool WD = PASS != 3;
     __shared__ uint32_t ntab[kNormalLdsWords];
     const NormalTables tab = fill_normal_tables(ntab, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -1024,12 +1027,13 @@ __global__ void __launch_bounds__(kSeriesBlock, PASS == 2 ? kSeriesWaves - 1 : k
         // chunk-end value from zero: a lane folds its samples of every step (weight a), its steps with weight a^(64 kSpan),
         // then one scan over the lanes
         double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int64_t jg = j0; jg < j1; jg += kGroup) {
+        auto fold = [&](const int64_t jg, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;        // every sample of the step inside the series: no masks
             double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int i = 0; i < kSpan; ++i) {
                 const int64_t j = jg + kSpan * lane + i;
-                const bool on = j < j1;
+                const bool on = FULL || j < j1;
                 double z0[6], z1[6];
                 normal_pairs<S_ACC_D_XY, 6>(key, (uint32_t)(on ? j : j1 - 1), z0, z1, tab);
                 const double zd[6] = {z0[0], z1[0], z0[1], z0[3], z1[3], z0[4]};
@@ -1038,7 +1042,10 @@ __global__ void __launch_bounds__(kSeriesBlock, PASS == 2 ? kSeriesWaves - 1 : k
             }
 #pragma unroll
             for (int k = 0; k < 6; ++k) acc[k] = __builtin_fma(kernarg_plan(sizeof(ginsim_mc_params))->a_step[k], acc[k], e[k]);
-        }
+        };
+        int64_t jg = j0;
+        for (; jg + kGroup <= j1; jg += kGroup) fold(jg, std::true_type{});
+        if (jg < j1) fold(jg, std::false_type{});
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             ScanWeights sw;                     // of the scan over the LANES: ratio a^kSpan
@@ -1114,8 +1121,9 @@ __global__ void __launch_bounds__(kSeriesBlock, PASS == 2 ? kSeriesWaves - 1 : k
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const uint32_t w = k == 0 ? wb[i][3 * S + 1] : (k == 1 ? wa[i][3 * S + 2] : wb[i][3 * S + 2]);
-                        const double ud = m->white_drift[k] ? u[i][k] : d[i][k];
-                        o[i][k] = truth[3 * j + k] + m->bias[k] + ud + m->white[k] * (double)normal_icdf(w, tab);
+                        const double ud = (WD && m->white_drift[k]) ? u[i][k] : d[i][k];
+                        const double tb = WD ? truth[3 * j + k] + m->bias[k] : truth[3 * j + k];
+                        o[i][k] = tb + ud + m->white[k] * (double)normal_icdf(w, tab);
                     }
                     if (VIB) {          // added last, as pathgen.py:500, 562 do
                         const Vec3 v = S ? add_vibration<S_GYR_VIB_XY>(Vec3{o[i][0], o[i][1], o[i][2]}, &kernarg_params()->vib_gyro, key, (uint32_t)j, tab, vpg)
@@ -1183,6 +1191,9 @@ __global__ void __launch_bounds__(64) series_scan_kernel(const SeriesPlan pl, in
     }
 }
 
+// which pass B a launch takes (ginsim_mc_kernel_name reports it)
+int series_pass_b(const ginsim_mc_params& p) { return any_vibration(p) ? 2 : (any_white_drift(p) ? 1 : 3); }
+
 // sensors only, few runs, long series
 bool series_path_applies(const ginsim_mc_params& p) {
     return p.algo_mask == 0 && !p.given_sensors && p.precision == 0 && !p.wave_trace && p.block_threads == 0 &&
@@ -1225,7 +1236,8 @@ hipError_t launch_series(const ginsim_mc_params& p, double* carry, hipStream_t s
     hipLaunchKernelGGL((series_kernel<0>), grid, block, 0, stream, p, pl);
     hipLaunchKernelGGL(series_scan_kernel, dim3((unsigned)(p.runs * 6)), dim3(64), 0, stream, pl, p.runs);
     if (any_vibration(p)) hipLaunchKernelGGL((series_kernel<2>), grid, block, 0, stream, p, pl);
-    else hipLaunchKernelGGL((series_kernel<1>), grid, block, 0, stream, p, pl);
+    else if (any_white_drift(p)) hipLaunchKernelGGL((series_kernel<1>), grid, block, 0, stream, p, pl);
+    else hipLaunchKernelGGL((series_kernel<3>), grid, block, 0, stream, p, pl);
     return hipGetLastError();
 }
 

@@ -450,8 +450,11 @@ def test_dispatch_queries_and_sensor_layout_rules_without_a_gpu():
     assert query(params(precision=1))[1].startswith('ginsim::f32::mc_kernel_f32_split<1, 1, false, 3,')
     # sensors only, few runs, long series: the time-parallel kernels -- with the series-major layout, or with one run (same thing)
     few = dict(algo_mask=0, runs=32, n=1440000)
-    assert query(params(sensor_layout=1, **few)) == (2, 'ginsim::series_kernel<1>')
-    assert query(params(sensor_layout=0, **dict(few, runs=1))) == (2, 'ginsim::series_kernel<1>')
+    assert query(params(sensor_layout=1, **few)) == (2, 'ginsim::series_kernel<3>')                    # pass B of the simple sensor model
+    assert query(params(sensor_layout=0, **dict(few, runs=1))) == (2, 'ginsim::series_kernel<3>')
+    general = params(sensor_layout=1, **few)
+    general.gyro.bias[1] = 1e-4                                                                        # a constant bias: the general model
+    assert query(general) == (2, 'ginsim::series_kernel<1>')
     assert query(params(sensor_layout=0, **few))[0] == 0                                               # run-fastest layout: one lane per run
     for bad in (dict(sensor_layout=1), dict(sensor_layout=1, algo_mask=0, runs=2000, n=1440000), dict(sensor_layout=1, algo_mask=0, runs=32, n=1000),
                 dict(sensor_layout=2, **few)):
