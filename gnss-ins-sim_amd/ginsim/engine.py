@@ -76,12 +76,16 @@ class DeviceView(object):
 class Context(object):
     """One GPU (one HIP stream).  Raises GinsimError when no GPU is visible -- there is no CPU path."""
 
+    _created = 0            # contexts of this process so far: `serial` orders them (= the order their streams were created in)
+
     def __init__(self, device=0):
         h = C.c_void_p()
         self.handle = None
         check(lib.ginsim_create(int(device), C.byref(h)))
         self.handle = h.value
         self.device = int(device)
+        Context._created += 1
+        self.serial = Context._created
         self.comm_ranks = 0
         # freed device regions by size (DeviceBuffer): regions of at least POOL_MIN bytes, pool_limit bytes in total -- at most a
         # third of the device's memory (96 GiB of an MI355X's 288 GB), so that on a smaller GPU the pool cannot sit on most of

@@ -288,3 +288,55 @@ def test_online_statistics_floor_for_a_constant_error(rf, algo):
             assert np.any(b[:, 2] < 1e-4 * np.abs(b[:, 1]))             # (the raw form is off by ~1.5e-8 |mean| here: >> 1e-7 std)
         online.release()
         kept.release()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('stats_start', [0, 2.0, -1])
+def test_kept_runs_riding_along_as_the_first_workgroup_change_nothing(monkeypatch, stats_start):
+    """Statistics-only Sim with keep_runs: the kept runs are integrated as the first 256-run workgroup of the batch on a sibling
+    context while the other runs are integrated statistics-only (ins_sim._BlockAndRest), instead of in a small launch of their own in
+    front of a launch over all runs.  Same kept series (bit for bit), same per-run process statistics (bit for bit: the same
+    kernel accumulates them for the same global run ids), same end-point statistics up to the association of the Chan merge."""
+    import contextlib
+    import io
+    import os
+    from conftest import PKG
+    from gnss_ins_sim.sim import imu_model, ins_sim
+    from demo_algorithms import free_integration, free_integration_odo
+    g = load_golden('t3_mid_rf0')
+    csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
+    R, K = 700, 4
+
+    def run(ride):
+        monkeypatch.setattr(ins_sim, 'KEPT_BLOCK', 256 if ride else 10 ** 9)
+        imu = imu_model.IMU(accuracy='mid-accuracy', axis=6, gps=True, odo=True, odo_opt={'scale': 0.999, 'stdv': 0.1})
+        algos = [free_integration.FreeIntegration(g['ini']), free_integration_odo.FreeIntegration(g['ini'])]
+        sim = ins_sim.Sim([100.0, 10.0, 0.0], csv, ref_frame=0, imu=imu, algorithm=algos, seed=17, keep_trajectories=False, keep_runs=K,
+                          stats_start=stats_start, device=0)
+        sim.run(R)
+        assert sim.mc.kept_block is ride
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim.results(err_stats_start=stats_start)
+        a = sim.err_stats
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim.results(err_stats_start=stats_start, extra_opt='ned')
+        return sim, a, sim.err_stats
+
+    s1, a1, n1 = run(True)
+    s0, a0, n0 = run(False)
+    assert set(s1.dmgr.accel.data.keys()) == set(range(K))
+    for r in range(K):
+        for nm in ('accel', 'gyro', 'odo', 'gps'):
+            np.testing.assert_array_equal(getattr(s1.dmgr, nm).data[r], getattr(s0.dmgr, nm).data[r])
+        for a in ('algo0', 'algo1'):
+            for nm in ('pos', 'vel', 'att_euler'):
+                np.testing.assert_array_equal(getattr(s1.dmgr, nm).data['%s_%d' % (a, r)], getattr(s0.dmgr, nm).data['%s_%d' % (a, r)])
+    for x, y in ((a1, a0), (n1, n0)):
+        for name in ('att_euler', 'pos', 'vel'):
+            for st in ('max', 'avg', 'std'):
+                assert sorted(x[name][st].keys()) == sorted(y[name][st].keys())
+                for key in x[name][st].keys():
+                    if stats_start == -1:       # end-point statistics over all runs: two partial records merged
+                        np.testing.assert_allclose(x[name][st][key], y[name][st][key], rtol=1e-12, atol=1e-15)
+                    else:                       # per-run records: the same numbers
+                        np.testing.assert_array_equal(x[name][st][key], y[name][st][key])
