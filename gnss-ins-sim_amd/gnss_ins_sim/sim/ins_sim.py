@@ -19,7 +19,9 @@ Keyword-only extras (defaults keep the reference behaviour):
                        ``max_device_bytes``), else keep only per-run end-point errors (stats-only).
     max_device_bytes   budget for materialised series on one GPU (default 64 GiB of the 288 GB).
     keep_runs          stats-only mode: still materialise sensors (incl. GPS / magnetometer), outputs and CSV files of the
-                       first K runs of this rank (the counter RNG reproduces them exactly in a second, small launch).
+                       first K runs of this rank (the counter RNG makes them the same runs wherever they are integrated: as the
+                       first 256-run workgroup of the batch on a sibling stream when K <= 256 and this process integrates on one
+                       GPU in fp64 -- no time of their own --, otherwise in a second, small launch).
     stats_start        stats-only mode: the ``err_stats_start`` that ``results()`` will be asked for (default 0 s, the
                        reference's default; -1 = end-point only).  The process-error statistics of that window are
                        accumulated inside the kernel; asking ``results()`` for another window integrates once more.
