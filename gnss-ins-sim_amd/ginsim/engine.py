@@ -609,7 +609,7 @@ class MonteCarloJob(object):
             self.launch()
         return self.ctx.timer_end() / k
 
-    def spread_outputs(self, tries=8, gain=0.07, min_gain=0.015, launches=16, max_hold=64 << 30):
+    def spread_outputs(self, tries=8, gain=0.07, min_gain=0.015, launches=16, max_hold=128 << 30):
         """Move the largest output region to where the launch runs faster, found by TIMING.
 
         The 288 GB of an MI355X are three 96 GB thirds -- the top level of the physical address, below it every HBM stack and
@@ -617,7 +617,9 @@ class MonteCarloJob(object):
         where the same launch with planes in two thirds reaches ~6.4 (C2: 1.33 against 1.23 ms; placing the planes by hand in a
         230 GB arena: profiles/r05_hbm_thirds.json).  hipMalloc does not say where a region lies, and a fresh process gets its
         first ~32 GB from one third.  So: the largest output region (the trajectories of an algorithm, else the sensor series) is
-        allocated AGAIN while every region tried before is still held -- the driver then has to take memory further on --, the
+        allocated AGAIN while every region tried before is still held -- the driver then has to take memory further on; from the
+        third failure on a spacer as large as everything held so far is held too, so that the search covers a whole third (96 GB)
+        in `tries` steps if it must (r05h: 8 candidates = 38 GB further on were still in the same third) --, the
         launch is timed with each candidate in the warm state, the search stops at a candidate that beats the original placement by
         `gain` (one third -> two is 8-10 %), and the best candidate stays if it is at least `min_gain` faster (a region that only
         partly reaches into another third is worth 2-4 %); everything else is freed.  Needs a second large region next to the one
@@ -653,11 +655,18 @@ class MonteCarloJob(object):
         original = big[key]
         layout = getattr(original, 'layout', None)
         held, best, best_ms, took = [], None, float('inf'), 0
+        cap = min(max_hold, free_now // 2)
+        holding = 0                             # bytes held on top of the job's own regions
         for t in range(int(tries)):
-            if (t + 1) * size > min(max_hold, free_now // 2):
+            if holding + size > cap:
                 break
             try:
+                jump = min(holding, cap - holding - size) if t >= 3 else 0       # a spacer as large as everything held so far
+                if jump >= size:
+                    held.append(DeviceBuffer(self.ctx, jump))
+                    holding += jump
                 cand = DeviceBuffer(self.ctx, size)
+                holding += size
             except RuntimeError:                # out of memory (another process took it meanwhile): keep what we have
                 break
             if layout is not None:
