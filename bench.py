@@ -562,7 +562,7 @@ def main():
                                keep_sensors=keep, keep_traj=keep, precision=args.precision)
     unit_bytes = BYTES_PER_SAMPLE_MC if args.precision == 'f64' else BYTES_PER_SAMPLE_MC // 2
     placement = None
-    if keep and args.placement == 'spread' and not args.pmc_child:
+    if keep and args.placement == 'spread' and not args.pmc_child and not args.shared_device:      # (ranks sharing ONE GPU would each hold up to half of it)
         placement = job.spread_outputs()            # set-up, like the warm-up: nothing of it is inside the timed region
     group = dist.group.WORLD if use_dist else None
     device = torch.device('cuda', local_rank) if args.backend == 'nccl' else torch.device('cpu')
