@@ -842,14 +842,14 @@ def main():
             legs.append(leg_mc(ginsim, workloads, ctx, 'C3_end_point_only', 'the same launch with end-point statistics only (r01 form)',
                                'long_drive', 200.0, 0, 262144, False, 'f64', 2, gps=True, **c3))
             legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32', 'BASELINE configs[4]: fp32 kernel on the C2 workload, 65 536 runs, '
-                               'materialised (60 B/sample*MC)', 'turn_90deg', 100.0, 1, 65536, True, 'f32', 20, traffic=traffic, place=place))
+                               'materialised (60 B/sample*MC)', 'turn_90deg', 100.0, 1, 65536, True, 'f32', 20, traffic=traffic))
             legs.append(leg_mc(ginsim, workloads, ctx, 'C5_fp32_262144', 'fp32 kernel, 262 144 runs, materialised', 'turn_90deg', 100.0, 1,
-                               262144, True, 'f32', 10, place=place))
+                               262144, True, 'f32', 10))
             # Sim(env=...) (beyond BASELINE's configurations, all of which use env=None): the C2 launch in a vibration environment
             legs.append(leg_mc(ginsim, workloads, ctx, 'C2_vibration_random', 'the C2 launch with Sim(env={acc: [0.03 0.03 0.03]g-random, '
                                'gyro: [0.5 0.5 0.5]d-random}): the vibration variant of the wave-specialised kernel (round 5; round 4: the plain kernel, one wavefront per SIMD)', 'turn_90deg',
                                100.0, 1, 65536, True, 'f64', 10,
-                               pmc=pmc, valu_too=True, place=place, **VIB_LEG))
+                               pmc=pmc, valu_too=True, **VIB_LEG))
             legs.append(leg_allan(ginsim, workloads, ctx, pmc=pmc))
             legs.append(leg_sim_e2e(workloads))
             out['configs'] = legs

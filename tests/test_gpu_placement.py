@@ -44,8 +44,8 @@ def test_spread_outputs_keeps_every_result_whichever_way_the_search_ends(ctx, al
     ctx.release_pool()
     free0 = ctx.mem_info()[0]
     # no candidate can be 50 % faster: everything tried is freed, the original regions are bound again
-    r = job.spread_outputs(tries=3, gain=0.5, min_gain=0.5, launches=2)
-    assert r['moved'] is None and r['candidates'] == 3 and r['region'].startswith('traj_'), r
+    r = job.spread_outputs(tries=3, gain=0.5, min_gain=0.5, launches=2, good_bytes_per_s=None)
+    assert r['moved'] is None and r['candidates'] == 6 and r['region'].startswith('traj_') and len(r['regions']) == 2, r      # two regions, three candidates each
     ctx.sync()
     for a, b in zip(want, _snapshot(job, algos)):
         np.testing.assert_array_equal(a, b)
@@ -53,7 +53,7 @@ def test_spread_outputs_keeps_every_result_whichever_way_the_search_ends(ctx, al
     # every candidate "wins" (gain < 0): the first one stays, the original region is freed
     key = r['region']
     old = job.buffer(key).ptr
-    r = job.spread_outputs(tries=3, gain=-10.0, min_gain=-10.0, launches=2)
+    r = job.spread_outputs(tries=3, gain=-10.0, min_gain=-10.0, launches=2, good_bytes_per_s=None)
     assert r['moved'] == key and r['candidates'] == 1 and r['launch_ms'] > 0, r
     assert job.buffer(key).ptr != old
     ctx.sync()
@@ -74,7 +74,7 @@ def test_spread_outputs_moves_the_sensor_series_when_they_are_the_largest_region
     job.run()
     ids = np.arange(0, 2048, 97)
     want = [job.sensors(nm, ids) for nm in ('accel', 'gyro', 'odo')]
-    r = job.spread_outputs(tries=2, gain=-10.0, min_gain=-10.0, launches=2)
+    r = job.spread_outputs(tries=2, gain=-10.0, min_gain=-10.0, launches=2, good_bytes_per_s=None)
     assert r['moved'] == 'imu', r
     assert job.buffer('accel').ptr == job.buffer('imu').ptr and job.buffer('gyro').ptr == job.buffer('imu').ptr + job.buffer('imu').nbytes // 2
     for a, nm in zip(want, ('accel', 'gyro', 'odo')):
