@@ -1,7 +1,7 @@
 // Fused Monte-Carlo kernel: sensor-error injection + strapdown mechanisation + end-point error.
 //
 // One lane = one Monte-Carlo run (no inter-lane traffic in the time loop; workgroups of 256 or 512 threads only
-// shape the placement on the SIMDs and share the 4 KB coefficient table of the normal transform).  Per-run state (Euler attitude + cached
+// shape the placement on the SIMDs and share the coefficient table (8 KB of LDS) of the normal transform).  Per-run state (Euler attitude + cached
 // trig, body/NED velocity, position, the six Gauss-Markov bias states) lives in VGPRs for the whole time loop.
 // Truth samples are wave-uniform and come in through the scalar cache.  Everything that leaves the lane is SoA [component][sample][run]
 // (run fastest) so that every store instruction of a wavefront writes 64 x 8 B contiguous bytes.
