@@ -257,14 +257,23 @@ def pmc_traffic_file(build):
         return None
 
 
+def brief_placement(p):
+    """MonteCarloJob.placement() without the arena's stripe map (the headline's top-level `placement` carries that once)."""
+    if p is None:
+        return None
+    a = p.get('arena', {})
+    return {'placed': p['placed'], 'unplaced': p['unplaced'], 'bytes': p['bytes'],
+            'arena_mapped_bytes': a.get('mapped_bytes'), 'arena_stripes_of_class': a.get('stripes_of_class')}
+
+
 # --------------------------------------------------------------------------------------------- legs (N = 1)
-def leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, reps=10, place=False):
+def leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, reps=10):
     """FreeIntegration.run alone for the whole batch: the given-sensors kernel reads the accel/gyro series the last step
     materialised (48 B) and writes att/pos/vel (72 B) per sample*MC -- the HBM-bound piece of the path."""
     rep = ginsim.MonteCarloJob(ctx, fs, rf, truth, None, None, ini, runs=R, keep_traj=True,
                                given={'gyro': job.buffer('gyro'), 'accel': job.buffer('accel')})
     rep.run()
-    placed = rep.spread_outputs() if place else None
+    placed = rep.placement()
     avg, mn = time_launches(ctx, rep.launch, reps)
     same = bool((rep.end_errors('free') == job.end_errors('free')).all())
     name = rep.kernel_name()
@@ -274,7 +283,7 @@ def leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, reps=
             '(%d runs x %d samples; 48 B read + 72 B written per sample*MC)' % (R, n), 'dtype': 'f64',
             'sample_MC_per_s': R * n / avg * 1e3, 'kernel_ms_min': mn,
             'roofline': roofline(b, avg, name, (traffic or {}).get(name, {}).get('hbm_bytes_per_launch')),
-            'bit_identical_to_fused_kernel': same, 'placement': placed}
+            'bit_identical_to_fused_kernel': same, 'placement': brief_placement(placed)}
 
 
 PMC_CUT_SAMPLES = 8192      # the C3-shaped launches of the --pmc-child workload are cut to this many samples
@@ -287,7 +296,7 @@ def cut_truth(truth, n):
 
 
 def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precision, reps, gps=False, pmc=None, traffic=None,
-           cut=None, valu_too=False, place=False, **job_kw):
+           cut=None, valu_too=False, **job_kw):
     ini, truth, _ = workloads.truth_from_profile(profile, fs, rf, fs_gps=10.0 if gps else 0.0, gps=gps)
     if cut:
         truth = cut_truth(truth, cut)
@@ -296,7 +305,7 @@ def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precisi
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, seed=SEED, keep_sensors=keep, keep_traj=keep,
                                precision=precision, **job_kw)
     job.run()
-    placed = job.spread_outputs() if (place and keep) else None
+    placed = job.placement() if keep else None
     avg, mn = time_launches(ctx, job.launch, reps, warm=2 if reps > 2 else 0)
     st = job.stats('free')
     unit = (BYTES_PER_SAMPLE_MC if precision == 'f64' else BYTES_PER_SAMPLE_MC // 2) if keep else 0
@@ -323,7 +332,7 @@ def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precisi
            'roofline': roof,
            'result': {'att_std_deg': (st.std[:3] * 57.29577951308232).tolist(), 'vel_std_mps': st.std[6:9].tolist(), 'runs': st.count}}
     if placed is not None:
-        out['placement'] = placed
+        out['placement'] = brief_placement(placed)
     job.release()
     return out
 
@@ -499,9 +508,11 @@ def main():
     ap.add_argument('--precision', choices=['f64', 'f32'], default='f64', help="f32 = BASELINE config 5's single-precision kernel")
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
     ap.add_argument('--no-legs', action='store_true', help='skip the configs[] legs (C3, C4 share, C5, Allan, mechanisation)')
-    ap.add_argument('--placement', choices=['spread', 'asis'], default='spread',
-                    help="spread: MonteCarloJob.spread_outputs() before anything is timed (the output planes in two of the device "
-                         "memory's three 96 GB thirds, found by timing); asis: wherever hipMalloc put them")
+    ap.add_argument('--placement', choices=['placed', 'asis'], default='placed',
+                    help="placed (the library's default, what an unconfigured Sim gets): the materialised series are carved from the "
+                         "device's placed arena (ABI 7: stripes cycling through the three classes of physical memory); asis: plain "
+                         "hipMalloc, wherever the driver puts the planes.  Either way the line carries BOTH rooflines (N = 1): "
+                         "`roofline` for --placement, `roofline_asis` / `roofline_placed` for the other one, same process")
     ap.add_argument('--no-repeat', action='store_true', help='N = 1: do not time the K steps a second time (headline_again)')
     ap.add_argument('--pmc', choices=['live', 'file', 'off'], default='live',
                     help='roofline.traffic: rocprofv3 PMC passes of this build (live), the stamped profiles/pmc_traffic.json, or null')
@@ -551,6 +562,8 @@ def main():
         else:
             dist.init_process_group(args.backend)
     ctx = ginsim.Context(local_rank)
+    if args.placement == 'asis' or args.shared_device:      # (ranks sharing ONE GPU would each build an arena on it)
+        ctx.placed_enabled, ctx.placed_note = False, '--placement asis' if args.placement == 'asis' else '--shared-device'
 
     fs, rf = args.fs, args.ref_frame
     R = args.runs_per_gpu or (65536 if world == 1 else 131072)
@@ -561,9 +574,7 @@ def main():
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, algos=('free',), seed=SEED,
                                keep_sensors=keep, keep_traj=keep, precision=args.precision)
     unit_bytes = BYTES_PER_SAMPLE_MC if args.precision == 'f64' else BYTES_PER_SAMPLE_MC // 2
-    placement = None
-    if keep and args.placement == 'spread' and not args.pmc_child and not args.shared_device:      # (ranks sharing ONE GPU would each hold up to half of it)
-        placement = job.spread_outputs()            # set-up, like the warm-up: nothing of it is inside the timed region
+    placement = job.placement() if keep else None           # the arena was built (one search) inside the constructor: set-up
     group = dist.group.WORLD if use_dist else None
     device = torch.device('cuda', local_rank) if args.backend == 'nccl' else torch.device('cpu')
     nsteps = args.warmup + args.steps
@@ -732,6 +743,25 @@ def main():
                  'seconds_after_the_first': t1 - t0 - elapsed, 'same_statistics': bool(merged2.count == merged.count and
                                                                                       np.array_equal(merged2.m2, merged.m2)),
                  'note': 'the K timed steps repeated in the same process after a 3 s pause and the same time-based pre-warm'}
+    # The SAME launches with the other placement, same process (N = 1): plain hipMalloc planes when the headline ran placed, placed
+    # planes when it ran --placement asis.  K launches back to back after the same time-based pre-warm, HIP events around each.
+    other = None
+    if world == 1 and keep and not args.pmc_child and not args.shared_device:
+        want_placed = args.placement == 'asis'
+        saved = (ctx.placed_enabled, ctx.placed_note)
+        if want_placed:
+            ctx.placed_enabled = os.environ.get('GINSIM_PLACED', '1') != '0'
+        try:
+            j2 = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, algos=('free',), seed=SEED, keep_sensors=True,
+                                      keep_traj=True, precision=args.precision, placed=want_placed)
+            k = max(2, min(args.steps, 100))
+            avg2, mn2 = time_launches(ctx, j2.launch, k)
+            other = {'placement': 'placed' if want_placed else 'asis', 'kernel_ms_avg': avg2, 'kernel_ms_min': mn2, 'launches': k,
+                     'got': brief_placement(j2.placement())}
+            j2.release()
+        except ginsim.GinsimError as e:                           # e.g. not enough memory for a second set of planes
+            other = {'placement': 'placed' if want_placed else 'asis', 'error': str(e)[:200]}
+        ctx.placed_enabled, ctx.placed_note = saved
     per_rank = None
     if use_dist and world > 1:          # the slowest GPU sets the step time: make it visible in the line
         rows = [None] * world
@@ -809,10 +839,21 @@ def main():
             'result': {'att_std_deg': (merged.std[:3] * r2d).tolist(), 'vel_std_mps': merged.std[6:9].tolist(),
                        'runs': merged.count},
         }
-        if placement is not None:
-            out['config']['placement'] = dict(placement, note='MonteCarloJob.spread_outputs() before the warm-up: the launch is ~8 % '
-                                              'slower when all 15 output planes lie in ONE of the three 96 GB thirds of the device memory '
-                                              '(profiles/r05_hbm_thirds.json); --placement asis times them where hipMalloc put them')
+        # where the planes lie -- top-level keys, so that the driver's record keeps them
+        out['placement'] = {'mode': args.placement if not args.shared_device else 'asis (--shared-device)',
+                            'job': placement,
+                            'note': 'placed = the library default (what an unconfigured Sim gets): the 15 output planes are carved from the '
+                                    "device's placed arena, whose 512 MiB stripes cycle through the three classes of physical memory "
+                                    '(ABI 7, csrc/placed.hip); arena.search_seconds / chunks_created / probes are the one-off cost of '
+                                    'building it, before the warm-up'}
+        if other is not None and 'kernel_ms_avg' in other:
+            key = 'roofline_' + other['placement']
+            out[key] = roofline(alg_bytes, other['kernel_ms_avg'], kname, None, kernel_ms_min=other['kernel_ms_min'],
+                                launches=other['launches'], got=other['got'],
+                                note='the same launch in the same process with the OTHER placement (%s), back to back after the '
+                                     'timed region' % ('plain hipMalloc planes' if other['placement'] == 'asis' else 'planes from the placed arena'))
+        elif other is not None:
+            out['roofline_' + other['placement']] = other
         if again is not None:
             out['headline_again'] = again
             out['roofline']['frac_again'] = alg_bytes / (again['kernel_ms_avg'] * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -824,15 +865,14 @@ def main():
             out['per_rank'] = per_rank
         if world == 1 and not args.no_legs:
             legs = []
-            place = args.placement == 'spread'
 
             if keep and args.precision == 'f64':
-                legs.append(leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic, place=place))
+                legs.append(leg_mechanisation(ginsim, ctx, job, fs, rf, truth, ini, R, n, traffic))
                 out['mechanisation_only'] = legs[-1]
             job.release()
             job = None
             legs.append(leg_mc(ginsim, workloads, ctx, 'C4_per_gpu_share', 'BASELINE configs[3] per-GPU share: turn_90deg @100 Hz, '
-                               '131 072 runs, fp64, materialised', 'turn_90deg', 100.0, 1, 131072, True, 'f64', 10, place=place))
+                               '131 072 runs, fp64, materialised', 'turn_90deg', 100.0, 1, 131072, True, 'f64', 10))
             c3 = dict(pmc=pmc)
             legs.append(leg_mc(ginsim, workloads, ctx, 'C3', 'BASELINE configs[2]: long_drive @200 Hz (n = 193 036), ref_frame 0, 262 144 '
                                'runs, fp64; trajectories would be 6 TB, so the kernel accumulates the per-run process-error statistics '

@@ -35,6 +35,7 @@ SOURCES = [
     ('mc_kernel_f32.hip', ['--offload-arch=' + ARCH, '-mllvm', '-disable-machine-licm', '-ffp-contract=off', '-fno-slp-vectorize']),
     ('stats.hip', ['--offload-arch=' + ARCH]),
     ('allan.hip', ['--offload-arch=' + ARCH]),
+    ('placed.hip', ['--offload-arch=' + ARCH]),
     ('ginsim_api.hip', ['--offload-arch=' + ARCH]),
     # host-only truth generator; no fused multiply-adds (see the file header)
     ('pathgen.cpp', ['-x', 'c++', '-ffp-contract=off']),

@@ -12,6 +12,7 @@
 #include "ginsim.h"
 #include "allan.hpp"
 #include "comm.hpp"
+#include "placed.hpp"
 
 namespace ginsim {
 
@@ -104,6 +105,7 @@ static hipError_t scratch(ginsim_ctx* c, int slot, size_t bytes, void** out) {
         hipError_t e_ = (expr);                                                               \
         if (e_ != hipSuccess) {                                                               \
             set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            if (e_ == hipErrorOutOfMemory) { (void)hipGetLastError(); return GINSIM_ERR_NOMEM; } \
             return GINSIM_ERR_HIP;                                                            \
         }                                                                                     \
     } while (0)
@@ -158,6 +160,7 @@ int ginsim_create(int device, ginsim_ctx** out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    ginsim::placed_context_created(device);
     *out = c;
     return GINSIM_OK;
 }
@@ -182,6 +185,7 @@ int ginsim_destroy(ginsim_ctx* c) {
     for (hipEvent_t e : c->comm_ev)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
+    ginsim::placed_context_destroyed(c->device);      // the device's last context gives its placed arena back
     delete c;
     return GINSIM_OK;
 }
@@ -197,10 +201,36 @@ int ginsim_device_name(ginsim_ctx* c, char* buf, size_t cap) {
 int ginsim_malloc(ginsim_ctx* c, size_t bytes, void** dptr) {
     REQUIRE(c && dptr, "malloc: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
-    const char* e = getenv("GINSIM_MALLOC_FLAGS");          // experiment (tools/exp_r05p.sh)
-    const unsigned flags = e ? (unsigned)atoi(e) : 0u;
-    if (flags) HIP_TRY(hipExtMallocWithFlags(dptr, bytes ? bytes : 8, flags));
-    else HIP_TRY(hipMalloc(dptr, bytes ? bytes : 8));
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 8));
+    return GINSIM_OK;
+}
+
+// ---- ABI 7: placed device memory (csrc/placed.hip)
+int ginsim_placed_configure(ginsim_ctx* c, const ginsim_placed_options* o) {
+    REQUIRE(c && o, "placed_configure: bad arguments");
+    return ginsim::placed_configure(c->device, *o);
+}
+
+int ginsim_placed_reserve(ginsim_ctx* c, size_t bytes) {
+    REQUIRE(c, "placed_reserve: NULL context");
+    return ginsim::placed_reserve(c->device, bytes);
+}
+
+int ginsim_malloc_placed(ginsim_ctx* c, size_t bytes, void** dptr) {
+    REQUIRE(c && dptr, "malloc_placed: bad arguments");
+    return ginsim::placed_malloc(c->device, bytes, dptr);
+}
+
+int ginsim_placed_release(ginsim_ctx* c) {
+    REQUIRE(c, "placed_release: NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ginsim::placed_release(c->device, false);
+}
+
+int ginsim_placed_info_get(ginsim_ctx* c, ginsim_placed_info* out) {
+    REQUIRE(c && out, "placed_info_get: bad arguments");
+    ginsim::placed_info(c->device, out);
     return GINSIM_OK;
 }
 
@@ -235,6 +265,7 @@ int ginsim_free(ginsim_ctx* c, void* dptr) {
     if (!dptr) return GINSIM_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ginsim::placed_owns(c->device, dptr)) return ginsim::placed_free(c->device, dptr);     // back to the arena's free list
     HIP_TRY(hipFree(dptr));
     return GINSIM_OK;
 }

@@ -1,0 +1,23 @@
+// Placed device memory: one arena per GPU whose 512 MiB stripes cycle through the three classes of physical memory an MI355X
+// has (csrc/placed.hip).  Internal interface of libginsim.so; the C ABI over it is in ginsim_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+#include "ginsim.h"
+
+namespace ginsim {
+
+// status: GINSIM_OK, GINSIM_ERR_PLACED (no usable arena on this device: the caller allocates with hipMalloc), GINSIM_ERR_NOMEM,
+// GINSIM_ERR_HIP; the message is left with set_error()
+int placed_configure(int device, const ginsim_placed_options& o);
+int placed_reserve(int device, size_t bytes);
+int placed_malloc(int device, size_t bytes, void** out);
+bool placed_owns(int device, const void* p);
+int placed_free(int device, void* p);
+int placed_release(int device, bool force);
+void placed_info(int device, ginsim_placed_info* out);
+void placed_context_created(int device);
+void placed_context_destroyed(int device);      // the last context of a device drops its arena
+
+}  // namespace ginsim

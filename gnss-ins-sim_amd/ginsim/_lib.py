@@ -16,11 +16,33 @@ LIB_PATH = os.environ.get('GINSIM_LIB') or os.path.join(os.path.dirname(_HERE), 
 ALGO_FREE = 1
 ALGO_ODO = 2
 
-OK, ERR_ARG, ERR_HIP, ERR_NODEV, ERR_RANGE = 0, -1, -2, -3, -4
+OK, ERR_ARG, ERR_HIP, ERR_NODEV, ERR_RANGE, ERR_NOMEM, ERR_PLACED = 0, -1, -2, -3, -4, -5, -6
 
 
 class GinsimError(RuntimeError):
     """HIP / device failure inside libginsim."""
+
+
+class GinsimOutOfMemory(GinsimError):
+    """The device is out of memory (GINSIM_ERR_NOMEM, ABI 7): the one failure worth a retry after giving memory back."""
+
+
+class PlacedUnavailable(GinsimError):
+    """This device has no usable placed arena (GINSIM_ERR_PLACED): allocate with ginsim_malloc instead."""
+
+
+class PlacedOptions(C.Structure):
+    """ginsim_placed_options (ABI 7); zero = the library's default."""
+    _fields_ = [('stripe_bytes', C.c_int64), ('budget_bytes', C.c_int64), ('limit_bytes', C.c_int64), ('search_seconds', C.c_double)]
+
+
+class PlacedInfo(C.Structure):
+    """ginsim_placed_info (ABI 7)."""
+    _fields_ = [('available', C.c_int32), ('classes', C.c_int32), ('searches', C.c_int32), ('failed', C.c_int32),
+                ('stripe_bytes', C.c_int64), ('mapped_bytes', C.c_int64), ('used_bytes', C.c_int64), ('limit_bytes', C.c_int64),
+                ('stripes_of_class', C.c_int64 * 3), ('chunks_created', C.c_int64), ('chunks_ambiguous', C.c_int64),
+                ('probes', C.c_int64), ('peak_held_bytes', C.c_int64), ('search_seconds', C.c_double),
+                ('last_search_seconds', C.c_double), ('anchor_ms', C.c_double), ('stripe_classes', C.c_char * 256)]
 
 
 class SensorModel(C.Structure):
@@ -80,6 +102,11 @@ _SIGS = {
     'ginsim_mem_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     'ginsim_malloc': (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     'ginsim_free': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'ginsim_placed_configure': (C.c_int, [C.c_void_p, C.POINTER(PlacedOptions)]),
+    'ginsim_placed_reserve': (C.c_int, [C.c_void_p, C.c_size_t]),
+    'ginsim_malloc_placed': (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    'ginsim_placed_release': (C.c_int, [C.c_void_p]),
+    'ginsim_placed_info_get': (C.c_int, [C.c_void_p, C.POINTER(PlacedInfo)]),
     'ginsim_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     'ginsim_memcpy_d2h': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     'ginsim_memset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
@@ -162,6 +189,10 @@ def check(rc):
     msg = lib.ginsim_last_error().decode('utf-8', 'replace')
     if rc in (ERR_ARG, ERR_RANGE):
         raise ValueError(msg)
+    if rc == ERR_NOMEM:
+        raise GinsimOutOfMemory(msg)
+    if rc == ERR_PLACED:
+        raise PlacedUnavailable(msg)
     raise GinsimError(msg)
 
 

@@ -168,9 +168,9 @@ class JobSet(_Parts):
     def release(self):
         self._each_part(lambda j: j.release())
 
-    def spread_outputs(self, **kw):
-        """MonteCarloJob.spread_outputs on every device at the same time: the per-device reports, device order."""
-        return self._each_part(lambda j: j.spread_outputs(**kw))
+    def placement(self):
+        """MonteCarloJob.placement of every part, device order."""
+        return self._each_part(lambda j: j.placement())
 
     # ---- statistics: per-device records folded with the library's Chan merge, device order
     def _merged(self, fn):

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(raw, s)]
     assert not missing, 'declared in include/ginsim.h but not exported: %s' % missing
     assert set(ginsim.EXPORTS) <= declared
-    assert ginsim.lib.ginsim_abi_version() == 6
+    assert ginsim.lib.ginsim_abi_version() == 7
 
 
 def test_no_gpu_fails_loudly():
