@@ -213,12 +213,12 @@ int ginsim_placed_configure(ginsim_ctx* c, const ginsim_placed_options* o) {
 
 int ginsim_placed_reserve(ginsim_ctx* c, size_t bytes) {
     REQUIRE(c, "placed_reserve: NULL context");
-    return ginsim::placed_reserve(c->device, bytes);
+    return ginsim::placed_reserve(c->device, c->stream, bytes);
 }
 
 int ginsim_malloc_placed(ginsim_ctx* c, size_t bytes, void** dptr) {
     REQUIRE(c && dptr, "malloc_placed: bad arguments");
-    return ginsim::placed_malloc(c->device, bytes, dptr);
+    return ginsim::placed_malloc(c->device, c->stream, bytes, dptr);
 }
 
 int ginsim_placed_release(ginsim_ctx* c) {

@@ -84,7 +84,8 @@ struct Arena {
     std::mutex mu;
     ginsim_placed_options opt{};
     bool configured = false, vmm_checked = false, vmm_ok = false, failed = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                       // the stream of the context that asked (probes run on it: a stream of the arena's own
+                                                        // would shift every later stream of the process to another hardware queue)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipMemAllocationProp prop{};
     hipMemAccessDesc access{};
@@ -175,8 +176,7 @@ int ensure_ready(Arena& a) {
     if (a.failed) { set_error("placed memory: device %d: an earlier search found fewer than two classes of physical memory", a.device); return GINSIM_ERR_PLACED; }
     int rc = resolve_options(a);
     if (rc) return rc;
-    if (!a.stream) {
-        P_TRY(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+    if (!a.e0) {
         P_TRY(hipEventCreate(&a.e0));
         P_TRY(hipEventCreate(&a.e1));
         a.prop = {};
@@ -453,9 +453,10 @@ int placed_configure(int device, const ginsim_placed_options& o) {
     return GINSIM_OK;
 }
 
-int placed_reserve(int device, size_t bytes) {
+int placed_reserve(int device, hipStream_t stream, size_t bytes) {
     Arena& a = *arena_of(device);
     std::lock_guard<std::mutex> lk(a.mu);
+    a.stream = stream;
     int rc = ensure_ready(a);
     if (rc) return rc;
     // what a first-fit carve of `bytes` (in up to a few regions) can count on: the free space
@@ -466,9 +467,10 @@ int placed_reserve(int device, size_t bytes) {
     return grow(a, (bytes - free_total + a.stripe() - 1) / a.stripe());
 }
 
-int placed_malloc(int device, size_t bytes, void** out) {
+int placed_malloc(int device, hipStream_t stream, size_t bytes, void** out) {
     Arena& a = *arena_of(device);
     std::lock_guard<std::mutex> lk(a.mu);
+    a.stream = stream;
     int rc = ensure_ready(a);
     if (rc) return rc;
     const size_t size = round_up(bytes ? bytes : 8, GRAIN);

@@ -11,8 +11,8 @@ namespace ginsim {
 // status: GINSIM_OK, GINSIM_ERR_PLACED (no usable arena on this device: the caller allocates with hipMalloc), GINSIM_ERR_NOMEM,
 // GINSIM_ERR_HIP; the message is left with set_error()
 int placed_configure(int device, const ginsim_placed_options& o);
-int placed_reserve(int device, size_t bytes);
-int placed_malloc(int device, size_t bytes, void** out);
+int placed_reserve(int device, hipStream_t stream, size_t bytes);        // stream: where the probes of a search run
+int placed_malloc(int device, hipStream_t stream, size_t bytes, void** out);
 bool placed_owns(int device, const void* p);
 int placed_free(int device, void* p);
 int placed_release(int device, bool force);
