@@ -561,9 +561,14 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(args.backend)
+    if args.shared_device and world > 1:
+        # TEST ONLY: every rank builds its arena on the ONE GPU they share -- each search may hold 1 / (2 N) of the device at
+        # most, so that the N > 1 control flow (arena search, then the collectives) runs on a one-GPU box without exhausting it
+        os.environ.setdefault('GINSIM_PLACED_BUDGET_GIB', '%d' % max(8, 288 // (2 * world)))
+        os.environ.setdefault('GINSIM_PLACED_LIMIT_GIB', '20')
     ctx = ginsim.Context(local_rank)
-    if args.placement == 'asis' or args.shared_device:      # (ranks sharing ONE GPU would each build an arena on it)
-        ctx.placed_enabled, ctx.placed_note = False, '--placement asis' if args.placement == 'asis' else '--shared-device'
+    if args.placement == 'asis':
+        ctx.placed_enabled, ctx.placed_note = False, '--placement asis'
 
     fs, rf = args.fs, args.ref_frame
     R = args.runs_per_gpu or (65536 if world == 1 else 131072)
@@ -601,6 +606,22 @@ def main():
             if ok:
                 ctx.comm_destroy()
             exchange, exchange_note = 'torch', exchange_note or 'abi exchange unavailable on another rank'
+    # what the communicators THEMSELVES say (ncclCommCount / UserRank / CuDevice), from every rank: the line's proof that RCCL saw N ranks
+    rccl_seen = None
+    if use_dist:
+        mine = None
+        if exchange == 'abi':
+            try:
+                mine = dict(zip(('ranks', 'rank', 'device'), ctx.comm_query()))
+            except Exception as e:                                 # noqa: BLE001
+                mine = {'error': repr(e)[:120]}
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        if rank == 0 and any(r is not None for r in rows):
+            counts = [r.get('ranks') for r in rows if r and 'ranks' in r]
+            rccl_seen = {'rccl_ranks': min(counts) if counts and len(counts) == world else None, 'every_rank': rows,
+                         'note': 'ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the library\'s own communicator on every rank '
+                                 '(ginsim_comm_query); rccl_ranks = the smallest count, None unless every rank answered'}
 
     def collect():
         """finish what can be finished: the all-reduce of batch s-2, then the record of batch s-1 -> issue its all-reduce"""
@@ -765,11 +786,15 @@ def main():
     per_rank = None
     if use_dist and world > 1:          # the slowest GPU sets the step time: make it visible in the line
         rows = [None] * world
+        unit_b = (BYTES_PER_SAMPLE_MC if args.precision == 'f64' else BYTES_PER_SAMPLE_MC // 2) if keep else 0
         dist.all_gather_object(rows, {'rank': rank, 'kernel_ms_avg': kern_avg_ms, 'kernel_ms_max': float(np.max(kern_ms)),
-                                      'device': ctx.name()})
+                                      'device': ctx.name(), 'placement': brief_placement(placement)})
         ks = [r['kernel_ms_avg'] for r in rows]
         per_rank = {'kernel_ms_avg': ks, 'min': min(ks), 'max': max(ks), 'argmax': int(np.argmax(ks)),
-                    'kernel_ms_max': [r['kernel_ms_max'] for r in rows]}
+                    'kernel_ms_max': [r['kernel_ms_max'] for r in rows],
+                    # every rank's own roofline: algorithmic bytes of ITS launch over ITS kernel time in the timed region
+                    'roofline_frac': [(unit_b * R * n + 72 * R) / (k * 1e-3) / 1e9 / HBM_PEAK_GBS for k in ks],
+                    'placement': [r['placement'] for r in rows]}
     assert merged.count == world * R, (merged.count, world * R)
 
     if args.pmc_child:      # every kernel a roofline object of the line is about, in the same passes
@@ -840,7 +865,7 @@ def main():
                        'runs': merged.count},
         }
         # where the planes lie -- top-level keys, so that the driver's record keeps them
-        out['placement'] = {'mode': args.placement if not args.shared_device else 'asis (--shared-device)',
+        out['placement'] = {'mode': args.placement,
                             'job': placement,
                             'note': 'placed = the library default (what an unconfigured Sim gets): the 15 output planes are carved from the '
                                     "device's placed arena, whose 512 MiB stripes cycle through the three classes of physical memory "
@@ -861,6 +886,10 @@ def main():
             out['cpu_baseline_note'] = 'omitted at N > 1: the CPU baseline is timed on rank 0 at N = 1 only (bench contract)'
         if single is not None:
             out['per_gpu_single'] = single
+            out['efficiency'] = out['value'] / (world * single['every_rank']['min'])
+            out['efficiency_note'] = 'value / (N x the slowest rank\'s single-GPU rate on the same per-GPU load): what this line says about scaling; the driver computes its own from the per-N values'
+        if rccl_seen is not None:
+            out.update(rccl_seen)
         if per_rank is not None:
             out['per_rank'] = per_rank
         if world == 1 and not args.no_legs:

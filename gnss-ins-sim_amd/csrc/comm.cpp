@@ -26,6 +26,9 @@ struct Api {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;           // optional: what the communicator itself says
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
     char err[256] = "";
@@ -51,6 +54,9 @@ Api& api() {
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(h, "ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
+        r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(dlsym(h, "ncclCommCuDevice"));
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
         if (!r.ok) snprintf(r.err, sizeof(r.err), "librccl lacks a symbol of the NCCL 2 API");
         return r;
@@ -110,6 +116,19 @@ void comm_destroy(Comm* c) {
 }
 
 int comm_nranks(const Comm* c) { return c ? c->nranks : 0; }
+
+// what the COMMUNICATOR answers (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), not what it was asked for: -1 where the
+// library lacks the query
+const char* comm_query(const Comm* c, int* nranks, int* rank, int* device) {
+    *nranks = *rank = *device = -1;
+    if (!c || !c->comm) return "no communicator";
+    Api& a = api();
+    ncclResult_t rc = 0;
+    if (a.CommCount && (rc = a.CommCount(c->comm, nranks)) != 0) return fail("ncclCommCount", rc);
+    if (a.CommUserRank && (rc = a.CommUserRank(c->comm, rank)) != 0) return fail("ncclCommUserRank", rc);
+    if (a.CommCuDevice && (rc = a.CommCuDevice(c->comm, device)) != 0) return fail("ncclCommCuDevice", rc);
+    return nullptr;
+}
 
 const char* comm_allgather_f64(Comm* c, const double* send, double* recv, size_t count, hipStream_t stream) {
     const ncclResult_t rc = api().AllGather(send, recv, count, kNcclDouble, c->comm, stream);

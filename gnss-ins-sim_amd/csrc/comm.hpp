@@ -13,6 +13,7 @@ const char* comm_unique_id(unsigned char* id128);
 const char* comm_create(int nranks, int rank, const unsigned char* id128, Comm** out);
 void comm_destroy(Comm* c);
 int comm_nranks(const Comm* c);
+const char* comm_query(const Comm* c, int* nranks, int* rank, int* device);      // read back from the communicator; -1 = query missing
 // all-gather `count` doubles per rank: send [count] -> recv [nranks][count], enqueued on `stream`
 const char* comm_allgather_f64(Comm* c, const double* send, double* recv, size_t count, hipStream_t stream);
 

@@ -531,6 +531,16 @@ int ginsim_comm_probe(void) {
     return GINSIM_OK;
 }
 
+int ginsim_comm_query(ginsim_ctx* c, int32_t* nranks, int32_t* rank, int32_t* device) {
+    REQUIRE(c && nranks && rank && device, "comm_query: bad arguments");
+    REQUIRE(c->comm, "comm_query: no communicator (ginsim_comm_init)");
+    int n = -1, r = -1, d = -1;
+    const char* err = comm_query(c->comm, &n, &r, &d);
+    if (err) { set_error("comm_query: %s", err); return GINSIM_ERR_HIP; }
+    *nranks = n; *rank = r; *device = d;
+    return GINSIM_OK;
+}
+
 int ginsim_comm_destroy(ginsim_ctx* c) {
     REQUIRE(c, "comm_destroy: NULL context");
     if (!c->comm) return GINSIM_OK;

@@ -134,6 +134,7 @@ _SIGS = {
     'ginsim_comm_unique_id': (C.c_int, [C.c_char_p]),
     'ginsim_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
     'ginsim_comm_destroy': (C.c_int, [C.c_void_p]),
+    'ginsim_comm_query': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'ginsim_end_stats_all_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     'ginsim_end_stats_all_finish': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     'ginsim_process_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _PD]),

@@ -106,24 +106,31 @@ def init_abi_comm(ctx, group=None, device=None):
     # failure like any other; its thread is abandoned (daemon), the context gets no communicator
     import threading
     limit = float(os.environ.get('GINSIM_COMM_INIT_TIMEOUT', '90'))
-    done, gave_up = {}, threading.Event()
+    done, state, lock = {}, {'gave_up': False}, threading.Lock()
 
     def work():
         try:
             ctx.comm_init(world, rank, box[0])
-            done['ok'] = True
-            if gave_up.is_set():            # the ranks agreed long ago that this communicator does not exist: drop it again
-                ctx.comm_destroy()
         except Exception as e:                  # noqa: BLE001
-            done['err'] = repr(e)
+            with lock:
+                done['err'] = repr(e)
+            return
+        with lock:                              # one lock decides who owns the outcome: either the main thread sees 'ok' ...
+            late = state['gave_up']
+            if not late:
+                done['ok'] = True
+        if late:                                # ... or the ranks agreed long ago that this communicator does not exist: drop it
+            ctx.comm_destroy()
     t = threading.Thread(target=work, name='ginsim-comm-init', daemon=True)
     t.start()
     t.join(limit)
-    if t.is_alive():
-        # the thread is still inside ncclCommInitRank on this context's handle: the context is poisoned -- it must not be
-        # destroyed under the thread (Context.close() leaks it while the thread lives), and a communicator that appears later
-        # is dropped by the thread itself and never used
-        gave_up.set()
+    with lock:
+        timed_out = not done                    # neither 'ok' nor 'err': the thread is still inside ncclCommInitRank
+        if timed_out:
+            state['gave_up'] = True
+    if timed_out:
+        # the context is poisoned -- it must not be destroyed under the thread (Context.close() leaks it while the thread lives),
+        # and a communicator that appears later is dropped by the thread itself and never used
         ctx._comm_abandoned = t
         problem = 'ncclCommInitRank did not return within %g s' % limit
     elif 'err' in done:

@@ -268,6 +268,12 @@ class Context(object):
         check(lib.ginsim_comm_init(self.handle, int(nranks), int(rank), bytes(unique_id)))
         self.comm_ranks = int(nranks)
 
+    def comm_query(self):
+        """(ranks, rank, device) as the communicator itself reports them (ncclCommCount / UserRank / CuDevice; -1 = query missing)."""
+        n, r, d = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        check(lib.ginsim_comm_query(self.handle, C.byref(n), C.byref(r), C.byref(d)))
+        return n.value, r.value, d.value
+
     def comm_destroy(self):
         if self.handle:
             check(lib.ginsim_comm_destroy(self.handle))

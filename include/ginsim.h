@@ -315,6 +315,9 @@ int ginsim_comm_unique_id(unsigned char* id /*[GINSIM_COMM_ID_BYTES]*/);
  * context is left without a communicator and may retry. */
 int ginsim_comm_init(ginsim_ctx* ctx, int32_t nranks, int32_t rank, const unsigned char* id);
 int ginsim_comm_destroy(ginsim_ctx* ctx);
+/* ABI 7: what the communicator ITSELF answers (ncclCommCount, ncclCommUserRank, ncclCommCuDevice) -- evidence that RCCL saw the
+ * ranks the caller meant, for the benchmark line (`rccl_ranks`); -1 where the loaded librccl lacks a query. */
+int ginsim_comm_query(ginsim_ctx* ctx, int32_t* nranks, int32_t* rank, int32_t* device);
 /* ginsim_end_stats_begin / _finish over ALL ranks: reduction of this rank's end errors (runs may be 0: an empty record) ->
  * all-gather of the 28-double records -> copy into pinned slot `slot` (0..7), all on the context's stream; _finish waits for
  * that slot only and returns the Chan merge of the non-empty records in rank order (the same on every rank). */

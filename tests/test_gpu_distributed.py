@@ -123,6 +123,25 @@ def test_rccl_exchange_executes_on_one_gpu():
     assert 'behind the C ABI' in abi['config']['parallelism'] and 'unavailable' not in abi['config']['parallelism'] \
         and 'disagreed' not in abi['config']['parallelism'], abi['config']['parallelism']
     assert abi['result'] == plain['result']
+    # the line's proof that RCCL saw the ranks: read back from the communicator itself (ncclCommCount / UserRank / CuDevice)
+    assert abi['rccl_ranks'] == 1 and abi['every_rank'] == [{'ranks': 1, 'rank': 0, 'device': 0}], abi.get('every_rank')
+    assert 'rccl_ranks' not in plain
+
+
+def test_arena_search_then_collectives_with_two_ranks():
+    """the N > 1 control flow WITH the placement -- every rank builds its placed arena (the chunk search, on
+    the one GPU they share, each holding a capped share of it), then the ranks meet in the collectives: per_gpu_single turns,
+    warm-up, timed steps, exchange.  16 384 runs per rank materialise 1.97 GB: placed by default.  The line carries every rank's
+    placement and roofline and its own efficiency figure."""
+    d = _bench(2, ['--steps', '4', '--warmup', '2', '--runs-per-gpu', '16384', '--cpu-baseline-seconds', '0', '--no-legs', '--pmc', 'off',
+                   '--backend', 'gloo', '--shared-device'], launcher=False)
+    assert d['n_gpus'] == 2 and d['result']['runs'] == 2 * 16384
+    pl = d['per_rank']['placement']
+    assert len(pl) == 2 and all(p['placed'] == ['imu', 'traj_free'] and sum(p['arena_stripes_of_class']) >= 4 for p in pl), pl
+    assert d['placement']['mode'] == 'placed' and d['placement']['job']['arena']['classes'] >= 2
+    assert len(d['per_rank']['roofline_frac']) == 2 and all(0.05 < f < 0.95 for f in d['per_rank']['roofline_frac'])
+    np.testing.assert_allclose(d['efficiency'], d['value'] / (2 * d['per_gpu_single']['every_rank']['min']), rtol=1e-12)
+    assert 'rccl_ranks' not in d                      # gloo: no communicator of the library's own to ask
 
 
 def test_abi_exchange_one_rank_communicator():
