@@ -124,15 +124,19 @@ def reference_python_baseline(budget_s):
     as BASELINE.md section 2 does) AND all host cores (multiprocessing over Sim.run(R / P)).  Timed here by
     tools/time_reference.py when the reference is importable (the build container), otherwise the committed, host-stamped
     record of that tool (profiles/reference_cpu.json), labelled as quoted."""
-    ref = '/root/reference'
-    if os.path.isdir(os.path.join(ref, 'gnss_ins_sim')):
+    # where the unmodified reference lies: $GNSS_INS_SIM_REFERENCE (the variable the drop-in's fall-through uses; the way to time
+    # the reference BESIDE the GPU on a GPU host -- README "reference CPU baseline"), else the build container's /root/reference
+    ref = os.environ.get('GNSS_INS_SIM_REFERENCE') or '/root/reference'
+    if os.path.isfile(os.path.join(ref, 'gnss_ins_sim', 'sim', 'ins_sim.py')) and os.path.isdir(os.path.join(ref, 'demo_motion_def_files')):
         runs = max(20, int(budget_s * 4.5e4 / 1000))
         try:
             out = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'time_reference.py'), '--runs', str(runs), '--json',
                                   '--no-write'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=40 * budget_s + 120,
-                                 universal_newlines=True, cwd=tempfile.gettempdir(), env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+                                 universal_newlines=True, cwd=tempfile.gettempdir(),
+                                 env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1', GNSS_INS_SIM_REFERENCE=ref))
             rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
             rec['kind'] = 'reference'
+            rec['timed_here'] = 'the unmodified reference at %s, in this run, on this host' % ref
             return rec
         except Exception as e:                                     # noqa: BLE001 -- a baseline must not fail the bench
             return {'value': None, 'kind': 'reference', 'error': repr(e)[:200]}
