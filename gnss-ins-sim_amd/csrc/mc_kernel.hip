@@ -810,19 +810,25 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
     // strictly more than 1/(k+1) of the LDS so that k+1 workgroups do not fit: 81 KB (k = 1), 54 KB (k = 2)
     const size_t lds = p.block_threads > 0 ? 0 : kLdsPerCu / (per_cu + 1) + 1024;
     const dim3 grid((unsigned)((p.runs + tb - 1) / tb)), block(tb);
-    if constexpr (WD && (ALGOS == GINSIM_ALGO_FREE || ALGOS == GINSIM_ALGO_ODO)) {
-        if (p.out_proc[ALGOS == GINSIM_ALGO_FREE ? 0 : 1]) {       // the general sensor model serves all PS launches
+    if constexpr (ALGOS == GINSIM_ALGO_FREE || ALGOS == GINSIM_ALGO_ODO) {
+        if (p.out_proc[ALGOS == GINSIM_ALGO_FREE ? 0 : 1]) {
             const bool ned = RF == 0 && p.proc_pos_ned;
-            if (any_vibration(p)) {
-                GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d, true>", RF, ALGOS, ned ? 2 : 1)
-                if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1, true>), grid, block, lds, stream, p);
-                else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1, true>), grid, block, lds, stream, p);
+            if constexpr (WD) {                     // the general sensor model: every statistics form, vibration included
+                if (any_vibration(p)) {
+                    GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d, true>", RF, ALGOS, ned ? 2 : 1)
+                    if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1, true>), grid, block, lds, stream, p);
+                    else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1, true>), grid, block, lds, stream, p);
+                    return hipGetLastError();
+                }
+                GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d, false>", RF, ALGOS, ned ? 2 : 1)
+                if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1>), grid, block, lds, stream, p);
+                else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1>), grid, block, lds, stream, p);
+                return hipGetLastError();
+            } else {                                // the simple model (every standard IMU grade), statistics in the state's own units
+                GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, false, 1, false>", RF, ALGOS)
+                hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, false, 1>), grid, block, lds, stream, p);
                 return hipGetLastError();
             }
-            GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d, false>", RF, ALGOS, ned ? 2 : 1)
-            if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1>), grid, block, lds, stream, p);
-            return hipGetLastError();
         }
     }
     if constexpr (WD) {
@@ -853,7 +859,12 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream, char* n
     }
     // the simple-model variant of the two-algorithm ref_frame 0 kernels is the one instantiation that spills: use the general one
     constexpr bool kSimpleFits = !(RF == 0 && ALGOS == (GINSIM_ALGO_FREE | GINSIM_ALGO_ODO));
-    if (any_white_drift(p) || any_vibration(p) || !kSimpleFits || p.out_proc[0] || p.out_proc[1]) return launch3<RF, ALGOS, true>(p, stream, name, cap);
+    // online process statistics: the simple model where the launch has no NED record to keep (round 6: that instantiation no longer
+    // spills -- 245 registers -- and saves the general model's 30 selects per step; with the NED record it would, 36 B per lane)
+    const bool proc = p.out_proc[0] || p.out_proc[1];
+    const bool general_ps = proc && getenv("GINSIM_PS_GENERAL") != nullptr;       // read per call: the tests compare the two kernels bit for bit
+    if (any_white_drift(p) || any_vibration(p) || !kSimpleFits || (proc && p.ref_frame == 0 && p.proc_pos_ned) || general_ps)
+        return launch3<RF, ALGOS, true>(p, stream, name, cap);
     if constexpr (kSimpleFits) return launch3<RF, ALGOS, false>(p, stream, name, cap);
     return hipErrorInvalidValue;
 }
@@ -1431,3 +1442,4 @@ hipError_t launch_gather_runs(const double* series, int C, int64_t n, int64_t ru
 }
 
 }  // namespace ginsim
+

@@ -260,7 +260,7 @@ def test_online_statistics_floor_for_a_constant_error(rf, algo):
     started 1e-3 rad / 0.5 m/s away from the truth.  Round 5: the online accumulator keeps its sums about the first in-window
     error (Proc<SHIFT> in csrc/mc_kernel.hip), so the std is the TRUE small value, as the kept-trajectory path (Welford) and the
     reference's np.std (ins_data_manager.py:761-795) give it.  The one exception is the ref_frame 0 free-integration kernel
-    (C3's: 251 VGPRs without the nine extra doubles), which keeps raw sums and with them a rounding floor of ~1.5e-8 |mean| on the
+    (C3's: 245-251 VGPRs without the nine extra doubles), which keeps raw sums and with them a rounding floor of ~1.5e-8 |mean| on the
     std; max and mean are unaffected everywhere."""
     import ginsim
     g = load_golden('t2_turn_rf%d' % rf)
@@ -288,6 +288,31 @@ def test_online_statistics_floor_for_a_constant_error(rf, algo):
             assert np.any(b[:, 2] < 1e-4 * np.abs(b[:, 1]))             # (the raw form is off by ~1.5e-8 |mean| here: >> 1e-7 std)
         online.release()
         kept.release()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rf,algo', [(0, 'free'), (0, 'odo'), (1, 'free'), (1, 'odo')])
+def test_simple_model_statistics_kernel_is_bit_identical_to_the_general_one(monkeypatch, rf, algo):
+    """Round 6: launches with online process statistics take the SIMPLE-sensor-model instantiation
+    (mc_kernel<RF, ALGO, false, false, 1>: no white-drift axis, no constant bias -- every standard IMU grade) where round 5 always
+    took the general one; C3 (rf 0, free) 0.99 -> 0.92 s.  x + 0.0 and the compiled-out selects change no bit: per-run statistics
+    and both end-point records equal the general kernel's ($GINSIM_PS_GENERAL forces it), which the goldens pin."""
+    import ginsim
+    from ginsim import workloads
+    ini, truth, _ = workloads.truth_from_profile('turn_90deg', 100.0, rf)
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    ctx = ginsim.default_context()
+    kw = dict(runs=700, seed=77, algos=(algo,), odo_err={'scale': 0.999, 'stdv': 0.1}, proc_first=13, end_ned=(rf == 0))
+    got = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv('GINSIM_PS_GENERAL', '1')
+        job = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc, gyr, ini, **kw).run()
+        assert job.kernel_name() == 'ginsim::mc_kernel<%d, %d, false, %s, 1, false>' % (rf, 1 if algo == 'free' else 2, 'true' if general else 'false')
+        got.append([job.process_stats_online(algo).copy(), job.end_errors(algo)] + ([job.end_errors(algo, ned=True)] if rf == 0 else []))
+        job.release()
+    for a, b in zip(*got):
+        np.testing.assert_array_equal(a, b)
 
 
 @pytest.mark.gpu
