@@ -646,6 +646,14 @@ def main():
             merged = m if m is not None else merged
         return merged
 
+    launched = [0]                      # launches of the headline kernel by this process so far (the kernel trace's index of a launch)
+    _launch = job.launch
+
+    def counted_launch():
+        launched[0] += 1
+        _launch()
+    job.launch = counted_launch
+
     def step(s):
         job.params.run_offset = (s * world + rank) * R      # a fresh batch of global run ids every step
         if s % stride == 0:
@@ -731,6 +739,7 @@ def main():
         step(s)
     drain()
     fence()
+    timed_first = launched[0]           # the timed steps are launches timed_first .. timed_first + steps - 1 of this kernel in this process
     t0 = time.perf_counter()
     for s in range(args.warmup, nsteps):
         step(s)
@@ -863,6 +872,9 @@ def main():
             'prewarm_ms': prewarm_ms,
             'roofline': roofline(alg_bytes, kern_avg_ms, kname, (traffic or {}).get(kname, {}).get('hbm_bytes_per_launch'),
                                  traffic_source=traffic_source,
+                                 timed_launches={'first': timed_first, 'count': args.steps,
+                                                 'note': 'zero-based index among the launches of this kernel at this grid size in the '
+                                                         'process: the rows of a rocprofv3 kernel trace of the same command to average'},
                                  note='writes exactly its algorithmic bytes; store-bound: a pure non-temporal fill of the same 15-plane '
                                       'pattern takes ~1.15 ms, see DESIGN.md section 4.1'),
             'result': {'att_std_deg': (merged.std[:3] * r2d).tolist(), 'vel_std_mps': merged.std[6:9].tolist(),

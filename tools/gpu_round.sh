@@ -42,3 +42,12 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_IN
 # 37 minutes of a gpurun call in round 4 -- so no pass of those blocks; every pass below a timeout)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_allan -o bench -- python $ROOT/tools/bench_allan.py > $OUT/prof_allan.json 2> $OUT/prof_allan.log
 du -sh $OUT
+# the summaries are made HERE (the raw databases do not fit the 64 MiB gpurun copies back): profiles/<tag>_* of this box's copy of the
+# repository -> gpurun_out/evidence_<tag>/; of the raw run the logs, the JSON lines and the kernel-trace database of the bench
+# command stay (what a reader needs to re-derive <tag>_kernel_trace_stats.csv), the counter databases go
+cd $ROOT
+python tools/summarize_prof.py $TAG --traffic > $OUT/summarize.log 2>&1; tail -2 $OUT/summarize.log
+mkdir -p gpurun_out/evidence_$TAG && cp profiles/${TAG}_* profiles/pmc_traffic.json gpurun_out/evidence_$TAG/ 2>/dev/null
+find $OUT -name "*.db" ! -path "*prof_trace*" -delete
+find $OUT -name "*.db" -size +45M -delete
+du -sh $OUT gpurun_out/evidence_$TAG
