@@ -589,3 +589,36 @@ def test_reported_kernel_names_are_the_compiled_kernels():
     for kw in cases:
         k = name(**kw)
         assert k in compiled, 'ginsim_mc_kernel_name reports %r for %r, which is not a compiled kernel' % (k, kw)
+
+
+def test_dropin_launcher_puts_the_drop_in_in_front_of_a_checkout_s_own_packages(tmp_path):
+    """Round 6 (found by executing the reference's demo_free_integration.py byte for byte): `python script.py` makes the SCRIPT's
+    directory sys.path[0], and in a checkout of the reference that directory holds the reference's own gnss_ins_sim/ and
+    demo_algorithms/ -- $PYTHONPATH alone does not shadow them.  gnss-ins-sim_amd/dropin.py runs the script with the drop-in first
+    and names the checkout for the fall-through.  Here: a stand-in "checkout" whose packages would raise on import."""
+    import subprocess
+    import sys
+    co = tmp_path / 'checkout'
+    for pkg in ('gnss_ins_sim', 'gnss_ins_sim/sim', 'demo_algorithms'):
+        (co / pkg).mkdir(parents=True)
+        (co / pkg / '__init__.py').write_text('raise ImportError("the checkout\'s own package was imported")\n')
+    (co / 'gnss_ins_sim' / 'sim' / 'ins_sim.py').write_text('raise ImportError("the checkout\'s own ins_sim was imported")\n')
+    (co / 'demo.py').write_text(
+        'import os, sys\n'
+        'from gnss_ins_sim.sim import imu_model\n'
+        'from demo_algorithms import free_integration\n'
+        'print("IMU", imu_model.__file__)\n'
+        'print("ALGO", free_integration.__file__)\n'
+        'print("REF", os.environ.get("GNSS_INS_SIM_REFERENCE"))\n'
+        'print("ARGV", sys.argv)\n')
+    env = {k: v for k, v in os.environ.items() if k not in ('PYTHONPATH', 'GNSS_INS_SIM_REFERENCE')}
+    out = subprocess.run([sys.executable, os.path.join(PKG, 'dropin.py'), 'demo.py', '--flag'], cwd=str(co), env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
+    assert out.returncode == 0, out.stdout
+    lines = dict(l.split(' ', 1) for l in out.stdout.splitlines() if ' ' in l)
+    assert os.path.abspath(lines['IMU']).startswith(os.path.abspath(PKG)) and os.path.abspath(lines['ALGO']).startswith(os.path.abspath(PKG))
+    assert lines['REF'] == str(co) and lines['ARGV'] == "['demo.py', '--flag']"
+    # the plain way fails exactly as a user in a checkout would see it: the checkout's packages win
+    plain = subprocess.run([sys.executable, 'demo.py'], cwd=str(co), env=dict(env, PYTHONPATH=PKG), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
+    assert plain.returncode != 0 and "the checkout's own package was imported" in plain.stdout
