@@ -185,6 +185,7 @@ int ginsim_destroy(ginsim_ctx* c) {
     for (hipEvent_t e : c->comm_ev)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
+    ginsim::placed_free_owner(c->device, c);          // regions this context carved and never freed go back to the free list
     ginsim::placed_context_destroyed(c->device);      // the device's last context gives its placed arena back
     delete c;
     return GINSIM_OK;
@@ -218,7 +219,7 @@ int ginsim_placed_reserve(ginsim_ctx* c, size_t bytes) {
 
 int ginsim_malloc_placed(ginsim_ctx* c, size_t bytes, void** dptr) {
     REQUIRE(c && dptr, "malloc_placed: bad arguments");
-    return ginsim::placed_malloc(c->device, c->stream, bytes, dptr);
+    return ginsim::placed_malloc(c->device, c->stream, bytes, c, dptr);
 }
 
 int ginsim_placed_release(ginsim_ctx* c) {

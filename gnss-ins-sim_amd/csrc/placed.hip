@@ -93,7 +93,8 @@ struct Arena {
     std::vector<Chunk> stripes;
     Chunk ref[3]; int nref = 0;                         // each in a reservation of its own (stripe bytes)
     double anchor_ms = 0.0;                             // s: the time of a same-class pair fill (2 x the fastest single-window fill)
-    std::map<size_t, size_t> free_, used_;              // offset -> bytes
+    std::map<size_t, size_t> free_;                     // offset -> bytes
+    std::map<size_t, std::pair<size_t, const void*>> used_;      // offset -> (bytes, the context that carved it)
     size_t used_bytes = 0;
     int contexts = 0;
     // report
@@ -269,6 +270,10 @@ int grow(Arena& a, size_t add) {
     const size_t keep_free = 2 * GiB;
     const size_t budget = std::min((size_t)a.opt.budget_bytes, fr > keep_free ? fr - keep_free : 0) / S;
     if (budget < add + (size_t)(3 - a.nref)) {
+        if ((size_t)a.opt.budget_bytes / S < add + (size_t)(3 - a.nref)) {         // the option, not the device, is what is short
+            set_error("placed memory: a search budget of %.1f GiB cannot hold a request of %.1f GiB and the references", a.opt.budget_bytes / (double)GiB, add * S / (double)GiB);
+            return GINSIM_ERR_PLACED;
+        }
         set_error("placed memory: %.1f GiB free on device %d, %.1f GiB wanted", fr / (double)GiB, a.device, add * S / (double)GiB);
         return GINSIM_ERR_NOMEM;
     }
@@ -437,6 +442,17 @@ void drop_all(Arena& a) {
     a.failed = false;
 }
 
+// a carved region back to the free list, merged with its neighbours
+void give_back(Arena& a, std::map<size_t, std::pair<size_t, const void*>>::iterator it) {
+    size_t o = it->first, len = it->second.first;
+    a.used_bytes -= len;
+    a.used_.erase(it);
+    auto nx = a.free_.lower_bound(o);
+    if (nx != a.free_.end() && o + len == nx->first) { len += nx->second; nx = a.free_.erase(nx); }
+    if (nx != a.free_.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == o) { o = pv->first; len += pv->second; a.free_.erase(pv); } }
+    a.free_[o] = len;
+}
+
 }  // namespace
 
 int placed_configure(int device, const ginsim_placed_options& o) {
@@ -467,7 +483,7 @@ int placed_reserve(int device, hipStream_t stream, size_t bytes) {
     return grow(a, (bytes - free_total + a.stripe() - 1) / a.stripe());
 }
 
-int placed_malloc(int device, hipStream_t stream, size_t bytes, void** out) {
+int placed_malloc(int device, hipStream_t stream, size_t bytes, const void* owner, void** out) {
     Arena& a = *arena_of(device);
     std::lock_guard<std::mutex> lk(a.mu);
     a.stream = stream;
@@ -480,7 +496,7 @@ int placed_malloc(int device, hipStream_t stream, size_t bytes, void** out) {
             const size_t off = it->first, len = it->second;
             a.free_.erase(it);
             if (len > size) a.free_[off + size] = len - size;
-            a.used_[off] = size;
+            a.used_[off] = {size, owner};
             a.used_bytes += size;
             *out = a.va + off;
             return GINSIM_OK;
@@ -507,14 +523,19 @@ int placed_free(int device, void* p) {
     const size_t off = (size_t)((char*)p - a.va);
     auto it = a.used_.find(off);
     if (it == a.used_.end()) { set_error("placed memory: %p is not the start of a region carved from the arena of device %d", p, device); return GINSIM_ERR_ARG; }
-    size_t o = it->first, len = it->second;
-    a.used_bytes -= len;
-    a.used_.erase(it);
-    auto nx = a.free_.lower_bound(o);
-    if (nx != a.free_.end() && o + len == nx->first) { len += nx->second; nx = a.free_.erase(nx); }
-    if (nx != a.free_.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == o) { o = pv->first; len += pv->second; a.free_.erase(pv); } }
-    a.free_[o] = len;
+    give_back(a, it);
     return GINSIM_OK;
+}
+
+// a context is going away: what it carved and never freed (buffers that outlive their context, garbage collected in any order)
+// returns to the free list
+void placed_free_owner(int device, const void* owner) {
+    Arena& a = *arena_of(device);
+    std::lock_guard<std::mutex> lk(a.mu);
+    for (auto it = a.used_.begin(); it != a.used_.end();) {
+        auto cur = it++;
+        if (cur->second.second == owner) give_back(a, cur);
+    }
 }
 
 int placed_release(int device, bool force) {

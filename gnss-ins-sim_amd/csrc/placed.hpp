@@ -12,7 +12,8 @@ namespace ginsim {
 // GINSIM_ERR_HIP; the message is left with set_error()
 int placed_configure(int device, const ginsim_placed_options& o);
 int placed_reserve(int device, hipStream_t stream, size_t bytes);        // stream: where the probes of a search run
-int placed_malloc(int device, hipStream_t stream, size_t bytes, void** out);
+int placed_malloc(int device, hipStream_t stream, size_t bytes, const void* owner, void** out);
+void placed_free_owner(int device, const void* owner);                   // everything `owner` carved and did not free
 bool placed_owns(int device, const void* p);
 int placed_free(int device, void* p);
 int placed_release(int device, bool force);

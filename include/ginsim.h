@@ -60,7 +60,8 @@ int  ginsim_free(ginsim_ctx* ctx, void* dptr);   /* regions of ginsim_malloc and
  * takes 1.3-1.9 x the time of a pair in different classes).  Chunks are created until every class has its share of the request
  * (or the budget is spent: then two classes, or GINSIM_ERR_PLACED), the rest is given back to the driver.  Every region carved
  * from the arena larger than a stripe spans the classes, whatever its planes' sizes; regions are handed out by a first-fit free
- * list and the arena grows by whole stripes.  The reference has no counterpart (its arrays are NumPy's). */
+ * list and the arena grows by whole stripes.  ginsim_destroy returns what its context carved and never freed; the device's last
+ * context gives the arena's memory back.  The reference has no counterpart (its arrays are NumPy's). */
 typedef struct {
     int64_t stripe_bytes;       /* 0: 512 MiB.  A power of two >= 64 MiB (below 512 MiB a chunk no longer lies in ONE class) */
     int64_t budget_bytes;       /* 0: 200 GiB.  Most physical memory one search may hold while it looks for the classes */

@@ -197,3 +197,45 @@ def test_the_unconfigured_sim_gets_placed_planes_and_the_same_statistics():
     np.testing.assert_array_equal(run7[0], run7[1])
     small = _sim(64)
     assert small.placement['placed'] == []
+
+
+def test_no_usable_arena_means_plain_hipmalloc_not_an_error(ctx):
+    """A search whose budget cannot hold the request (here: three chunks), or that cannot tell two classes apart, ends as GINSIM_ERR_PLACED; the
+    context remembers why, jobs fall back to plain hipMalloc planes and compute the same bits.  A limit smaller than a request
+    likewise.  Re-configuring (with nothing carved) gives the arena back its defaults."""
+    import ctypes as C
+    import gc
+    import ginsim
+    from ginsim import _lib
+    gc.collect()                        # the Sims of the test before this one hold regions of the device's arena until they are collected
+    ctx.sync()
+    ctx.release_pool()
+    assert ctx.placed_info()['mapped_bytes'] == 0, ctx.placed_info()
+    tiny = _lib.PlacedOptions(stripe_bytes=512 << 20, budget_bytes=3 * (512 << 20), limit_bytes=0, search_seconds=0.0)
+    assert ginsim.lib.ginsim_placed_configure(ctx.handle, C.byref(tiny)) == 0
+    other = ginsim.Context(0)           # a fresh context: its own enabled / note state, the device's arena
+    try:
+        assert other.placed_reserve(2 * G) is False
+        assert not other.placed_enabled and 'budget' in other.placed_note, other.placed_note
+        job = _job(other, runs=8192, n=1000, algos=('free',), keep_sensors=True, keep_traj=True, placed=True).run()        # asks, gets plain planes
+        assert job.placement()['placed'] == [] and job.placement()['arena']['available'] == 0
+        ref = _job(ctx, runs=8192, n=1000, algos=('free',), keep_sensors=True, keep_traj=True, placed=False).run()
+        np.testing.assert_array_equal(job.end_errors('free'), ref.end_errors('free'))
+        job.release(); ref.release()
+    finally:
+        other.close()
+    # a limit of one stripe: the arena exists but cannot take a 2 GiB request
+    small = _lib.PlacedOptions(stripe_bytes=0, budget_bytes=0, limit_bytes=512 << 20, search_seconds=0.0)
+    assert ginsim.lib.ginsim_placed_configure(ctx.handle, C.byref(small)) == 0
+    third = ginsim.Context(0)
+    try:
+        assert third.placed_reserve(2 * G) is False and 'limit' in third.placed_note, third.placed_note
+    finally:
+        third.close()
+    # defaults again
+    assert ginsim.lib.ginsim_placed_configure(ctx.handle, C.byref(_lib.PlacedOptions())) == 0
+    assert ctx.placed_reserve(1 * G), ctx.placed_note
+    assert ctx.placed_info()['available'] == 1
+    # configuring while the arena exists is refused
+    with pytest.raises(ValueError, match='exists already'):
+        _lib.check(ginsim.lib.ginsim_placed_configure(ctx.handle, C.byref(tiny)))
