@@ -83,7 +83,7 @@ struct Arena {
     int device = 0;
     std::mutex mu;
     ginsim_placed_options opt{};
-    bool configured = false, vmm_checked = false, vmm_ok = false, failed = false;
+    bool configured = false, vmm_checked = false, vmm_ok = false, failed = false, no_growth = false;
     hipStream_t stream = nullptr;                       // the stream of the context that asked (probes run on it: a stream of the arena's own
                                                         // would shift every later stream of the process to another hardware queue)
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -261,6 +261,10 @@ bool plan(size_t add, const std::vector<size_t>* of, size_t* takes) {
 // Add `add` stripes to the arena: create chunks, find their classes, deal them to the range, give the rest back.
 int grow(Arena& a, size_t add) {
     const size_t S = a.stripe();
+    if (a.no_growth) {
+        set_error("placed memory: the arena of device %d stopped growing after a mapping failure", a.device);
+        return GINSIM_ERR_PLACED;
+    }
     if ((a.stripes.size() + add) * S > a.va_bytes) {
         set_error("placed memory: the arena of device %d would exceed its limit of %.1f GiB", a.device, a.va_bytes / (double)GiB);
         return GINSIM_ERR_PLACED;
@@ -402,11 +406,20 @@ int grow(Arena& a, size_t add) {
             }
         }
         for (Chunk& c : pool) if (c.taken) (void)hipMemRelease(c.h);       // (a map failed: what was not reached)
-        if (a.stripes.size() > first && hipMemSetAccess(a.va + first * S, (a.stripes.size() - first) * S, &a.access, 1) != hipSuccess) {
+        if (rc == GINSIM_OK && a.stripes.size() > first &&
+            hipMemSetAccess(a.va + first * S, (a.stripes.size() - first) * S, &a.access, 1) != hipSuccess) {
             set_error("placed memory: hipMemSetAccess on the arena failed");
             rc = GINSIM_ERR_HIP;
         }
-        if (a.stripes.size() > first) {         // the new stripes are free space; merge with a free block that ends where they begin
+        if (rc != GINSIM_OK) {                  // nothing half-mapped stays behind: the new stripes go back, the arena is what it was
+            while (a.stripes.size() > first) {
+                (void)unmap_chunk(a, a.stripes.back());
+                (void)hipMemRelease(a.stripes.back().h);
+                a.stripes.pop_back();
+            }
+            (void)driver_flush();
+            a.no_growth = true;                 // the addresses above `first` were mapped once: this arena does not grow again
+        } else if (a.stripes.size() > first) {  // the new stripes are free space; merge with a free block that ends where they begin
             size_t off = first * S, len = (a.stripes.size() - first) * S;
             if (!a.free_.empty()) {
                 auto last = std::prev(a.free_.end());
@@ -439,7 +452,7 @@ void drop_all(Arena& a) {
     a.nref = 0;
     a.anchor_ms = 0.0;
     a.free_.clear(); a.used_.clear(); a.used_bytes = 0;
-    a.failed = false;
+    a.failed = a.no_growth = false;
 }
 
 // a carved region back to the free list, merged with its neighbours
