@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "placed.hpp"
+#include "placed_logic.hpp"
 
 namespace ginsim {
 
@@ -93,9 +94,7 @@ struct Arena {
     std::vector<Chunk> stripes;
     Chunk ref[3]; int nref = 0;                         // each in a reservation of its own (stripe bytes)
     double anchor_ms = 0.0;                             // s: the time of a same-class pair fill (2 x the fastest single-window fill)
-    std::map<size_t, size_t> free_;                     // offset -> bytes
-    std::map<size_t, std::pair<size_t, const void*>> used_;      // offset -> (bytes, the context that carved it)
-    size_t used_bytes = 0;
+    placed::FreeList regions;                           // what is carved from the mapped part of the range, and by which context
     int contexts = 0;
     // report
     int searches = 0; int64_t created = 0, ambiguous = 0, probes = 0, peak_held = 0; double search_s = 0.0, last_s = 0.0;
@@ -230,34 +229,6 @@ int window_ms(Arena& a, char* x, double* ms) {
     return timed(a, [&] { hipLaunchKernelGGL(placed_window_fill, dim3(PROBE_BLOCKS), dim3(256), 0, a.stream, (d2*)x, rows); }, 3, ms);
 }
 
-// the order of the classes inside the t-th group of three stripes: one of the six permutations, chosen by a hash of t, so that no
-// plane stride meets the same class at every one of its planes
-void group_order(size_t t, int* order) {
-    static const int perm[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {2, 1, 0}, {1, 0, 2}};
-    const uint32_t h = ((uint32_t)t * 2654435761u) >> 13;
-    for (int i = 0; i < 3; ++i) order[i] = perm[h % 6][i];
-}
-
-// How many chunks each class gives to a request of `add` stripes: equal shares, the others making up what a short class lacks.
-// false: not enough chunks, or (four stripes and more) one class would give more than three quarters of them.
-bool plan(size_t add, const std::vector<size_t>* of, size_t* takes) {
-    takes[0] = takes[1] = takes[2] = 0;
-    size_t need = add;
-    while (need > 0) {
-        int active = 0;
-        for (int c = 0; c < 3; ++c) active += takes[c] < of[c].size();
-        if (!active) return false;
-        const size_t share = (need + active - 1) / active;
-        for (int c = 0; c < 3 && need > 0; ++c) {
-            const size_t g = std::min({share, of[c].size() - takes[c], need});
-            takes[c] += g;
-            need -= g;
-        }
-    }
-    if (add < 4) return true;
-    return 4 * std::max({takes[0], takes[1], takes[2]}) <= 3 * add;
-}
-
 // Add `add` stripes to the arena: create chunks, find their classes, deal them to the range, give the rest back.
 int grow(Arena& a, size_t add) {
     const size_t S = a.stripe();
@@ -301,7 +272,8 @@ int grow(Arena& a, size_t add) {
         if (a.nref == 3 && usable(3) >= add) break;                         // every class can give its third
         if (now_s() - t0 > a.opt.search_seconds) {                          // out of time: settle for an uneven deal if there is one
             size_t tk[3];
-            if (plan(add, of, tk) || now_s() - t0 > 3.0 * a.opt.search_seconds) break;
+            const size_t have[3] = {of[0].size(), of[1].size(), of[2].size()};
+            if (placed::plan(add, have, tk) || now_s() - t0 > 3.0 * a.opt.search_seconds) break;
         }
         Chunk c;
         if (hipMemCreate(&c.h, S, &a.prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }      // out of memory: settle
@@ -351,7 +323,8 @@ int grow(Arena& a, size_t add) {
     // settle: every class gives an equal share of `add`; what a short class cannot give the others make up (water-filling).
     // A request of four stripes or more must come from at least two classes with no class giving more than three quarters.
     size_t takes[3] = {0, 0, 0};
-    if (rc == GINSIM_OK && !plan(add, of, takes)) {
+    const size_t have[3] = {of[0].size(), of[1].size(), of[2].size()};
+    if (rc == GINSIM_OK && !placed::plan(add, have, takes)) {
         set_error("placed memory: device %d: %d class(es) of physical memory told apart within %.0f GiB / %.1f s (chunks by class: %zu %zu %zu, wanted %zu)",
                   a.device, a.nref, pool.size() * S / (double)GiB, now_s() - t0, of[0].size(), of[1].size(), of[2].size(), add);
         rc = GINSIM_ERR_PLACED;
@@ -389,21 +362,14 @@ int grow(Arena& a, size_t add) {
     }
     if (rc == GINSIM_OK) {
         const size_t first = a.stripes.size();
-        size_t next[3] = {0, 0, 0}, placed = 0;
-        for (size_t g = 0; placed < add && rc == GINSIM_OK; ++g) {
-            int order[3];
-            group_order(first / 3 + g, order);
-            for (int j = 0; j < 3 && placed < add && rc == GINSIM_OK; ++j) {
-                const int c = order[j];
-                if (next[c] >= takes[c]) continue;          // this class has given its share
-                Chunk& src = pool[of[c][next[c]++]];
-                Chunk ch = src;
-                ch.taken = ch.is_ref = false;
-                if ((rc = map_chunk(a, ch, a.va + a.stripes.size() * S)) != GINSIM_OK) break;
-                src.taken = false;                          // it is the arena's now
-                a.stripes.push_back(ch);
-                ++placed;
-            }
+        size_t next[3] = {0, 0, 0};
+        for (const int c : placed::deal(first, add, takes)) {       // the classes of the new stripes, in address order
+            Chunk& src = pool[of[c][next[c]++]];
+            Chunk ch = src;
+            ch.taken = ch.is_ref = false;
+            if ((rc = map_chunk(a, ch, a.va + a.stripes.size() * S)) != GINSIM_OK) break;
+            src.taken = false;                              // it is the arena's now
+            a.stripes.push_back(ch);
         }
         for (Chunk& c : pool) if (c.taken) (void)hipMemRelease(c.h);       // (a map failed: what was not reached)
         if (rc == GINSIM_OK && a.stripes.size() > first &&
@@ -419,13 +385,8 @@ int grow(Arena& a, size_t add) {
             }
             (void)driver_flush();
             a.no_growth = true;                 // the addresses above `first` were mapped once: this arena does not grow again
-        } else if (a.stripes.size() > first) {  // the new stripes are free space; merge with a free block that ends where they begin
-            size_t off = first * S, len = (a.stripes.size() - first) * S;
-            if (!a.free_.empty()) {
-                auto last = std::prev(a.free_.end());
-                if (last->first + last->second == off) { off = last->first; len += last->second; a.free_.erase(last); }
-            }
-            a.free_[off] = len;
+        } else if (a.stripes.size() > first) {
+            a.regions.extend((a.stripes.size() - first) * S);       // the new stripes are free space
         }
     }
     a.last_s = now_s() - t0;
@@ -451,19 +412,8 @@ void drop_all(Arena& a) {
     (void)hipGetLastError();
     a.nref = 0;
     a.anchor_ms = 0.0;
-    a.free_.clear(); a.used_.clear(); a.used_bytes = 0;
+    a.regions.clear();
     a.failed = a.no_growth = false;
-}
-
-// a carved region back to the free list, merged with its neighbours
-void give_back(Arena& a, std::map<size_t, std::pair<size_t, const void*>>::iterator it) {
-    size_t o = it->first, len = it->second.first;
-    a.used_bytes -= len;
-    a.used_.erase(it);
-    auto nx = a.free_.lower_bound(o);
-    if (nx != a.free_.end() && o + len == nx->first) { len += nx->second; nx = a.free_.erase(nx); }
-    if (nx != a.free_.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == o) { o = pv->first; len += pv->second; a.free_.erase(pv); } }
-    a.free_[o] = len;
 }
 
 }  // namespace
@@ -489,8 +439,7 @@ int placed_reserve(int device, hipStream_t stream, size_t bytes) {
     int rc = ensure_ready(a);
     if (rc) return rc;
     // what a first-fit carve of `bytes` (in up to a few regions) can count on: the free space
-    size_t free_total = 0;
-    for (auto& f : a.free_) free_total += f.second;
+    const size_t free_total = a.regions.free_total();
     bytes = round_up(bytes, GRAIN) + 4 * GRAIN;
     if (free_total >= bytes) return GINSIM_OK;
     return grow(a, (bytes - free_total + a.stripe() - 1) / a.stripe());
@@ -504,19 +453,13 @@ int placed_malloc(int device, hipStream_t stream, size_t bytes, const void* owne
     if (rc) return rc;
     const size_t size = round_up(bytes ? bytes : 8, GRAIN);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        for (auto it = a.free_.begin(); it != a.free_.end(); ++it) {
-            if (it->second < size) continue;
-            const size_t off = it->first, len = it->second;
-            a.free_.erase(it);
-            if (len > size) a.free_[off + size] = len - size;
-            a.used_[off] = {size, owner};
-            a.used_bytes += size;
+        size_t off = 0;
+        if (a.regions.carve(size, owner, &off)) {
             *out = a.va + off;
             return GINSIM_OK;
         }
         if (attempt) break;
-        size_t tail = 0;                        // a free block that ends where the mapped range ends is extended by the growth
-        if (!a.free_.empty()) { auto last = std::prev(a.free_.end()); if (last->first + last->second == a.mapped()) tail = last->second; }
+        const size_t tail = a.regions.free_tail();          // a free block at the end of the mapped range is extended by the growth
         rc = grow(a, (size - tail + a.stripe() - 1) / a.stripe());
         if (rc) return rc;
     }
@@ -533,10 +476,10 @@ bool placed_owns(int device, const void* p) {
 int placed_free(int device, void* p) {
     Arena& a = *arena_of(device);
     std::lock_guard<std::mutex> lk(a.mu);
-    const size_t off = (size_t)((char*)p - a.va);
-    auto it = a.used_.find(off);
-    if (it == a.used_.end()) { set_error("placed memory: %p is not the start of a region carved from the arena of device %d", p, device); return GINSIM_ERR_ARG; }
-    give_back(a, it);
+    if (!a.regions.give_back((size_t)((char*)p - a.va))) {
+        set_error("placed memory: %p is not the start of a region carved from the arena of device %d", p, device);
+        return GINSIM_ERR_ARG;
+    }
     return GINSIM_OK;
 }
 
@@ -545,16 +488,13 @@ int placed_free(int device, void* p) {
 void placed_free_owner(int device, const void* owner) {
     Arena& a = *arena_of(device);
     std::lock_guard<std::mutex> lk(a.mu);
-    for (auto it = a.used_.begin(); it != a.used_.end();) {
-        auto cur = it++;
-        if (cur->second.second == owner) give_back(a, cur);
-    }
+    (void)a.regions.give_back_all_of(owner);
 }
 
 int placed_release(int device, bool force) {
     Arena& a = *arena_of(device);
     std::lock_guard<std::mutex> lk(a.mu);
-    if (!a.used_.empty() && !force) return GINSIM_OK;
+    if (!a.regions.nothing_carved() && !force) return GINSIM_OK;
     drop_all(a);
     return GINSIM_OK;
 }
@@ -575,7 +515,7 @@ void placed_info(int device, ginsim_placed_info* out) {
     out->failed = a.failed;
     out->stripe_bytes = a.opt.stripe_bytes;
     out->mapped_bytes = (int64_t)a.mapped();
-    out->used_bytes = (int64_t)a.used_bytes;
+    out->used_bytes = (int64_t)a.regions.used_bytes();
     out->limit_bytes = a.opt.limit_bytes;
     out->chunks_created = a.created;
     out->chunks_ambiguous = a.ambiguous;

@@ -622,3 +622,16 @@ def test_dropin_launcher_puts_the_drop_in_in_front_of_a_checkout_s_own_packages(
     plain = subprocess.run([sys.executable, 'demo.py'], cwd=str(co), env=dict(env, PYTHONPATH=PKG), stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
     assert plain.returncode != 0 and "the checkout's own package was imported" in plain.stdout
+
+
+def test_placed_arena_logic_on_the_host(tmp_path):
+    """The device-free parts of the placed arena (csrc/placed_logic.hpp: the first-fit free list with owners, the plan of how many
+    chunks each class gives, the order of the classes over the stripes) compiled with g++ and checked on the CPU
+    (tests/cpp/placed_logic_check.cpp): 20 000 random carve / give-back operations without overlap or lost bytes, the three-quarters
+    rule, planes of exactly three stripes spread over the classes."""
+    import subprocess
+    exe = str(tmp_path / 'placed_logic_check')
+    subprocess.run(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I' + os.path.join(PKG, 'csrc'), '-o', exe,
+                    os.path.join(REPO, 'tests', 'cpp', 'placed_logic_check.cpp')], check=True, timeout=300)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == 'ok', out.stdout
