@@ -27,7 +27,7 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 
-hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap);      // name: report, do not launch
+hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap, double* proc_about);      // name: report, do not launch
 hipError_t launch_mc_f32(const ginsim_mc_params& p, float* truth32, hipStream_t stream, char* name, size_t cap);
 size_t mc_f32_truth_bytes(const ginsim_mc_params& p);
 int mc_variant(const ginsim_mc_params& p);
@@ -359,7 +359,7 @@ int ginsim_mc_kernel_name(const ginsim_mc_params* p, char* buf, size_t cap) {
     if (p->precision == 1) (void)launch_mc_f32(*p, nullptr, nullptr, buf, cap);
     else if (series_path_applies(*p))       // the dominant one of series_kernel<0>, series_scan_kernel, series_kernel<1 | 2>
         snprintf(buf, cap, "ginsim::series_kernel<%d>", series_pass_b(*p));
-    else (void)launch_mc(*p, nullptr, buf, cap);
+    else (void)launch_mc(*p, nullptr, buf, cap, nullptr);
     REQUIRE(buf[0], "mc_kernel_name: no kernel serves these parameters");
     return GINSIM_OK;
 }
@@ -381,7 +381,9 @@ int ginsim_mc_run(ginsim_ctx* c, const ginsim_mc_params* p) {
         HIP_TRY(scratch(c, 3, sizeof(double) * 6 * (size_t)nchunks * (size_t)p->runs, &carry));
         HIP_TRY(launch_series(*p, reinterpret_cast<double*>(carry), c->stream));
     } else {
-        HIP_TRY(launch_mc(*p, c->stream, nullptr, 0));
+        void* about = nullptr;          // the launch-wide shift of the online process statistics (mc_kernel.hip, Proc): nine doubles
+        if (p->out_proc[0] || p->out_proc[1]) HIP_TRY(scratch(c, 3, 9 * sizeof(double), &about));
+        HIP_TRY(launch_mc(*p, c->stream, nullptr, 0, reinterpret_cast<double*>(about)));
     }
     return GINSIM_OK;
 }
@@ -395,6 +397,7 @@ static int check_mc_params(const ginsim_mc_params* p) {
     REQUIRE(p->runs <= (int64_t)0x7FFFFFFF * 64, "mc_run: too many runs for one launch");
     REQUIRE(p->fs > 0.0, "mc_run: fs must be positive");
     REQUIRE(p->ref_frame == 0 || p->ref_frame == 1, "mc_run: ref_frame must be 0 or 1");
+    REQUIRE(p->proc_plain_sums == 0 || p->proc_plain_sums == 1, "mc_run: proc_plain_sums must be 0 or 1");
     REQUIRE(p->algo_mask >= 0 && p->algo_mask <= 3, "mc_run: algo_mask must be a combination of GINSIM_ALGO_*");
     REQUIRE(p->algo_mask != 0 || (!p->given_sensors && (p->out_accel || p->out_gyro || p->out_odo)),
             "mc_run: algo_mask 0 (sensors only) needs sensor outputs");

@@ -202,12 +202,11 @@ __device__ __forceinline__ double angle_range_pi_mul(double x) {
 // sum e^2 / n - mean^2 with a relative rounding error of ~ 2^-53 (1 + mean^2 / var) sqrt(n) -- 1e-12 for mean^2 / var up
 // to 1e3 at n = 2e5.  process_stats_kernel (stats.hip), which reads kept trajectories, keeps the Welford / Chan-merge form
 // and is the checker: the two agree to 1e-9 relative (tests/test_process_stats.py), the online form to 1e-7 with the oracle.
-// The floor of the raw form (still what the ref_frame 0 free-integration and the vibration variants run; every other variant
-// shifts the sums, see Proc): an error that is (nearly) CONSTANT over the window -- a noise-free or ideal IMU with an initial
+// The floor of the raw form: an error that is (nearly) CONSTANT over the window -- a noise-free or ideal IMU with an initial
 // offset, a deterministic bias -- has var << mean^2, and what sum e^2 / n - mean^2 leaves of a std below ~1.5e-8 |mean| is
-// rounding (clamped at 0 here).  The kept-trajectory path has no such floor; a shift about the first sample's error would
-// remove it at the price of 18 more registers, which the ref_frame 0 variants (251 VGPRs) do not have
-// (tests/test_process_stats.py::test_online_statistics_floor_for_a_constant_error pins the bound).
+// rounding (clamped at 0 here).  No variant runs the raw form any more: the sums are kept about an error close to the mean,
+// per lane where the registers are there, per launch where they are not (see Proc;
+// tests/test_process_stats.py::test_online_statistics_floor_for_a_constant_error).
 // The attitude error is wrapped to [-pi, pi] only when some lane of the wavefront is outside it (wrap_pi3).
 __device__ __forceinline__ double wrap_pi_lane(double x) { return fabs(x) <= kPi ? x : angle_range_pi_mul(x); }
 
@@ -218,58 +217,6 @@ __device__ __forceinline__ void wrap_pi3(double (&e)[9]) {
     }
 }
 
-// SHIFT (round 5): the sums are kept about the FIRST in-window error of the run (sum (e - e0), sum (e - e0)^2): a (nearly)
-// constant error then leaves var = sum d^2 / n - (sum d / n)^2 with d of the size of the error's VARIATION, and the floor of the
-// raw form (~1.5e-8 |mean| on the std) is gone.  Nine more doubles per lane: every process-statistics variant takes them except
-// the ref_frame 0 free-integration ones (251 VGPRs without them: C3's kernel keeps the raw sums, documented and pinned by
-// tests/test_process_stats.py) and the vibration variants (already at the register limit).
-template <bool SHIFT>
-struct Proc {
-    double s1[9], s2[9], mx[9], e0[SHIFT ? 9 : 1];
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int c = 0; c < 9; ++c) { s1[c] = 0.0; s2[c] = 0.0; mx[c] = 0.0; }
-#pragma unroll
-        for (int c = 0; c < (SHIFT ? 9 : 1); ++c) e0[c] = 0.0;
-    }
-    // t = truth att3, pos3, vel3 of this sample (wave-uniform); NED: position error in local NED metres (:542-552);
-    // first (wave-uniform): this is the first sample of the window
-    template <bool NED>
-    __device__ __forceinline__ void add(const Nav& s, const double (&t)[9], bool first) {
-        double e[9];
-        e[0] = s.att.yaw - t[0]; e[1] = s.att.pit - t[1]; e[2] = s.att.rol - t[2];
-        wrap_pi3(e);
-        if (NED) {
-            const Vec3 d = lla_error_ned(s.pos, Vec3{t[3], t[4], t[5]});
-            e[3] = d.x; e[4] = d.y; e[5] = d.z;
-        } else {
-            e[3] = s.pos.x - t[3]; e[4] = s.pos.y - t[4]; e[5] = s.pos.z - t[5];
-        }
-        e[6] = s.vel.x - t[6]; e[7] = s.vel.y - t[7]; e[8] = s.vel.z - t[8];
-        if (SHIFT && first) {
-#pragma unroll
-            for (int c = 0; c < 9; ++c) e0[c] = e[c];
-        }
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            const double d = SHIFT ? e[c] - e0[c] : e[c];
-            s1[c] += d;
-            s2[c] = __builtin_fma(d, d, s2[c]);
-            mx[c] = fmax(mx[c], fabs(e[c]));
-        }
-    }
-    __device__ __forceinline__ void store(double* __restrict__ out, int64_t runs, int64_t r, double cnt) const {
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            const double md = cnt > 0.0 ? s1[c] / cnt : 0.0;
-            const double var = cnt > 0.0 ? s2[c] / cnt - md * md : 0.0;
-            out[(0 * 9 + c) * runs + r] = mx[c];
-            out[(1 * 9 + c) * runs + r] = SHIFT ? e0[c] + md : md;
-            out[(2 * 9 + c) * runs + r] = var > 0.0 ? sqrt(var) : 0.0;
-        }
-    }
-};
-
 // Truth samples are the same for every lane.  Reading them through the constant address space tells the
 // compiler the data are invariant, so a wave-uniform index becomes an s_load (scalar cache, lgkmcnt) instead
 // of a per-lane global_load -- which matters beyond the 64x fewer bytes: vector loads share the vmcnt counter
@@ -279,6 +226,70 @@ typedef const double __attribute__((address_space(4))) * uniform_ptr;
 __device__ __forceinline__ uniform_ptr as_uniform(const double* p) {
     return (uniform_ptr)(uintptr_t)p;
 }
+
+// SHIFT 1 (round 5): the sums are kept about the FIRST in-window error of the run (sum (e - e0), sum (e - e0)^2): a (nearly)
+// constant error then leaves var = sum d^2 / n - (sum d / n)^2 with d of the size of the error's VARIATION, and the floor of the
+// raw form (~1.5e-8 |mean| on the std) is gone.  Nine more doubles per lane: every process-statistics variant that has them.
+// SHIFT 2 (round 6): the ref_frame 0 free-integration variants (245-251 VGPRs: C3's kernel) and the vibration variants do not.
+// Their sums are kept about ONE error for the whole launch: that of the first run's initial state against the truth at sample 0
+// (proc_shift_kernel writes the nine numbers before the launch; proc_first > 0 keeps sample 0's, the errors grow from it).  It is
+// the same for every lane, so it costs no vector register: it is re-read with scalar loads next to the nine subtractions, the way
+// the truth sample is.  What is left under the sums is the error's growth plus what the runs' initial states differ by.
+// The nine subtractions cost C3 2.3 %; a caller whose runs start ON the truth (nine zero shifts: the same sums either way) may say
+// so (ginsim_mc_params.proc_plain_sums, which ginsim.MonteCarloJob works out from the initial state and the truth it uploads) and
+// gets SHIFT 0 in these variants.
+template <int SHIFT>
+struct Proc {
+    double s1[9], s2[9], mx[9], e0[SHIFT == 1 ? 9 : 1];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { s1[c] = 0.0; s2[c] = 0.0; mx[c] = 0.0; }
+#pragma unroll
+        for (int c = 0; c < (SHIFT == 1 ? 9 : 1); ++c) e0[c] = 0.0;
+    }
+    // the process error of one state against the truth sample t = att3, pos3, vel3 (ins_data_manager.py:761-795); NED: the
+    // position error in local NED metres (:542-552)
+    template <bool NED>
+    static __device__ __forceinline__ void error(const Nav& s, const double (&t)[9], double (&e)[9]) {
+        e[0] = s.att.yaw - t[0]; e[1] = s.att.pit - t[1]; e[2] = s.att.rol - t[2];
+        wrap_pi3(e);
+        if (NED) {
+            const Vec3 d = lla_error_ned(s.pos, Vec3{t[3], t[4], t[5]});
+            e[3] = d.x; e[4] = d.y; e[5] = d.z;
+        } else {
+            e[3] = s.pos.x - t[3]; e[4] = s.pos.y - t[4]; e[5] = s.pos.z - t[5];
+        }
+        e[6] = s.vel.x - t[6]; e[7] = s.vel.y - t[7]; e[8] = s.vel.z - t[8];
+    }
+    // t (wave-uniform): the truth of this sample; first (wave-uniform): this is the first sample of the window;
+    // about (SHIFT 2): the launch's nine shifts, wave-uniform
+    template <bool NED>
+    __device__ __forceinline__ void add(const Nav& s, const double (&t)[9], bool first, uniform_ptr about) {
+        double e[9];
+        error<NED>(s, t, e);
+        if (SHIFT == 1 && first) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) e0[c] = e[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const double d = SHIFT == 1 ? e[c] - e0[c] : (SHIFT == 2 ? e[c] - about[c] : e[c]);
+            s1[c] += d;
+            s2[c] = __builtin_fma(d, d, s2[c]);
+            mx[c] = fmax(mx[c], fabs(e[c]));
+        }
+    }
+    __device__ __forceinline__ void store(double* __restrict__ out, int64_t runs, int64_t r, double cnt, uniform_ptr about) const {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const double md = cnt > 0.0 ? s1[c] / cnt : 0.0;
+            const double var = cnt > 0.0 ? s2[c] / cnt - md * md : 0.0;
+            out[(0 * 9 + c) * runs + r] = mx[c];
+            out[(1 * 9 + c) * runs + r] = SHIFT == 1 ? e0[c] + md : (SHIFT == 2 ? about[c] + md : md);
+            out[(2 * 9 + c) * runs + r] = var > 0.0 ? sqrt(var) : 0.0;
+        }
+    }
+};
 
 // Sensor sample j of one 3-axis sensor: truth + bias + drift + white  (pathgen.py:500, 562), and the
 // Gauss-Markov update d[j+1] = a d[j] + b N[j] (pathgen.py:589-590).
@@ -378,10 +389,12 @@ __device__ __forceinline__ Vec3 add_vibration(const Vec3& o, vib_ptr v, const Rn
 // to 256 VGPRs + a few AGPRs = one wavefront per SIMD, 30 % slower at 262 144 runs, with no functional symptom;
 // tests/test_host_cpu.py now reads the compiler's resource report).
 // PS: 0 = no process statistics; 1 = online process-error statistics of the (single) algorithm; 2 = the same with the
-// position error in NED metres (ref_frame 0).
+// position error in NED metres (ref_frame 0); 3 / 4 = 1 / 2 with the sums taken as they are (ginsim_mc_params.proc_plain_sums:
+// the caller states that the runs start ON the truth, so the launch's shift would be nine zeros -- the same sums without the
+// nine subtractions per step; only the variants whose shift is per launch have the form, see Proc).
 // VIB: the sensors carry a vibration term (vib_accel / vib_gyro; general sensor model, generate mode).
 template <int RF, int ALGOS, bool GIVEN, bool WD, int PS = 0, bool VIB = false>
-__global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
+__global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a, const double* __restrict__ proc_about) {
     static_assert(PS == 0 || (!GIVEN && (ALGOS == GINSIM_ALGO_FREE || ALGOS == GINSIM_ALGO_ODO)), "process statistics: one algorithm, generate mode");
     static_assert(!VIB || (!GIVEN && WD), "vibration: generate mode, general sensor model");
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -427,16 +440,24 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
 
     if (FREE && a.out_traj[0]) store9(a.out_traj[0], plane, r, fi);
     if (ODO && a.out_traj[1]) store9(a.out_traj[1], plane, r, od);
-    // the shifted sums wherever the registers are there (see Proc)
-    constexpr bool PSHIFT = PS != 0 && !VIB && !(RF == 0 && ALGOS == GINSIM_ALGO_FREE);
-    Proc<PSHIFT> ps;
+    // the sums shifted per lane wherever the registers are there, per launch elsewhere (see Proc)
+    constexpr bool PNED = PS == 2 || PS == 4, PPLAIN = PS >= 3;
+    static_assert(!PPLAIN || (RF == 0 && ALGOS == GINSIM_ALGO_FREE && !VIB), "plain sums: only where the shift is per launch and optional");
+    constexpr int PSHIFT = PS == 0 ? 0 : ((!VIB && !(RF == 0 && ALGOS == GINSIM_ALGO_FREE)) ? 1 : (PPLAIN ? 0 : 2));
     const uniform_ptr nav_truth = as_uniform(a.ref_nav);
+    // opaque per use: hoisted out of the time loop the nine shifts would sit in 18 SGPRs the loop does not have
+    auto about = [&]() -> uniform_ptr {
+        uniform_ptr q = as_uniform(proc_about);
+        if (PSHIFT == 2) asm volatile("" : "+s"(q));
+        return q;
+    };
+    Proc<PSHIFT> ps;
     if (PS) {
         ps.clear();
         if (a.proc_first <= 0) {                    // sample 0 is the initial state (free_integration.py:96-102)
             const double t[9] = {nav_truth[0], nav_truth[1], nav_truth[2], nav_truth[3], nav_truth[4], nav_truth[5],
                                  nav_truth[6], nav_truth[7], nav_truth[8]};
-            ps.template add<PS == 2>(FREE ? fi : od, t, true);
+            ps.template add<PNED>(FREE ? fi : od, t, true, about());
         }
     }
 
@@ -502,7 +523,7 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
             if (j + 1 >= a.proc_first) {            // wave-uniform
                 const uniform_ptr q = nav_truth + 9 * (j + 1);
                 const double t[9] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
-                ps.template add<PS == 2>(FREE ? fi : od, t, a.proc_first > 0 && j + 1 == a.proc_first);
+                ps.template add<PNED>(FREE ? fi : od, t, a.proc_first > 0 && j + 1 == a.proc_first, about());
             }
         }
     }
@@ -512,8 +533,22 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a) {
         if (FREE && a.out_end_ned[0]) store_end_ned(a.out_end_ned[0], runs, r, fi);
         if (ODO && a.out_end_ned[1]) store_end_ned(a.out_end_ned[1], runs, r, od);
     }
-    if (PS) ps.store(a.out_proc[FREE ? 0 : 1], runs, r, (double)(n - (a.proc_first > 0 ? a.proc_first : 0)));
+    if (PS) ps.store(a.out_proc[FREE ? 0 : 1], runs, r, (double)(n - (a.proc_first > 0 ? a.proc_first : 0)), about());
     if (trace) trace[3] = __builtin_amdgcn_s_memtime();
+}
+
+// The launch-wide shift of the process statistics (Proc, SHIFT 2): the process error of the FIRST run's initial state against
+// the truth at sample 0, nine doubles.  One lane, before the launch, on its stream.
+template <int RF, bool NED>
+__global__ void proc_shift_kernel(const ginsim_mc_params a, double* __restrict__ about) {
+    const double* ini = a.ini + 10 * (a.ini_first < (uint64_t)a.n_ini ? a.ini_first : 0);
+    Nav z;
+    nav_init<RF>(z, ini, a.ini_has_g);
+    const double t[9] = {a.ref_nav[0], a.ref_nav[1], a.ref_nav[2], a.ref_nav[3], a.ref_nav[4], a.ref_nav[5],
+                         a.ref_nav[6], a.ref_nav[7], a.ref_nav[8]};
+    double e[9];
+    Proc<0>::error<NED>(z, t, e);
+    for (int c = 0; c < 9; ++c) about[c] = e[c];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -754,7 +789,7 @@ static bool any_white_drift(const ginsim_mc_params& p) {
 static const char* tf(bool b) { return b ? "true" : "false"; }
 
 template <int RF, int ALGOS, bool WD>
-static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
+static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap, double* about) {
     const int tb = p.block_threads > 0 ? p.block_threads : kBlock;
     const int64_t waves = (p.runs + kWave - 1) / kWave;
     if constexpr ((ALGOS & GINSIM_ALGO_FREE) != 0) {
@@ -813,20 +848,47 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
     if constexpr (ALGOS == GINSIM_ALGO_FREE || ALGOS == GINSIM_ALGO_ODO) {
         if (p.out_proc[ALGOS == GINSIM_ALGO_FREE ? 0 : 1]) {
             const bool ned = RF == 0 && p.proc_pos_ned;
+            // the variants whose sums are shifted per launch (Proc, SHIFT 2): the nine shifts are written first, on the same stream
+            auto write_shift = [&](bool vib) -> hipError_t {
+                if (!vib && !(RF == 0 && ALGOS == GINSIM_ALGO_FREE)) return hipSuccess;
+                if (!about) return hipErrorInvalidValue;
+                if (ned) hipLaunchKernelGGL((proc_shift_kernel<RF, RF == 0>), dim3(1), dim3(1), 0, stream, p, about);
+                else hipLaunchKernelGGL((proc_shift_kernel<RF, false>), dim3(1), dim3(1), 0, stream, p, about);
+                return hipGetLastError();
+            };
+            // ... unless the caller states that the runs start on the truth (nine zero shifts): the plain sums
+            constexpr bool kPlainForm = RF == 0 && ALGOS == GINSIM_ALGO_FREE;
+            const bool plain = kPlainForm && p.proc_plain_sums != 0 && !any_vibration(p);
             if constexpr (WD) {                     // the general sensor model: every statistics form, vibration included
                 if (any_vibration(p)) {
                     GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d, true>", RF, ALGOS, ned ? 2 : 1)
-                    if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1, true>), grid, block, lds, stream, p);
-                    else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1, true>), grid, block, lds, stream, p);
+                    if (hipError_t e = write_shift(true); e != hipSuccess) return e;
+                    if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1, true>), grid, block, lds, stream, p, about);
+                    else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1, true>), grid, block, lds, stream, p, about);
                     return hipGetLastError();
                 }
-                GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d, false>", RF, ALGOS, ned ? 2 : 1)
-                if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1>), grid, block, lds, stream, p);
-                else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1>), grid, block, lds, stream, p);
+                GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, %d, false>", RF, ALGOS, (ned ? 2 : 1) + (plain ? 2 : 0))
+                if constexpr (kPlainForm) {
+                    if (plain) {
+                        if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 4>), grid, block, lds, stream, p, about);
+                        else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 3>), grid, block, lds, stream, p, about);
+                        return hipGetLastError();
+                    }
+                }
+                if (hipError_t e = write_shift(false); e != hipSuccess) return e;
+                if (ned) hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, RF == 0 ? 2 : 1>), grid, block, lds, stream, p, about);
+                else hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 1>), grid, block, lds, stream, p, about);
                 return hipGetLastError();
             } else {                                // the simple model (every standard IMU grade), statistics in the state's own units
-                GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, false, 1, false>", RF, ALGOS)
-                hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, false, 1>), grid, block, lds, stream, p);
+                GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, false, %d, false>", RF, ALGOS, plain ? 3 : 1)
+                if constexpr (kPlainForm) {
+                    if (plain) {
+                        hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, false, 3>), grid, block, lds, stream, p, about);
+                        return hipGetLastError();
+                    }
+                }
+                if (hipError_t e = write_shift(false); e != hipSuccess) return e;
+                hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, false, 1>), grid, block, lds, stream, p, about);
                 return hipGetLastError();
             }
         }
@@ -834,17 +896,17 @@ static hipError_t launch3(const ginsim_mc_params& p, hipStream_t stream, char* n
     if constexpr (WD) {
         if (any_vibration(p)) {
             GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, true, 0, true>", RF, ALGOS)
-            hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 0, true>), grid, block, lds, stream, p);
+            hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, true, 0, true>), grid, block, lds, stream, p, about);
             return hipGetLastError();
         }
     }
     GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, false, %s, 0, false>", RF, ALGOS, tf(WD))
-    hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, WD>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL((mc_kernel<RF, ALGOS, false, WD>), grid, block, lds, stream, p, about);
     return hipGetLastError();
 }
 
 template <int RF, int ALGOS>
-static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
+static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap, double* about) {
     if (p.given_sensors) {
         if constexpr (ALGOS != 0) {
             GINSIM_NAME_OR("ginsim::mc_kernel<%d, %d, true, false, 0, false>", RF, ALGOS)
@@ -852,7 +914,7 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream, char* n
             const int64_t waves = (p.runs + kWave - 1) / kWave;
             const int per_cu = waves <= 1024 ? 1 : 2;
             const size_t lds = p.block_threads > 0 ? 0 : kLdsPerCu / (per_cu + 1) + 1024;
-            hipLaunchKernelGGL((mc_kernel<RF, ALGOS, true, false>), dim3((unsigned)((p.runs + tb - 1) / tb)), dim3(tb), lds, stream, p);
+            hipLaunchKernelGGL((mc_kernel<RF, ALGOS, true, false>), dim3((unsigned)((p.runs + tb - 1) / tb)), dim3(tb), lds, stream, p, about);
             return hipGetLastError();
         }
         return hipErrorInvalidValue;        // given sensors without an algorithm: rejected by the C ABI
@@ -864,23 +926,23 @@ static hipError_t launch2(const ginsim_mc_params& p, hipStream_t stream, char* n
     const bool proc = p.out_proc[0] || p.out_proc[1];
     const bool general_ps = proc && getenv("GINSIM_PS_GENERAL") != nullptr;       // read per call: the tests compare the two kernels bit for bit
     if (any_white_drift(p) || any_vibration(p) || !kSimpleFits || (proc && p.ref_frame == 0 && p.proc_pos_ned) || general_ps)
-        return launch3<RF, ALGOS, true>(p, stream, name, cap);
-    if constexpr (kSimpleFits) return launch3<RF, ALGOS, false>(p, stream, name, cap);
+        return launch3<RF, ALGOS, true>(p, stream, name, cap, about);
+    if constexpr (kSimpleFits) return launch3<RF, ALGOS, false>(p, stream, name, cap, about);
     return hipErrorInvalidValue;
 }
 
 template <int RF>
-static hipError_t launch1(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
+static hipError_t launch1(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap, double* about) {
     switch (p.algo_mask) {
-        case 0: return launch2<RF, 0>(p, stream, name, cap);      // sensors only (Sim without an algorithm)
-        case GINSIM_ALGO_FREE: return launch2<RF, GINSIM_ALGO_FREE>(p, stream, name, cap);
-        case GINSIM_ALGO_ODO: return launch2<RF, GINSIM_ALGO_ODO>(p, stream, name, cap);
-        default: return launch2<RF, GINSIM_ALGO_FREE | GINSIM_ALGO_ODO>(p, stream, name, cap);
+        case 0: return launch2<RF, 0>(p, stream, name, cap, about);      // sensors only (Sim without an algorithm)
+        case GINSIM_ALGO_FREE: return launch2<RF, GINSIM_ALGO_FREE>(p, stream, name, cap, about);
+        case GINSIM_ALGO_ODO: return launch2<RF, GINSIM_ALGO_ODO>(p, stream, name, cap, about);
+        default: return launch2<RF, GINSIM_ALGO_FREE | GINSIM_ALGO_ODO>(p, stream, name, cap, about);
     }
 }
 
-hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap) {
-    return p.ref_frame == 1 ? launch1<1>(p, stream, name, cap) : launch1<0>(p, stream, name, cap);
+hipError_t launch_mc(const ginsim_mc_params& p, hipStream_t stream, char* name, size_t cap, double* about) {
+    return p.ref_frame == 1 ? launch1<1>(p, stream, name, cap, about) : launch1<0>(p, stream, name, cap, about);
 }
 
 // ---------------------------------------------------------------------------------------------------

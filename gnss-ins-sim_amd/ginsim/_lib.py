@@ -69,7 +69,7 @@ class McParams(C.Structure):
                 ('wave_trace', C.c_void_p), ('block_threads', C.c_int32), ('end_pos_ned', C.c_int32),
                 ('precision', C.c_int32), ('proc_pos_ned', C.c_int32),
                 ('ref_nav', C.c_void_p), ('proc_first', C.c_int64), ('out_proc', C.c_void_p * 2),
-                ('out_end_ned', C.c_void_p * 2), ('sensor_layout', C.c_int32), ('reserved4', C.c_int32),
+                ('out_end_ned', C.c_void_p * 2), ('sensor_layout', C.c_int32), ('proc_plain_sums', C.c_int32),
                 ('vib_accel', Vibration), ('vib_gyro', Vibration)]
 
 

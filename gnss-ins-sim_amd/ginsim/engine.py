@@ -467,6 +467,29 @@ class StatsResult(object):
         return StatsResult(out)
 
 
+def starts_on_truth(table, nav0, ref_frame=0):
+    """Do all the initial states of `table` ([n_ini][10]: pos3 LLA, body velocity3, yaw / pitch / roll, g) lie ON the truth's first
+    sample `nav0` (att3, pos3, vel3)?  Then the error at sample 0 is zero for every run, the launch-wide shift of the online process
+    statistics would be nine zeros, and the launch may take its sums as they are (ginsim_mc_params.proc_plain_sums: the same
+    numbers, nine subtractions per step fewer).  Only ref_frame 0 has the form (there the truth's position is LLA like the
+    table's).  The position must agree exactly, the attitude to 1e-12 rad modulo a turn, the velocity -- the body velocity turned
+    into the navigation frame here, pathgen's own there -- to 1e-9 m/s: the plain sums' floor under such means is 1e-8 of them."""
+    if int(ref_frame) != 0:
+        return False
+    nav0 = np.asarray(nav0, dtype=np.float64)
+    for row in np.asarray(table, dtype=np.float64).reshape(-1, 10):
+        datt = np.mod(row[6:9] - nav0[0:3] + np.pi, 2.0 * np.pi) - np.pi
+        if not (np.all(np.abs(datt) <= 1e-12) and np.array_equal(row[0:3], nav0[3:6])):
+            return False
+        c, s = np.cos(row[6:9]), np.sin(row[6:9])
+        n2b = np.array([[c[1] * c[0], c[1] * s[0], -s[1]],
+                        [s[2] * s[1] * c[0] - c[2] * s[0], s[2] * s[1] * s[0] + c[2] * c[0], c[1] * s[2]],
+                        [s[1] * c[2] * c[0] + s[0] * s[2], s[1] * c[2] * s[0] - c[0] * s[2], c[1] * c[2]]])
+        if not np.all(np.abs(n2b.T @ row[3:6] - nav0[6:9]) <= 1e-9):
+            return False
+    return True
+
+
 class MonteCarloJob(object):
     """One batch of MC runs on one device: fused noise injection + mechanisation + end-point error.
 
@@ -612,6 +635,7 @@ class MonteCarloJob(object):
                 raise ValueError('NED position errors exist in ref_frame 0 only')
             self._bufs['ref_nav'] = ctx.upload(self._ref_nav)
             p.ref_nav, p.proc_first, p.proc_pos_ned = self._bufs['ref_nav'].ptr, int(proc_first), int(bool(proc_ned))
+            p.proc_plain_sums = int(starts_on_truth(table, self._ref_nav[0], ref_frame))
         if end_ned and (int(ref_frame) != 0 or precision != 'f64' or given is not None):
             raise ValueError('end_ned: ref_frame 0, fp64, generated sensors')
         for a in self.algos:

@@ -242,7 +242,14 @@ typedef struct {
                                * kernel, whose time loop is ONE sequential chain over n per lane -- for long series (config 5:
                                * 1 440 000 samples) seconds instead of a millisecond.  A caller that wants few long series
                                * sets sensor_layout = 1 (or asks ginsim_mc_variant first: 2 = time-parallel). */
-    int32_t   reserved4;
+    int32_t   proc_plain_sums; /* online process statistics, the variants whose sums are shifted per LAUNCH (ref_frame 0 free integration; see
+                               * csrc/mc_kernel.hip, Proc): 0 (default) = the sums are kept about the error of the first run's initial
+                               * state against the truth at sample 0, so an error that is nearly constant over the window keeps its true
+                               * std (np.std, ins_data_manager.py:761-795).  1 = the caller states that every run starts ON the truth
+                               * (that error is zero): the sums are taken as they are -- what nine zero shifts give, nine
+                               * double-precision subtractions per step fewer (BASELINE config 3: 2.3 %).  Stating it of runs that
+                               * start off the truth brings back the rounding floor of ~1.5e-8 |mean| on the std.  (Was reserved4,
+                               * which had to be 0.) */
     /* ---- ABI 5: vibration, Sim(env={'acc': ..., 'gyro': ...}) -> the vib term of pathgen.acc_gen / gyro_gen ---- */
     ginsim_vibration vib_accel, vib_gyro;
 } ginsim_mc_params;

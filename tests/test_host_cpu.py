@@ -114,6 +114,28 @@ def test_sensor_model_coefficients():
     np.testing.assert_allclose(np.array(m.white[:]), err['vrw'] / np.sqrt(1 / 200.0), rtol=1e-15)
 
 
+def test_starts_on_truth_is_what_lets_a_statistics_launch_take_plain_sums():
+    """ginsim_mc_params.proc_plain_sums (include/ginsim.h): MonteCarloJob states it only when every initial state lies on the
+    truth's first sample -- attitude and position exactly, the velocity to 1e-9 m/s."""
+    from ginsim import workloads
+    from ginsim.engine import starts_on_truth, ini_table
+    ini, truth, _ = workloads.truth_from_profile('turn_90deg', 100.0, 0)          # yaw 315 deg in the table, -45 deg in the truth
+    nav0 = np.concatenate([truth['ref_att'][0], truth['ref_pos'][0], truth['ref_vel'][0]])
+    table, _ = ini_table(ini)
+    assert starts_on_truth(table, nav0) and not starts_on_truth(table, nav0, ref_frame=1)         # ref_frame 1 has no plain form
+    for col, d in ((6, 1e-9), (0, 1e-12), (2, 1e-6), (3, 1e-6), (8, -1e-9)):
+        off = table.copy()
+        off[0, col] += d
+        assert not starts_on_truth(off, nav0), col
+    two = np.concatenate([table, table])                    # several sets of initial states: every one of them
+    assert starts_on_truth(two, nav0)
+    two[1, 7] += 1e-6
+    assert not starts_on_truth(two, nav0)
+    off = table.copy()
+    off[0, 3] += 1e-11                                       # below what the velocity check resolves: still on the truth
+    assert starts_on_truth(off, nav0)
+
+
 def test_ini_table_shapes():
     import ginsim
     t, has_g = ginsim.ini_table(np.arange(9.0))
@@ -586,6 +608,12 @@ def test_reported_kernel_names_are_the_compiled_kernels():
              dict(ref_frame=0, runs=262144, out_accel=None, out_gyro=None, out_traj=none(None, None), out_proc=none(4096, None), proc_pos_ned=1),
              dict(out_accel=None, out_gyro=None, out_traj=none(None, None), out_proc=none(4096, None)),
              dict(precision=1, out_accel=None, out_gyro=None, out_traj=none(None, None))]
+    # the plain-sum forms of the statistics kernels whose shift is per launch (proc_plain_sums = 1: ref_frame 0 free integration only)
+    plain = [dict(c, proc_plain_sums=1) for c in cases if c.get('out_proc') is not None]
+    assert name(**plain[0]) == 'ginsim::mc_kernel<0, 1, false, false, 3, false>' and name(**cases[13]) == 'ginsim::mc_kernel<0, 1, false, false, 1, false>'
+    assert name(**plain[1]) == 'ginsim::mc_kernel<0, 1, false, true, 4, false>'
+    assert name(**plain[2]) == name(**cases[15])                # ref_frame 1: the shift is per lane, there is no plain form
+    cases += plain
     for kw in cases:
         k = name(**kw)
         assert k in compiled, 'ginsim_mc_kernel_name reports %r for %r, which is not a compiled kernel' % (k, kw)
