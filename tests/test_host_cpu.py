@@ -659,7 +659,25 @@ def test_placed_arena_logic_on_the_host(tmp_path):
     rule, planes of exactly three stripes spread over the classes."""
     import subprocess
     exe = str(tmp_path / 'placed_logic_check')
-    subprocess.run(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I' + os.path.join(PKG, 'csrc'), '-o', exe,
+    subprocess.run(['g++', '-std=c++17', '-O1', '-g', '-Wall', '-Werror'] + SANITIZE + ['-I' + os.path.join(PKG, 'csrc'), '-o', exe,
                     os.path.join(REPO, 'tests', 'cpp', 'placed_logic_check.cpp')], check=True, timeout=300)
-    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == 'ok', out.stdout
+
+
+# GPU AddressSanitizer is not available on the pool: the sanitizers run on the CPU builds of the host-side code
+SANITIZE = ['-fsanitize=address,undefined', '-fno-sanitize-recover=all']
+
+
+def test_pathgen_under_the_sanitizers(tmp_path):
+    """csrc/pathgen.cpp (the truth generator, host code of libginsim.so: pathgen.py:26-329) compiled with g++ and the address and
+    undefined-behaviour sanitizers, driven by tests/cpp/pathgen_sanitize_check.cpp: every command type, both frames, GPS and
+    magnetometer rows on and off, three rates, into heap blocks of exactly the sizes include/ginsim.h:130-137 asks for; the
+    refusals; the ABI-6 leaves.  (The numbers are held to the reference by test_native_pathgen_*.)"""
+    import subprocess
+    exe = str(tmp_path / 'pathgen_sanitize_check')
+    subprocess.run(['g++', '-std=c++17', '-O1', '-g', '-ffp-contract=off', '-Wall'] + SANITIZE + ['-I' + os.path.join(REPO, 'include'), '-o', exe,
+                    os.path.join(PKG, 'csrc', 'pathgen.cpp'), os.path.join(REPO, 'tests', 'cpp', 'pathgen_sanitize_check.cpp')],
+                   check=True, timeout=300)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == 'ok', out.stdout
