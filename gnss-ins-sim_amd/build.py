@@ -36,6 +36,7 @@ SOURCES = [
     ('stats.hip', ['--offload-arch=' + ARCH]),
     ('allan.hip', ['--offload-arch=' + ARCH]),
     ('placed.hip', ['--offload-arch=' + ARCH]),
+    ('vib_psd.hip', ['--offload-arch=' + ARCH]),
     ('ginsim_api.hip', ['--offload-arch=' + ARCH]),
     # host-only truth generator; no fused multiply-adds (see the file header)
     ('pathgen.cpp', ['-x', 'c++', '-ffp-contract=off']),

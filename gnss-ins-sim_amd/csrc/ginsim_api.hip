@@ -39,6 +39,10 @@ int mc_variant_f32(const ginsim_mc_params& p);
 hipError_t launch_gather_runs_f32(const float* series, int C, int64_t n, int64_t runs, const int64_t* ids, int nsel,
                                   double* out, hipStream_t s);
 hipError_t launch_aux(const ginsim_aux_params& p, hipStream_t s);
+size_t vib_psd_scratch_bytes(int64_t period, int64_t runs);
+int launch_vib_psd(int device, hipStream_t stream, const double* amp, int64_t period, int64_t runs, uint64_t run_offset, uint64_t seed,
+                   int sensor, int halve, void* scratch, double* out);
+void vib_psd_drop_plans(int device);
 hipError_t launch_rng_probe(uint64_t seed, uint64_t run, uint32_t stream, int64_t count, double* z0, double* z1,
                             uint32_t* words, hipStream_t stream_h);
 hipError_t launch_aos_to_soa(const double* src, double* dst, int64_t R, int64_t n, int C, hipStream_t s);
@@ -184,6 +188,7 @@ int ginsim_destroy(ginsim_ctx* c) {
     if (c->comm_host) (void)hipHostFree(c->comm_host);
     for (hipEvent_t e : c->comm_ev)
         if (e) (void)hipEventDestroy(e);
+    ginsim::vib_psd_drop_plans(c->device);            // hipFFT plans of the PSD vibration (rebuilt on demand)
     (void)hipStreamDestroy(c->stream);
     ginsim::placed_free_owner(c->device, c);          // regions this context carved and never freed go back to the free list
     ginsim::placed_context_destroyed(c->device);      // the device's last context gives its placed arena back
@@ -418,10 +423,15 @@ static int check_mc_params(const ginsim_mc_params* p) {
         if (rc) return rc;
     }
     for (const ginsim_vibration* v : {&p->vib_accel, &p->vib_gyro}) {
-        REQUIRE(v->type == GINSIM_VIB_NONE || v->type == GINSIM_VIB_RANDOM || v->type == GINSIM_VIB_SINUSOIDAL,
-                "mc_run: vibration type must be 0 (none), 1 (random) or 2 (sinusoidal)");
+        REQUIRE(v->type == GINSIM_VIB_NONE || v->type == GINSIM_VIB_RANDOM || v->type == GINSIM_VIB_SINUSOIDAL || v->type == GINSIM_VIB_PSD,
+                "mc_run: vibration type must be 0 (none), 1 (random), 2 (sinusoidal) or 3 (psd)");
         if (v->type == GINSIM_VIB_NONE) continue;
         REQUIRE(!p->given_sensors, "mc_run: a vibration term cannot be added to given sensors");
+        if (v->type == GINSIM_VIB_PSD) {
+            REQUIRE(v->series && v->period >= 2 && v->period <= 16384, "mc_run: a psd vibration needs its series (ginsim_vib_psd_series) and their period (2 .. 16384)");
+            REQUIRE(p->precision == 0, "mc_run: the psd vibration runs on the fp64 kernels only");
+            REQUIRE(p->sensor_layout == 0, "mc_run: the psd vibration runs on the lane-per-run kernels only (sensor_layout 0)");
+        }
         REQUIRE(std::isfinite(v->amp[0]) && std::isfinite(v->amp[1]) && std::isfinite(v->amp[2]) && std::isfinite(v->omega_dt),
                 "mc_run: vibration amplitudes / frequency must be finite");
     }
@@ -533,6 +543,22 @@ int ginsim_comm_probe(void) {
     const char* err = comm_probe();
     if (err) { set_error("comm_probe: %s", err); return GINSIM_ERR_HIP; }
     return GINSIM_OK;
+}
+
+int ginsim_vib_psd_series(ginsim_ctx* c, const double* amp, int64_t period, int64_t runs, uint64_t run_offset, uint64_t seed,
+                          int32_t sensor, int32_t halve_per_run, double* out) {
+    REQUIRE(c && amp && out, "vib_psd_series: NULL argument");
+    REQUIRE(period >= 2 && period <= 16384 && period % 2 == 0, "vib_psd_series: period %lld must be even, 2 .. 16384 (time_series_from_psd.py:36-43)",
+            (long long)period);
+    REQUIRE(runs >= 1 && runs <= (int64_t)0x7FFFFFFF * 64, "vib_psd_series: runs=%lld out of range", (long long)runs);
+    REQUIRE(sensor == 0 || sensor == 1, "vib_psd_series: sensor must be 0 (accelerometer) or 1 (gyroscope)");
+    REQUIRE(halve_per_run == 0 || halve_per_run == 1, "vib_psd_series: halve_per_run must be 0 or 1");
+    for (int64_t k = 0; k < 3 * (period / 2 + 1); ++k)
+        REQUIRE(std::isfinite(amp[k]) && amp[k] >= 0.0, "vib_psd_series: amplitude %lld is negative or not finite", (long long)k);
+    HIP_TRY(hipSetDevice(c->device));
+    void* ws = nullptr;
+    HIP_TRY(scratch(c, 3, vib_psd_scratch_bytes(period, runs), &ws));
+    return launch_vib_psd(c->device, c->stream, amp, period, runs, run_offset, seed, sensor, halve_per_run, ws, out);
 }
 
 int ginsim_comm_query(ginsim_ctx* c, int32_t* nranks, int32_t* rank, int32_t* device) {

@@ -358,11 +358,19 @@ __device__ __forceinline__ Vec3 vibration_term(const Vec3& o, vib_ptr v, double 
     return r;
 }
 
+// run / runs: the lane's run and the batch's size (the layout of the 'psd' series, [axis][sample mod period][run])
 template <uint32_t STREAM>
 __device__ __forceinline__ Vec3 add_vibration(const Vec3& o, vib_ptr v, const RngKey& key, uint32_t j, const NormalTables& tab,
-                                              const Vec3& phase) {
+                                              const Vec3& phase, int64_t run, int64_t runs) {
     Vec3 r = o;
-    if (v->type == GINSIM_VIB_RANDOM) {
+    if (v->type == GINSIM_VIB_PSD) {                // made before the launch (vib_psd.hip), tiled to n (time_series_from_psd.py:58-63)
+        const int64_t period = v->period;
+        const double* s = v->series + (int64_t)(j % (uint32_t)period) * runs + run;
+        const int64_t pl = period * runs;
+        r.x = o.x + s[0];
+        r.y = o.y + s[pl];
+        r.z = o.z + s[2 * pl];
+    } else if (v->type == GINSIM_VIB_RANDOM) {
         double z0[2], z1[2];
         normal_pairs<STREAM, 2>(key, j, z0, z1, tab);
         r.x = o.x + v->amp[0] * z0[0];
@@ -496,8 +504,8 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a, co
                 gyr = sense3<WD>(cur_g, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             }
             if (VIB) {
-                if (need_acc) acc = add_vibration<S_ACC_VIB_XY>(acc, &kernarg_params()->vib_accel, key, jj, tab, vpa);
-                if (need_gyr) gyr = add_vibration<S_GYR_VIB_XY>(gyr, &kernarg_params()->vib_gyro, key, jj, tab, vpg);
+                if (need_acc) acc = add_vibration<S_ACC_VIB_XY>(acc, &kernarg_params()->vib_accel, key, jj, tab, vpa, r, runs);
+                if (need_gyr) gyr = add_vibration<S_GYR_VIB_XY>(gyr, &kernarg_params()->vib_gyro, key, jj, tab, vpg, r, runs);
             }
             if (need_acc && a.out_accel) store3(a.out_accel, plane, off, acc);
             if (need_gyr && a.out_gyro) store3(a.out_gyro, plane, off, gyr);
@@ -751,8 +759,11 @@ static int split_policy() {        // GINSIM_SPLIT=0 / 1 forces the plain / wave
 
 // 1 = wave-specialised kernel (mc_kernel_split), 0 = one wavefront does everything for its 64 runs (mc_kernel)
 static bool any_vibration(const ginsim_mc_params& p) { return p.vib_accel.type != GINSIM_VIB_NONE || p.vib_gyro.type != GINSIM_VIB_NONE; }
+// a 'psd' vibration (ABI 8) is a series read per lane and sample: the lane-per-run kernel has it, nothing else
+static bool any_psd_vibration(const ginsim_mc_params& p) { return p.vib_accel.type == GINSIM_VIB_PSD || p.vib_gyro.type == GINSIM_VIB_PSD; }
 
 int mc_variant(const ginsim_mc_params& p) {
+    if (any_psd_vibration(p)) return 0;
     if (any_vibration(p)) {
         // the vibration term lives in the plain kernels, except where they would run with one wavefront per SIMD: a single free
         // integration, generated sensors, at most 1024 wavefronts of runs (C2's shape) -> mc_kernel_split<..., VIB = true>
@@ -1199,8 +1210,8 @@ __global__ void __launch_bounds__(kSeriesBlock, PASS == 2 ? kSeriesWaves - 1 : k
                         o[i][k] = tb + ud + m->white[k] * (double)normal_icdf(w, tab);
                     }
                     if (VIB) {          // added last, as pathgen.py:500, 562 do
-                        const Vec3 v = S ? add_vibration<S_GYR_VIB_XY>(Vec3{o[i][0], o[i][1], o[i][2]}, &kernarg_params()->vib_gyro, key, (uint32_t)j, tab, vpg)
-                                         : add_vibration<S_ACC_VIB_XY>(Vec3{o[i][0], o[i][1], o[i][2]}, &kernarg_params()->vib_accel, key, (uint32_t)j, tab, vpa);
+                        const Vec3 v = S ? add_vibration<S_GYR_VIB_XY>(Vec3{o[i][0], o[i][1], o[i][2]}, &kernarg_params()->vib_gyro, key, (uint32_t)j, tab, vpg, 0, 0)
+                                         : add_vibration<S_ACC_VIB_XY>(Vec3{o[i][0], o[i][1], o[i][2]}, &kernarg_params()->vib_accel, key, (uint32_t)j, tab, vpa, 0, 0);
                         o[i][0] = v.x; o[i][1] = v.y; o[i][2] = v.z;
                     }
                     if (!FULL && out) { st(out + j, o[i][0]); st(out + pl.sc + j, o[i][1]); st(out + 2 * pl.sc + j, o[i][2]); }
@@ -1269,7 +1280,7 @@ int series_pass_b(const ginsim_mc_params& p) { return any_vibration(p) ? 2 : (an
 
 // sensors only, few runs, long series
 bool series_path_applies(const ginsim_mc_params& p) {
-    return p.algo_mask == 0 && !p.given_sensors && p.precision == 0 && !p.wave_trace && p.block_threads == 0 &&
+    return p.algo_mask == 0 && !p.given_sensors && p.precision == 0 && !p.wave_trace && p.block_threads == 0 && !any_psd_vibration(p) &&
            p.runs <= 1024 && p.n >= 2048 && (p.sensor_layout == 1 || p.runs == 1);
 }
 

@@ -50,9 +50,13 @@ class SensorModel(C.Structure):
                 ('white', C.c_double * 3), ('white_drift', C.c_int32 * 3), ('reserved', C.c_int32)]
 
 
+VIB_PSD = 3
+
+
 class Vibration(C.Structure):
-    """ginsim_vibration (ABI 5): type 0 none / 1 random / 2 sinusoidal."""
-    _fields_ = [('type', C.c_int32), ('random_phase', C.c_int32), ('amp', C.c_double * 3), ('omega_dt', C.c_double)]
+    """ginsim_vibration (ABI 5): type 0 none / 1 random / 2 sinusoidal; ABI 8: 3 psd, a series on the device."""
+    _fields_ = [('type', C.c_int32), ('random_phase', C.c_int32), ('amp', C.c_double * 3), ('omega_dt', C.c_double),
+                ('series', C.c_void_p), ('period', C.c_int64)]
 
 
 class McParams(C.Structure):
@@ -135,6 +139,8 @@ _SIGS = {
     'ginsim_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
     'ginsim_comm_destroy': (C.c_int, [C.c_void_p]),
     'ginsim_comm_query': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'ginsim_vib_psd_series': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32,
+                                        C.c_void_p]),
     'ginsim_end_stats_all_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     'ginsim_end_stats_all_finish': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     'ginsim_process_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _PD]),

@@ -391,14 +391,15 @@ VIB_TYPES = {'random': 1, 'sinusoidal': 2}
 def vibration(vib_def, fs, random_phase):
     """ginsim_vibration from the reference's vib_def dict ({'type': 'random' | 'sinusoidal', 'x', 'y', 'z'[, 'freq']}, what
     Sim.__parse_env makes of an env string, ins_sim.py:642-701).  random_phase: gyro_gen draws one uniform phase per run and
-    axis for a sinusoidal vibration (pathgen.py:553-555), acc_gen uses phase 0 (:490-492).  'psd' is outside the path."""
+    axis for a sinusoidal vibration (pathgen.py:553-555), acc_gen uses phase 0 (:490-492).  A 'psd' definition (an (n, 4) env
+    array, ins_sim.py:686-697) needs its series on the device first: MonteCarloJob makes them (psd_amplitudes,
+    ginsim_vib_psd_series) and fills type 3 in itself."""
     v = _lib.Vibration()
     if vib_def is None:
         return v
     kind = str(vib_def['type']).lower()
     if kind == 'psd':
-        raise NotImplementedError("vibration from a PSD (time_series_from_psd.py: an inverse FFT per run and axis) is outside "
-                                  "the accelerated path (SURVEY.md section 2, #15); 'random' and 'sinusoidal' run on the device")
+        raise ValueError("a 'psd' vibration is a series per run: MonteCarloJob(vib_accel=..., vib_gyro=...) makes it on the device")
     if kind not in VIB_TYPES:
         raise ValueError('unknown vibration type %r' % (vib_def['type'],))
     v.type = VIB_TYPES[kind]
@@ -408,6 +409,37 @@ def vibration(vib_def, fs, random_phase):
         v.omega_dt = 2.0 * math.pi * float(vib_def['freq']) * dt           # the reference's product, left to right
         v.random_phase = int(bool(random_phase))
     return v
+
+
+PSD_MAX_PERIOD = 16384          # time_series_from_psd.py:41-43
+
+
+def psd_amplitudes(vib_def, fs, n):
+    """The host part of time_series_from_psd.time_series_from_psd (time_series_from_psd.py:16-50) for the three axes of one
+    sensor: (period N, amplitudes (3, N // 2 + 1), given_on_grid) -- or None where the reference returns zeros (:32-34: the PSD
+    reaches beyond fs / 2).
+      N = n, n + 1 when n is odd, at most 16384 (:36-43; the series is tiled to n, :58-63)
+      the PSD interpolated to linspace(0, fs / 2, N // 2 + 1) unless it is GIVEN on that many points (:44-48)
+      interior bins halved (single- to double-sided, :49), a = sqrt(sxx N fs) (:50)
+    given_on_grid: the reference then halves the CALLER'S array in place at every call (no copy was made): run r of a batch
+    sees 0.5^(r + 1).  The amplitudes returned are then those of the array as it is now, nothing halved; the device applies the
+    run's factor (ginsim_vib_psd_series, halve_per_run) and the caller of a Sim mutates the arrays afterwards as the reference does."""
+    freq = np.asarray(vib_def['freq'], dtype=np.float64)
+    fs = float(fs)
+    if fs < 2.0 * freq[-1] or fs < 0.0:
+        return None
+    N = int(n) + (int(n) % 2)
+    N = min(N, PSD_MAX_PERIOD)
+    L = N // 2 + 1
+    on_grid = freq.shape[0] == L
+    amp = np.empty((3, L))
+    for c, k in enumerate('xyz'):
+        sxx = np.asarray(vib_def[k], dtype=np.float64)
+        if not on_grid:
+            sxx = np.interp(np.linspace(0, fs / 2.0, L), freq, sxx)
+            sxx[1:L - 1] = 0.5 * sxx[1:L - 1]
+        amp[c] = np.sqrt(sxx * N * fs)
+    return N, amp, on_grid
 
 
 def ini_table(ini):
@@ -566,8 +598,9 @@ class MonteCarloJob(object):
             p.gyro = sensor_model(gyro_err, 'arw', fs)
             # vibration (Sim(env=...)): vib_def dicts as Sim.__parse_env makes them; the lane-per-run kernels of both precisions
             # and the time-parallel series kernels carry the term
-            p.vib_accel = vibration(vib_accel, float(fs), random_phase=False)
-            p.vib_gyro = vibration(vib_gyro, float(fs), random_phase=True)
+            self._bufs = {}
+            p.vib_accel = self._vibration(ctx, vib_accel, 0, float(fs), precision)
+            p.vib_gyro = self._vibration(ctx, vib_gyro, 1, float(fs), precision)
         else:
             if vib_accel is not None or vib_gyro is not None:
                 raise ValueError('given sensors: a vibration model cannot be added to sensor series that already exist')
@@ -585,7 +618,7 @@ class MonteCarloJob(object):
         p.ref_end[:] = [float(x) for x in end]
         # device-resident inputs
         # (one allocation and one copy for all of them: ini table, truth specific force / angular rate [/ forward speed])
-        self._bufs = {}
+        self._bufs = getattr(self, '_bufs', {})
         parts = [table.reshape(-1), np.asarray(truth['ref_accel'], dtype=np.float64).reshape(-1),
                  np.asarray(truth['ref_gyro'], dtype=np.float64).reshape(-1)]
         if self.want_odo:
@@ -606,7 +639,7 @@ class MonteCarloJob(object):
         use_placed = (big >= ctx.PLACED_MIN_JOB) if placed is None else bool(placed)
         use_placed = bool(use_placed and big > 0 and ctx.placed_reserve(big))
         if self.keep_sensors:
-            if not self.algos and given is None and precision == 'f64':
+            if not self.algos and given is None and precision == 'f64' and _lib.VIB_PSD not in (p.vib_accel.type, p.vib_gyro.type):
                 # few runs, long series: the time-parallel series kernels, series-major output (the library decides)
                 p.sensor_layout = 1
                 v = C.c_int32(0)
@@ -839,6 +872,27 @@ class MonteCarloJob(object):
                 ini = self._ini_table[call if call < self._ini_table.shape[0] else 0]
                 pos[k] += geoparams.lla2ecef(ini[0:3]) if self._ref_frame == 1 else ini[0:3]
         return att, pos, vel
+
+    def _vibration(self, ctx, vib_def, sensor, fs, precision):
+        """ginsim_vibration of one sensor (0 accelerometer, 1 gyroscope).  A 'psd' definition becomes type 3: the series of all
+        runs, [3][period][runs], are made on the device now (pathgen.py:479-484 / :541-546 make them per run)."""
+        if vib_def is None or str(vib_def['type']).lower() != 'psd':
+            return vibration(vib_def, fs, random_phase=bool(sensor))
+        if precision != 'f64':
+            raise NotImplementedError("the 'psd' vibration runs on the fp64 kernels only")
+        v = _lib.Vibration()
+        made = psd_amplitudes(vib_def, fs, self.n)
+        if made is None:                # the reference's time_series_from_psd returns zeros (the PSD reaches beyond fs / 2)
+            return v
+        period, amp, on_grid = made
+        buf = self._bufs['vib_psd_%d' % sensor] = ctx.malloc(3 * period * self.runs * 8)
+        amp = np.ascontiguousarray(amp)
+        p = self.params
+        check(ctx.retry_oom(lambda: lib.ginsim_vib_psd_series(ctx.handle, amp.ctypes.data, period, self.runs, p.run_offset, p.seed,
+                                                             sensor, int(on_grid), buf.ptr)))
+        v.type, v.series, v.period = _lib.VIB_PSD, buf.ptr, period
+        self.psd_given_on_grid = getattr(self, 'psd_given_on_grid', False) or on_grid
+        return v
 
     def release(self):
         for b in self._bufs.values():

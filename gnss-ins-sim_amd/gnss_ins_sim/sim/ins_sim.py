@@ -239,7 +239,13 @@ class Sim(object):
         if isinstance(self.data_src, str) and os.path.isdir(self.data_src):
             self._run_from_files()
         else:
-            self._run_monte_carlo()
+            self._psd_on_grid = []
+            try:
+                self._run_monte_carlo()
+            finally:
+                for v in self._psd_on_grid:
+                    for k in 'xyz':
+                        v[k][1:-1] *= 0.5 ** self.sim_count
         self.sim_complete = True
 
     AUTO_SPREAD_WORK = 2 ** 30      # sample x run products from which an un-configured Sim uses every visible GPU
@@ -365,7 +371,8 @@ class Sim(object):
             if kinds[i] == 'odo' and not self.imu.odo:
                 raise ValueError("algorithm %d needs 'odo' but the IMU model has no odometer" % i)
 
-        # environment --> vibration parameters (ins_sim.py:482-489): 'random' and 'sinusoidal' models run in the kernels
+        # environment --> vibration parameters (ins_sim.py:482-489): 'random' and 'sinusoidal' models are terms of the kernels, a
+        # 'psd' model is a series per run and axis made on the device before the launch (ginsim_vib_psd_series)
         vib_acc = vib_gyro = None
         if self.env is not None:
             if 'acc' in self.env.keys():
@@ -373,9 +380,16 @@ class Sim(object):
             if 'gyro' in self.env.keys():
                 vib_gyro = self._parse_env(self.env['gyro'])
             for v in (vib_acc, vib_gyro):
-                if v is not None:
-                    ginsim.vibration(v, fs_imu, False)       # raises for what the device path does not carry (a PSD)
+                if v is not None and v['type'] != 'psd':
+                    ginsim.vibration(v, fs_imu, False)       # raises for a definition the kernels do not know
+                elif v is not None and self.precision != 'f64':
+                    raise NotImplementedError("the 'psd' vibration (an (n, 4) env array) runs on the fp64 kernels only")
         vib = dict(vib_accel=vib_acc, vib_gyro=vib_gyro)
+        # A PSD given on the series' own frequency grid is halved IN PLACE by the reference at every run and axis
+        # (time_series_from_psd.py:44-49: no copy is made when no interpolation is needed; the arrays are views of the caller's
+        # env).  The device applies run r's factor 0.5^(r + 1); the arrays are left as the reference leaves them, after the run.
+        self._psd_on_grid = [v for v in (vib_acc, vib_gyro) if v is not None and v['type'] == 'psd' and
+                             (ginsim.psd_amplitudes(v, fs_imu, n) or (0, 0, False))[2]]
 
         rank, world, group, xdev = self._dist()
         first, count = distributed.shard(self.sim_count, world, rank)

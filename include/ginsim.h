@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define GINSIM_ABI_VERSION 7
+#define GINSIM_ABI_VERSION 8
 
 /* status codes */
 #define GINSIM_OK          0
@@ -166,19 +166,40 @@ typedef struct {            /* one 3-axis sensor: pathgen.acc_gen / gyro_gen / b
  *   type 1 'random'      vib[j][k] = amp[k] N[j][k]                     (:485-488, :547-550; three more normals per sample)
  *   type 2 'sinusoidal'  vib[j][k] = amp[k] sin(omega_dt j + phase[k])  omega_dt = 2 pi freq dt; phase = 0 for the accelerometer
  *                        (:489-492), one uniform draw per run and axis times 2 pi for the gyroscope (:551-555)
- * The 'psd' type (time_series_from_psd.py, an inverse FFT per run and axis) is outside the path.
+ *   type 3 'psd' (ABI 8) vib[j][k] = series[k][j mod period][run]       (:479-484, :541-546: time_series_from_psd.py:16-63, a
+ *                        random-phase inverse FFT of `period` <= 16384 points per run and axis, tiled to n); the series are made
+ *                        on the device by ginsim_vib_psd_series BEFORE the launch and read by it
  * Vibration launches run on the general-sensor-model lane-per-run kernels (ginsim_mc_variant 0; fp64 and fp32 -- the fp32 term
  * is defined operation by operation, csrc/mc_kernel_f32.hip add_vibration) or, sensors only for few runs, on the time-parallel
- * series kernels (variant 2); given sensors refuse it. */
+ * series kernels (variant 2); given sensors refuse it.  Type 3 runs on the fp64 lane-per-run kernels only. */
 #define GINSIM_VIB_NONE       0
 #define GINSIM_VIB_RANDOM     1
 #define GINSIM_VIB_SINUSOIDAL 2
+#define GINSIM_VIB_PSD        3
 typedef struct {
     int32_t type;           /* GINSIM_VIB_* */
     int32_t random_phase;   /* sinusoidal: 1 = a uniform phase per run and axis (gyro_gen), 0 = phase 0 (acc_gen) */
     double  amp[3];         /* vib_def['x'/'y'/'z']: 1 sigma (random) or peak (sinusoidal), m/s^2 or rad/s */
     double  omega_dt;       /* sinusoidal: ((2.0 * pi) * freq) * dt, rounded as the reference's left-to-right product */
+    /* ---- ABI 8: type 3 ---- */
+    const double* series;   /* device [3][period][runs], run fastest: what ginsim_vib_psd_series wrote for THESE runs */
+    int64_t period;         /* N of time_series_from_psd.py:36-43: n (n + 1 when n is odd), at most 16384 */
 } ginsim_vibration;
+
+/* ABI 8.  The vibration series of one 3-axis sensor from a single-sided power spectral density, for `runs` Monte-Carlo runs at once
+ * (pathgen.py:479-484 / :541-546 call time_series_from_psd.time_series_from_psd(sxx, freq, fs, n) per run and axis):
+ *   x = real(ifft(X)),  X[k] = a[k] exp(i pi z[k]) for k = 0 .. period/2,  Hermitian above  (time_series_from_psd.py:51-57)
+ * amp (HOST, [3][period / 2 + 1]) = a = sqrt(sxx' period fs), sxx' the PSD interpolated to the period's frequency grid with its
+ * interior bins halved (:44-50) -- leaf arithmetic of O(period), left to the caller (ginsim.psd_amplitudes in the Python layer).
+ * z[k] (time_series_from_psd.py:52, np.random.randn(L)) are the normals the 'random' vibration of the same sensor would draw at
+ * SAMPLE k (streams 10 / 11 accel, 12 / 13 gyro of run run_offset + r): x, y, z of bin k.  One batched complex-to-real FFT
+ * (hipFFT, loaded at run time) per block of runs, then a transposition into out (DEVICE, [3][period][runs], run fastest), scaled
+ * by 1 / period.  sensor: 0 accelerometer, 1 gyroscope.
+ * halve_per_run = 1 reproduces what the reference does when the PSD is GIVEN on the period's own grid (freq.shape[0] ==
+ * period / 2 + 1): it then halves the caller's array in place at every call (:49 without the copy np.interp makes), so run r of a
+ * Sim.run() sees interior bins scaled by 0.5^(r + 1); amp is then a of the array as given (nothing halved). */
+int ginsim_vib_psd_series(ginsim_ctx* ctx, const double* amp, int64_t period, int64_t runs, uint64_t run_offset, uint64_t seed,
+                          int32_t sensor, int32_t halve_per_run, double* out);
 
 typedef struct {
     int64_t  n;             /* IMU samples per run */

@@ -277,7 +277,7 @@ def gm_coeffs(corr, drift, fs):
 
 def vibration_series(fs, n, vib_def, nv=None, u=None):
     """The vib term of pathgen.acc_gen / gyro_gen (pathgen.py:476-492 / 538-556) for R runs: (R,n,3) (or (1,n,3) when it is
-    the same for every run).  vib_def: the dict Sim.__parse_env makes ('random' | 'sinusoidal'; 'psd' is outside the path);
+    the same for every run).  vib_def: the dict Sim.__parse_env makes ('random' | 'sinusoidal'; 'psd': psd_series);
     nv (R,n,3): the normals of a 'random' vibration; u (R,3) or None: the uniforms of a sinusoidal vibration's random phases
     (gyro_gen: np.random.rand(1) per axis; None = phase 0, acc_gen)."""
     amp = np.array([vib_def['x'], vib_def['y'], vib_def['z']], dtype=np.float64)
@@ -292,6 +292,41 @@ def vibration_series(fs, n, vib_def, nv=None, u=None):
         phase = np.asarray(u, dtype=np.float64) * 2 * math.pi               # np.random.rand(1)*2*math.pi (:553)
         return amp * np.sin(arg[None, :, None] + phase[:, None, :])
     raise NotImplementedError(kind)
+
+
+def psd_series(vib_def, fs, n, z, calls_before=0):
+    """time_series_from_psd.time_series_from_psd (time_series_from_psd.py:16-63) for the three axes of one run, as pathgen.acc_gen /
+    gyro_gen call it (pathgen.py:479-484 / :541-546): (n, 3), or zeros where the reference returns status False.
+    z (L, 3): the normals np.random.randn(L) returned for x, y, z (:52).  calls_before: how many times the reference has already been
+    through this PSD -- it halves a PSD GIVEN on the series' own grid in place at every call (:44-49: no copy without the
+    interpolation), so run r of a batch starts from 0.5^r of the array; nothing is mutated here."""
+    freq = np.asarray(vib_def['freq'], dtype=np.float64)
+    out = np.zeros((n, 3))
+    if fs < 2.0 * freq[-1] or fs < 0.0:
+        return out
+    N = n + (n % 2)
+    repeat = N != n
+    if N > 16384:
+        N, repeat = 16384, True
+    L = N // 2 + 1
+    for c, key in enumerate('xyz'):
+        sxx = np.array(vib_def[key], dtype=np.float64)
+        if freq.shape[0] != L:
+            sxx = np.interp(np.linspace(0, fs / 2.0, L), freq, sxx)
+        else:
+            sxx[1:L - 1] = sxx[1:L - 1] * 0.5 ** calls_before
+        sxx[1:L - 1] = 0.5 * sxx[1:L - 1]
+        ax = np.sqrt(sxx * N * fs)
+        xk = ax * np.exp(1j * (math.pi * z[:, c]))
+        xk = np.hstack([xk, xk[-2:0:-1].conj()])
+        x = np.fft.ifft(xk).real
+        out[:, c] = np.hstack([np.tile(x, (n // N,)), x[0:n % N]]) if repeat else x
+    return out
+
+
+def psd_len(n):
+    """L of time_series_from_psd for a series of n samples."""
+    return min(n + (n % 2), 16384) // 2 + 1
 
 
 def sensor_errors(fs, ref, err, rw_key, nd, nw, vib=None):
@@ -419,6 +454,8 @@ def mc_vibration(seed, runs, fs, n, vib_def, sensor):
     if vib_def is None:
         return None
     kind = vib_def['type'].lower()
+    if kind == 'psd':       # the phases of bin k are the normals a 'random' vibration would draw at sample k; run r is call r
+        return np.stack([psd_series(vib_def, fs, n, philox.vib_normals(seed, r, psd_len(n), sensor), calls_before=int(r)) for r in runs])
     if kind == 'random':
         return vibration_series(fs, n, vib_def, nv=np.stack([philox.vib_normals(seed, r, n, sensor) for r in runs]))
     u = np.stack([philox.vib_phase_uniforms(seed, r, sensor) for r in runs]) if sensor == 'gyr' else None

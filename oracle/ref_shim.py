@@ -23,9 +23,11 @@ from . import philox
 
 class RandnShim:
     def __init__(self, seed, n, acc_corr, gyro_corr, gps_m=0, mag=False, odo=False, first_run=0, vib_acc=None, vib_gyro=None):
-        """vib_acc / vib_gyro: None | 'random' | 'sinusoidal' -- the vibration type Sim(env=...) gives each sensor: a 'random'
-        vibration draws randn(n) three times between the drift and the white-noise draws (pathgen.py:486-488, 548-550); a
-        'sinusoidal' gyro vibration draws np.random.rand(1) three times (:553-555), served by ``rand``."""
+        """vib_acc / vib_gyro: None | 'random' | 'sinusoidal' | ('psd', L) -- the vibration type Sim(env=...) gives each sensor: a
+        'random' vibration draws randn(n) three times between the drift and the white-noise draws (pathgen.py:486-488, 548-550); a
+        'psd' vibration randn(L) three times at the same place (:479-484, :541-546 -> time_series_from_psd.py:52; the status
+        False path draws nothing: pass None); a 'sinusoidal' gyro vibration draws np.random.rand(1) three times (:553-555),
+        served by ``rand``."""
         self.seed, self.n = seed, n
         self.vib = (vib_acc, vib_gyro)
         self._phase_k = 0
@@ -44,6 +46,9 @@ class RandnShim:
                 q.append(d[:, i].copy() if inf[i] else d.copy())
             if vib == 'random':
                 v = philox.vib_normals(self.seed, self.run, self.n, sensor)
+                q += [v[:, 0].copy(), v[:, 1].copy(), v[:, 2].copy()]
+            elif isinstance(vib, tuple) and vib[0] == 'psd':        # randn(L) for x, y, z (time_series_from_psd.py:52)
+                v = philox.vib_normals(self.seed, self.run, vib[1], sensor)
                 q += [v[:, 0].copy(), v[:, 1].copy(), v[:, 2].copy()]
             q.append(w.copy())
         if self.gps_m:

@@ -46,6 +46,9 @@ def golden_vibration(g):
             out.append(None)
             continue
         amp = g['vib_%s_amp' % sensor]
+        if str(g['vib_%s_type' % sensor]) == 'psd':      # fresh arrays, as they were BEFORE the reference's run (it halves a PSD given
+            out.append({'type': 'psd', 'freq': g['vib_%s_freq' % sensor].copy(), 'x': amp[0].copy(), 'y': amp[1].copy(), 'z': amp[2].copy()})
+            continue                                     # on the series' own grid in place: time_series_from_psd.py:44-49)
         v = {'type': str(g['vib_%s_type' % sensor]), 'x': float(amp[0]), 'y': float(amp[1]), 'z': float(amp[2])}
         if v['type'] == 'sinusoidal':
             v['freq'] = float(g['vib_%s_freq' % sensor])
@@ -54,6 +57,8 @@ def golden_vibration(g):
 
 
 T3_VIB = ['t3_vib_random_rf1', 't3_vib_sin_rf0', 't3_vib_mixed_rf1']
+# Sim(env=<(n, 4) PSD array>): interpolated + given on the grid (halved in place per run), an odd series length, a series tiled beyond 16384
+T3_PSD = ['t3_vib_psd_rf1', 't3_vib_psd_odd_rf0', 't3_vib_psd_tiled_rf0']
 
 
 @pytest.fixture(scope='session')

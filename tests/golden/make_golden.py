@@ -244,6 +244,35 @@ DEMO_IMU = {'gyro_b': np.array([0.0, 0.0, 0.0]),
             'accel_b_corr': np.array([200.0, 200.0, 200.0])}
 
 
+def psd_env(kind, unit=1.0):
+    """(rows, 4) single-sided PSD arrays [freq, x, y, z] for Sim(env=...) (ins_sim.py:115-121, :686-697).
+    'coarse': seven rows up to 60 Hz -- at fs = 100 Hz the rows above fs / 2 are cut by Sim.__parse_env and the rest is
+    interpolated to the series' grid (time_series_from_psd.py:44-48); 'grid<L>': L rows on linspace(0, 50, L), the grid of a
+    series of 2 (L - 1) samples at 100 Hz: no interpolation, the reference halves the array in place at every call (:49)."""
+    if kind == 'coarse':
+        f = np.array([0.0, 2.0, 5.0, 12.0, 25.0, 40.0, 60.0])
+        x = np.array([0.0, 1e-4, 4e-4, 9e-4, 2e-4, 5e-5, 1e-5])
+        return np.stack([f, unit * x, unit * 0.5 * x[::-1], unit * (x + 1e-4)], axis=1)
+    L = int(kind[4:])
+    f = np.linspace(0.0, 50.0, L)
+    x = 2e-4 * np.exp(-((f - 14.0) / 6.0) ** 2) + 1e-5
+    return np.stack([f, unit * x, unit * 0.3 * x, unit * (x[::-1] * 0.5)], axis=1)
+
+
+PSD_ODD = """ini lat (deg),ini lon (deg),ini alt (m),ini vx_body (m/s),ini vy_body (m/s),ini vz_body (m/s),ini yaw (deg),ini pitch (deg),ini roll (deg)
+31.5,120.4,10,3,0,0,20,0,0
+command type,yaw (deg),pitch (deg),roll (deg),vx_body (m/s),vy_body (m/s),vz_body (m/s),command duration (s),GPS visibility
+1,4,0,0,0.5,0,0,3.33,1
+"""
+
+PSD_LONG = """ini lat (deg),ini lon (deg),ini alt (m),ini vx_body (m/s),ini vy_body (m/s),ini vz_body (m/s),ini yaw (deg),ini pitch (deg),ini roll (deg)
+31.5,120.4,10,6,0,0,-70,0,0
+command type,yaw (deg),pitch (deg),roll (deg),vx_body (m/s),vy_body (m/s),vz_body (m/s),command duration (s),GPS visibility
+1,0.5,0,0,0.02,0,0,120,1
+1,-1,0,0,0,0,0,50,1
+"""
+
+
 def err_dict_arrays(prefix, e):
     return {prefix + k: np.array(v, dtype=np.float64) for k, v in e.items()}
 
@@ -270,8 +299,10 @@ def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=
     for a in algos:
         mod = free_integration_odo if a == 'odo' else free_integration
         objs.append(mod.FreeIntegration(ini.copy()))
-    sim = ins_sim.Sim([fs, fs_gps, 0.0], csv, ref_frame=ref_frame, imu=imu, env=env, algorithm=objs)
-    kind = lambda e: None if e is None else ('random' if 'random' in e.lower() else 'sinusoidal')
+    env_given = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in (env or {}).items()}    # the reference halves a PSD given
+    sim = ins_sim.Sim([fs, fs_gps, 0.0], csv, ref_frame=ref_frame, imu=imu, env=env, algorithm=objs)    # on the series' grid IN PLACE
+    kind = lambda e: None if e is None else (('psd', min(n + n % 2, 16384) // 2 + 1) if isinstance(e, np.ndarray) else
+                                             ('random' if 'random' in e.lower() else 'sinusoidal'))
     shim = RandnShim(SEED, n, imu.accel_err['b_corr'], imu.gyro_err['b_corr'], gps_m=m, mag=(axis == 9),
                      odo=odo_opt is not None, vib_acc=kind((env or {}).get('acc')), vib_gyro=kind((env or {}).get('gyro')))
     with injected(shim):
@@ -288,11 +319,13 @@ def t3_case(name, ref_frame, accuracy, gps, odo_opt, algos, R, fs_gps=0.0, axis=
     out['gyro'] = np.stack([d.gyro.data[r][k] for r in range(R)])
     for sensor in ('acc', 'gyro'):          # the env strings and what the reference's own Sim.__parse_env makes of them
         if env and sensor in env:
-            vd = sim._Sim__parse_env(env[sensor])
-            out['env_' + sensor] = np.array(env[sensor])
+            vd = sim._Sim__parse_env(env_given[sensor].copy() if isinstance(env_given[sensor], np.ndarray) else env_given[sensor])
+            out['env_' + sensor] = np.array(env_given[sensor])              # as it was BEFORE the run
             out['vib_%s_type' % sensor] = np.array(vd['type'])
             out['vib_%s_amp' % sensor] = np.array([vd['x'], vd['y'], vd['z']], dtype=np.float64)
-            out['vib_%s_freq' % sensor] = np.float64(vd.get('freq', 0.0))
+            out['vib_%s_freq' % sensor] = np.array(vd.get('freq', 0.0), dtype=np.float64)
+            if isinstance(env[sensor], np.ndarray):
+                out['env_%s_after' % sensor] = env[sensor].copy()           # what the reference left of the caller's array
     if odo_opt is not None:
         out['ref_odo'] = d.ref_odo.data
         out['odo'] = np.stack([d.odo.data[r][k] for r in range(R)])
@@ -624,6 +657,9 @@ CASES = [
     ('t3_vib_random_rf1', "t3_case('t3_vib_random_rf1', 1, 'mid-accuracy', False, None, ['fi'], 3, env={'acc': '[0.03 0.001 0.01]-random', 'gyro': '[0.1 0.2 0.3]d-random'})", ['t3_vib_random_rf1.npz']),
     ('t3_vib_sin_rf0', "t3_case('t3_vib_sin_rf0', 0, 'low-accuracy', False, {'scale': 0.999, 'stdv': 0.1}, ['fi', 'odo'], 3, env={'acc': '[0.01 0.02 0.03]g-2.5Hz-sinusoidal', 'gyro': '[0.5 0.4 0.3]d-0.7Hz-sinusoidal'})", ['t3_vib_sin_rf0.npz']),
     ('t3_vib_mixed_rf1', "t3_case('t3_vib_mixed_rf1', 1, dict(DEMO_IMU), False, None, ['fi'], 2, env={'acc': '[0.5 0.1 0.2]-12Hz-sinusoidal', 'gyro': '[0.002 0.001 0.003]-random'})", ['t3_vib_mixed_rf1.npz']),
+    ('t3_vib_psd_rf1', "t3_case('t3_vib_psd_rf1', 1, 'mid-accuracy', False, None, ['fi'], 3, env={'acc': psd_env('coarse'), 'gyro': psd_env('grid501', 1e-3)})", ['t3_vib_psd_rf1.npz']),
+    ('t3_vib_psd_odd_rf0', "t3_case('t3_vib_psd_odd_rf0', 0, 'low-accuracy', False, {'scale': 0.999, 'stdv': 0.1}, ['fi', 'odo'], 2, fs_gps=10.0, csv=PSD_ODD, env={'acc': '[0.02 0.01 0.03]-random', 'gyro': psd_env('coarse', 1e-2)})", ['t3_vib_psd_odd_rf0.npz']),
+    ('t3_vib_psd_tiled_rf0', "t3_case('t3_vib_psd_tiled_rf0', 0, 'high-accuracy', False, None, ['fi'], 2, fs_gps=10.0, csv=PSD_LONG, env={'acc': psd_env('coarse'), 'gyro': psd_env('coarse', 1e-3)})", ['t3_vib_psd_tiled_rf0.npz']),
     ('csv_case', 'csv_case()', ['csv_files_rf0.npz']),
     ('summary_case', 'summary_case()', ['summary_text_rf0.npz']),
     ('allan_case', 'allan_case()', ['allan_ref.npz']),

@@ -9,7 +9,7 @@ compared modulo 2*pi; end-point statistics 1e-7 relative (std of R=3..4 samples 
 import numpy as np
 import pytest
 
-from conftest import load_golden, assert_traj_close, ang_close, golden_vibration, T3_VIB
+from conftest import load_golden, assert_traj_close, ang_close, golden_vibration, T3_VIB, T3_PSD
 
 pytestmark = pytest.mark.gpu
 
@@ -186,7 +186,7 @@ def _golden_algo_order(name):
 
 
 @pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'] + T3_VIB +
-                         [n + ':plain' for n in T3_VIB])
+                         [n + ':plain' for n in T3_VIB] + T3_PSD)
 def test_t3_injected_noise_vs_reference(ctx, name, monkeypatch):
     """Unmodified reference Sim.run(R) fed the engine's Philox normals == fused kernel, per sample.  T3_VIB: the reference ran
     with Sim(env=...) -- random / sinusoidal vibration on either sensor (pathgen.py:476-492, 538-556); both kernels that carry the
@@ -209,6 +209,11 @@ def test_t3_injected_noise_vs_reference(ctx, name, monkeypatch):
     vib_acc, vib_gyro = golden_vibration(g)
     job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc_err, gyr_err, g['ini'], runs=R, algos=algos, odo_err=odo_err,
                                seed=int(g['seed']), keep_sensors=True, keep_traj=True, vib_accel=vib_acc, vib_gyro=vib_gyro).run()
+    if name in T3_PSD:
+        # env as an (n, 4) PSD array (pathgen.py:479-484, :541-546 -> time_series_from_psd.py): the series of every run and axis are
+        # made on the device before the launch (ginsim_vib_psd_series: the phases from the counter RNG, one batched inverse FFT) and
+        # read by the vibration variant of the lane-per-run kernel
+        assert job.kernel_name().startswith('ginsim::mc_kernel<') and job.kernel_name().endswith(', true>'), job.kernel_name()
     if name in T3_VIB:
         split = not plain and algos == ('free',)
         assert job.kernel_name().endswith(', true>') and job.kernel_name().startswith('ginsim::mc_kernel_split<' if split else 'ginsim::mc_kernel<'), job.kernel_name()

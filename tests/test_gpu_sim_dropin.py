@@ -80,7 +80,10 @@ def test_demo_free_integration_sequence(capsys):
     ('t3_vib_random_rf1', 'mid-accuracy', 1, None, ['fi'], True),
     ('t3_vib_sin_rf0', 'low-accuracy', 0, {'scale': 0.999, 'stdv': 0.1}, ['fi', 'odo'], True),
     ('t3_vib_sin_rf0', 'low-accuracy', 0, {'scale': 0.999, 'stdv': 0.1}, ['fi', 'odo'], False),
-    ('t3_vib_mixed_rf1', _demo_imu(), 1, None, ['fi'], False)])
+    ('t3_vib_mixed_rf1', _demo_imu(), 1, None, ['fi'], False),
+    # env as an (n, 4) PSD array (ins_sim.py:686-697): the accelerometer's interpolated to the series' grid, the gyroscope's given on it
+    ('t3_vib_psd_rf1', 'mid-accuracy', 1, None, ['fi'], True),
+    ('t3_vib_psd_rf1', 'mid-accuracy', 1, None, ['fi'], False)])
 def test_sim_with_a_vibration_environment(name, accuracy, rf, odo_opt, algo_tags, keep, capsys):
     """Sim(env={'acc': ..., 'gyro': ...}) (ins_sim.py:108-124, 482-495): the env STRINGS the golden recipe gave the unmodified
     reference, through the drop-in Sim -- sensor series per sample, end-point and process statistics as the reference computed
@@ -91,7 +94,7 @@ def test_sim_with_a_vibration_environment(name, accuracy, rf, odo_opt, algo_tags
     from demo_algorithms import free_integration_odo
     from demo_algorithms import free_integration
     g = load_golden(name)
-    env = {k: str(g['env_' + k]) for k in ('acc', 'gyro') if 'env_' + k in g}
+    env = {k: (g['env_' + k].copy() if g['env_' + k].ndim == 2 else str(g['env_' + k])) for k in ('acc', 'gyro') if 'env_' + k in g}
     assert env
     csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
     imu = imu_model.IMU(accuracy=accuracy, axis=6, gps=False, odo=odo_opt is not None, odo_opt=odo_opt)
@@ -101,6 +104,9 @@ def test_sim_with_a_vibration_environment(name, accuracy, rf, odo_opt, algo_tags
     sim = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=rf, imu=imu, mode=None, env=env, algorithm=algos, seed=int(g['seed']),
                       keep_trajectories=keep, keep_runs=0 if keep else 2, stats_start=2.0)
     sim.run(R)
+    for sensor, e in env.items():           # a PSD given on the series' grid is left as the reference leaves the caller's array: halved
+        if isinstance(e, np.ndarray):       # once per run (time_series_from_psd.py:44-49 works in place when it need not interpolate)
+            np.testing.assert_allclose(e, g['env_%s_after' % sensor], rtol=1e-15, atol=0)
     k = g['rows']
     d = sim.dmgr
     for r in range(R if keep else 2):

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(raw, s)]
     assert not missing, 'declared in include/ginsim.h but not exported: %s' % missing
     assert set(ginsim.EXPORTS) <= declared
-    assert ginsim.lib.ginsim_abi_version() == 7
+    assert ginsim.lib.ginsim_abi_version() == 8
 
 
 def test_no_gpu_fails_loudly():
@@ -501,7 +501,7 @@ def test_dispatch_queries_and_sensor_layout_rules_without_a_gpu():
 
 def test_env_strings_parse_like_the_reference_and_bad_ones_raise():
     """Sim.__parse_env (ins_sim.py:642-701): units ('g' = 9.8 m/s^2, 'd' = deg/s), the frequency of a sinusoidal model, the
-    exceptions of malformed strings; a PSD array is parsed (cut at fs/2) and then refused by the device path."""
+    exceptions of malformed strings; a PSD array is parsed (cut at fs/2)."""
     from gnss_ins_sim.sim import imu_model
     from gnss_ins_sim.sim import ins_sim
     csv = os.path.join(PKG, 'motion_profiles', 'turn_90deg.csv')
@@ -523,8 +523,30 @@ def test_env_strings_parse_like_the_reference_and_bad_ones_raise():
     psd = np.array([[1.0, 1e-3, 1e-3, 1e-3], [20.0, 2e-3, 2e-3, 2e-3], [60.0, 1e-3, 1e-3, 1e-3]])
     v = sim._parse_env(psd)
     assert v['type'] == 'psd' and v['freq'].tolist() == [1.0, 20.0]                          # 60 Hz is above fs / 2
-    s2 = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, env={'acc': psd}, algorithm=None)
-    with pytest.raises(NotImplementedError, match='PSD'):
+    # the PSD goldens: what the reference's own __parse_env made of the arrays (the cut at fs / 2), and the host half of
+    # time_series_from_psd (ginsim.psd_amplitudes: period, interpolation, halving, a = sqrt(sxx N fs))
+    import ginsim
+    g = load_golden('t3_vib_psd_rf1')
+    for sensor in ('acc', 'gyro'):
+        v = sim._parse_env(g['env_' + sensor].copy())
+        assert v['type'] == 'psd' and np.array_equal(v['freq'], g['vib_%s_freq' % sensor])
+        assert np.array_equal([v['x'], v['y'], v['z']], g['vib_%s_amp' % sensor])
+    acc = sim._parse_env(g['env_acc'].copy())
+    N, amp, on_grid = ginsim.psd_amplitudes(acc, 100.0, 1000)
+    assert (N, amp.shape, on_grid) == (1000, (3, 501), False) and acc['freq'][-1] == 40.0        # the 60 Hz row is gone
+    sxx = np.interp(np.linspace(0, 50.0, 501), acc['freq'], acc['y'])
+    sxx[1:500] *= 0.5
+    assert np.array_equal(amp[1], np.sqrt(sxx * 1000 * 100.0)) and amp[1][-1] == np.sqrt(acc['y'][-1] * 1e5)   # beyond the last row np.interp holds it; the end bins are not halved
+    gyr = sim._parse_env(g['env_gyro'].copy())
+    before = gyr['x'].copy()
+    N, amp, on_grid = ginsim.psd_amplitudes(gyr, 100.0, 1000)
+    assert on_grid and np.array_equal(amp[0], np.sqrt(before * 1000 * 100.0)) and np.array_equal(gyr['x'], before)   # nothing halved, nothing touched
+    assert ginsim.psd_amplitudes(gyr, 100.0, 333)[0] == 334 and ginsim.psd_amplitudes(gyr, 100.0, 17000)[0] == 16384
+    assert ginsim.psd_amplitudes(gyr, 90.0, 1000) is None                                            # fs < 2 freq[-1]: the reference returns zeros
+    with pytest.raises(ValueError, match='psd'):
+        ginsim.vibration(gyr, 100.0, False)                                                          # a series per run, not a term: MonteCarloJob makes it
+    s2 = ins_sim.Sim([100.0, 0.0, 0.0], csv, ref_frame=1, imu=imu, env={'acc': psd}, algorithm=None, precision='f32')
+    with pytest.raises(NotImplementedError, match='fp64'):
         s2.run(1)
 
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import ins_np, philox
-from conftest import load_golden, assert_traj_close, ang_close, golden_vibration, T3_VIB
+from conftest import load_golden, assert_traj_close, ang_close, golden_vibration, T3_VIB, T3_PSD
 
 
 def test_philox_known_answers():
@@ -189,15 +189,17 @@ def _errs(g):
     return acc, gyr
 
 
-@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'] + T3_VIB)
+@pytest.mark.parametrize('name', ['t3_demo_rf1', 't3_mid_rf0', 't3_white_gps_rf0', 't3_low_rf1', 't3_high_odo_rf0', 't3_drive200_rf0'] + T3_VIB + T3_PSD)
 def test_t3_injected_noise_end_to_end(name):
-    """T3_VIB: the same with Sim(env=...) -- random and sinusoidal vibration models (pathgen.py:476-492, 538-556)."""
+    """T3_VIB: the same with Sim(env=...) -- random and sinusoidal vibration models (pathgen.py:476-492, 538-556).  T3_PSD: env as an
+    (n, 4) PSD array (:479-484, :541-546 -> time_series_from_psd.py): interpolated to the series' grid, given on it (the reference then
+    halves the caller's array in place at every run), an odd series length, a series tiled beyond 16384 samples."""
     g = load_golden(name)
     R, k, fs, rf = int(g['R']), g['rows'], float(g['fs']), int(g['ref_frame'])
     acc_err, gyr_err = _errs(g)
     runs = np.arange(R)
     vib_acc, vib_gyro = golden_vibration(g)
-    assert (name in T3_VIB) == (vib_acc is not None or vib_gyro is not None)
+    assert (name in T3_VIB + T3_PSD) == (vib_acc is not None or vib_gyro is not None)
     accel, gyro = ins_np.mc_sensors(int(g['seed']), runs, fs, g['ref_accel'], g['ref_gyro'], acc_err, gyr_err, vib_acc, vib_gyro)
     np.testing.assert_allclose(accel[:, k], g['accel'], rtol=0, atol=1e-12)
     np.testing.assert_allclose(gyro[:, k], g['gyro'], rtol=0, atol=1e-14)
