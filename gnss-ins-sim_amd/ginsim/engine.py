@@ -150,6 +150,13 @@ class Context(object):
         if not self.placed_enabled:
             return False
         self._placed_configure()
+        # Growing means a search (0.3 - 4 s).  Jobs that are no longer reachable but sit in reference cycles -- a Sim the script has
+        # replaced by the next one -- still hold their regions until the collector runs: let it run first when what is free would
+        # not do (a script that makes one Sim after another then re-uses the same stripes: 3 ms instead of a search per Sim)
+        i = _lib.PlacedInfo()
+        if lib.ginsim_placed_info_get(self.handle, C.byref(i)) == 0 and i.mapped_bytes > 0 and i.mapped_bytes - i.used_bytes < int(nbytes):
+            import gc
+            gc.collect()
         rc = lib.ginsim_placed_reserve(self.handle, int(nbytes))
         if rc != 0:
             self._placed_refused(rc)
@@ -180,9 +187,12 @@ class Context(object):
         pool, the pool is given back to the driver and the call is made once more (the library's own allocations -- scratch
         regions, gather buffers -- do not know about the pool)."""
         rc = call()
-        if rc == _lib.ERR_NOMEM and self._pool_bytes:       # hipErrorOutOfMemory only (ABI 7): no other failure is retried
-            self.release_pool()
-            rc = call()
+        if rc == _lib.ERR_NOMEM:                            # hipErrorOutOfMemory only (ABI 7): no other failure is retried
+            import gc
+            gc.collect()                                    # unreachable jobs in reference cycles park their regions in the pool now
+            if self._pool_bytes:
+                self.release_pool()
+                rc = call()
         return rc
 
     def name(self):

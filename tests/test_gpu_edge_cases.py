@@ -433,6 +433,123 @@ def test_vibration_models_against_the_oracles(ctx, turn, case, rf, algos):
         q.release()
 
 
+def _psd_def(unit=1.0, grid=None):
+    """a vib_def of type 'psd' as Sim.__parse_env makes it from an (n, 4) array: six rows to interpolate, or `grid` rows on the grid
+    of a series of 2 (grid - 1) samples at 100 Hz"""
+    if grid is None:
+        f = np.array([0.0, 1.0, 4.0, 11.0, 30.0, 50.0])
+        x = unit * np.array([0.0, 2e-4, 8e-4, 3e-4, 1e-4, 2e-5])
+    else:
+        f = np.linspace(0.0, 50.0, grid)
+        x = unit * (3e-4 * np.exp(-((f - 9.0) / 5.0) ** 2) + 2e-5)
+    return {'type': 'psd', 'freq': f, 'x': x.copy(), 'y': 0.5 * x[::-1], 'z': x + unit * 1e-4}
+
+
+@pytest.mark.parametrize('rf,algos', [(1, ('free',)), (0, ('free', 'odo'))])
+def test_psd_vibration_against_the_oracle(ctx, turn, rf, algos):
+    """Sim(env=<PSD array>) (ABI 8; pathgen.py:479-484, :541-546 -> time_series_from_psd.py): a ragged batch with global run ids
+    offset -- the accelerometer's PSD interpolated, the gyroscope's given on the series' own grid (the reference halves that one
+    in place at every run: run g sees 0.5^(g + 1)) -- sensors per sample and trajectories against the NumPy restatement, which
+    the goldens hold to the reference; the launch is invariant to how the runs are split (the phases belong to the GLOBAL run id)."""
+    import ginsim
+    from ginsim import workloads
+    from oracle import ins_np
+    ini, truth = turn[rf]
+    n = truth['ref_accel'].shape[0]
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    va, vg = _psd_def(), _psd_def(1e-3, grid=n // 2 + 1)
+    before = vg['x'].copy()
+    odo_err = {'scale': 0.999, 'stdv': 0.1}
+    R, off, seed = 150, 37, 99
+    kw = dict(algos=algos, odo_err=odo_err, seed=seed, vib_accel=va, vib_gyro=vg)
+    job = ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc, gyr, ini, runs=R, run_offset=off, keep_sensors=True, keep_traj=True, **kw).run()
+    assert job.kernel_name().startswith('ginsim::mc_kernel<') and job.kernel_name().endswith('true>') and job.psd_given_on_grid
+    assert np.array_equal(vg['x'], before)                  # the engine mutates nothing (the drop-in Sim does, as the reference)
+    runs = np.arange(off, off + R)
+    a_ref, g_ref = ins_np.mc_sensors(seed, runs, 100.0, truth['ref_accel'], truth['ref_gyro'], acc, gyr, va, vg)
+    pick = np.array([0, 63, 64, 149])
+    np.testing.assert_allclose(job.sensors('accel', pick), a_ref[pick], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(job.sensors('gyro', pick), g_ref[pick], rtol=0, atol=1e-14)
+    a_plain, _ = ins_np.mc_sensors(seed, runs[pick], 100.0, truth['ref_accel'], truth['ref_gyro'], acc, gyr)
+    assert np.abs(a_ref[pick] - a_plain).std() > 0.05       # the term is there: ~0.1 m/s^2 rms
+    odo = ins_np.mc_odo(seed, runs[pick], truth['ref_odo'], odo_err) if 'odo' in algos else None
+    for a in algos:
+        att, pos, vel = ins_np.free_integration(rf, 100.0, g_ref[pick], a_ref[pick], ini, odo=odo if a == 'odo' else None)
+        got = job.trajectories(a, pick)
+        np.testing.assert_allclose(got[2], vel, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(got[1], pos, rtol=1e-12, atol=1e-8)
+        assert np.max(np.abs(np.mod(got[0] - att + np.pi, 2 * np.pi) - np.pi)) < 1e-10
+    # the same runs as two launches: their series come out of FFT batches of other sizes -- equal to rounding, not to the bit
+    parts = [ginsim.MonteCarloJob(ctx, 100.0, rf, truth, acc, gyr, ini, runs=r, run_offset=off + o, **kw).run() for o, r in ((0, 70), (70, 80))]
+    for a in algos:
+        np.testing.assert_allclose(np.concatenate([q.end_errors(a) for q in parts])[:, 3:], job.end_errors(a)[:, 3:], rtol=1e-9, atol=1e-9)
+    for q in parts + [job]:
+        q.release()
+
+
+def test_psd_vibration_series_in_blocks_tiled_and_refused(ctx, turn):
+    """ginsim_vib_psd_series makes its series in blocks of runs (two buffers of about 256 MiB): 700 runs of a 16384-point period
+    are two blocks (640 + 60); a series longer than 16384 samples repeats the period (time_series_from_psd.py:41-43, :58-63); a PSD
+    that reaches beyond fs / 2 gives the reference's zeros (:32-34) -- no term at all, the bits of the launch without an
+    environment; what the kernels do not carry is refused."""
+    import ctypes as C
+    import ginsim
+    from ginsim import workloads, _lib
+    from oracle import ins_np
+    ini, truth = turn[1]
+    acc, gyr = workloads.imu_grade('low-accuracy')
+    n = 16384 + 600
+    long_truth = {k: (np.concatenate([v] * 17)[:n] if hasattr(v, 'shape') and v.shape and v.shape[0] == 1000 else v) for k, v in truth.items()}
+    va = _psd_def()
+    R, seed = 700, 5
+    job = ginsim.MonteCarloJob(ctx, 100.0, 1, long_truth, acc, gyr, None, runs=R, algos=(), seed=seed, keep_sensors=True, vib_accel=va).run()
+    assert job.params.vib_accel.period == 16384 and job.params.vib_accel.type == 3 and job.sensor_layout == 'runs'
+    pick = np.array([0, 639, 640, 699])
+    a_ref, g_ref = ins_np.mc_sensors(seed, pick, 100.0, long_truth['ref_accel'], long_truth['ref_gyro'], acc, gyr, va, None)
+    got = job.sensors('accel', pick)
+    np.testing.assert_allclose(got, a_ref, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(job.sensors('gyro', pick), g_ref, rtol=0, atol=1e-14)
+    vib = got - ins_np.mc_sensors(seed, pick, 100.0, long_truth['ref_accel'], long_truth['ref_gyro'], acc, gyr)[0]
+    np.testing.assert_allclose(vib[:, 16384:], vib[:, :600], rtol=0, atol=1e-12)          # the period repeats
+    job.release()
+    # beyond fs / 2: zeros
+    ini1, t1 = turn[1]
+    far = _psd_def()
+    far['freq'] = far['freq'] * 1.2
+    a = ginsim.MonteCarloJob(ctx, 100.0, 1, t1, acc, gyr, ini1, runs=64, seed=3, keep_sensors=True, vib_gyro=far).run()
+    b = ginsim.MonteCarloJob(ctx, 100.0, 1, t1, acc, gyr, ini1, runs=64, seed=3, keep_sensors=True).run()
+    assert a.params.vib_gyro.type == 0 and np.array_equal(a.sensors('gyro', np.arange(64)), b.sensors('gyro', np.arange(64)))
+    # refusals
+    with pytest.raises(NotImplementedError, match='fp64'):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, t1, acc, gyr, ini1, runs=64, precision='f32', vib_accel=va)
+    with pytest.raises(ValueError, match='given sensors'):
+        ginsim.MonteCarloJob(ctx, 100.0, 1, t1, None, None, ini1, runs=64, vib_accel=va, given={'gyro': a.buffer('gyro'), 'accel': a.buffer('accel')})
+    b.params.vib_accel.type = 3                                 # type 3 without its series
+    with pytest.raises(ValueError, match='series'):
+        b.run()
+    buf = ctx.malloc(3 * 8 * 64 * 8)
+    amp = np.ones((3, 5))
+    for period, runs_, sensor in ((7, 64, 0), (16386, 64, 0), (8, 0, 0), (8, 64, 2)):
+        with pytest.raises(ValueError):
+            _lib.check(ginsim.lib.ginsim_vib_psd_series(ctx.handle, amp.ctypes.data, period, runs_, 0, 1, sensor, 0, buf.ptr))
+    amp[1, 2] = -1.0
+    with pytest.raises(ValueError, match='amplitude'):
+        _lib.check(ginsim.lib.ginsim_vib_psd_series(ctx.handle, amp.ctypes.data, 8, 64, 0, 1, 0, 0, buf.ptr))
+    # the smallest period: two samples, bins 0 and 1 (both real in the inverse transform)
+    amp = np.array([[4.0, 2.0], [0.0, 6.0], [8.0, 0.0]])
+    _lib.check(ginsim.lib.ginsim_vib_psd_series(ctx.handle, amp.ctypes.data, 2, 64, 11, 7, 1, 0, buf.ptr))
+    x = ctx.download(buf, (3, 2, 64))
+    from oracle import philox
+    for r in (0, 63):
+        z = philox.vib_normals(7, 11 + r, 2, 'gyr')
+        c = np.cos(np.pi * z)                                   # (bin, axis)
+        want = np.stack([(amp[:, 0] * c[0] + amp[:, 1] * c[1]) / 2.0, (amp[:, 0] * c[0] - amp[:, 1] * c[1]) / 2.0], axis=1)
+        np.testing.assert_allclose(x[:, :, r], want, rtol=0, atol=1e-14)
+    buf.free()
+    for q in (a, b):
+        q.release()
+
+
 @pytest.mark.parametrize('case', sorted(VIB_CASES))
 @pytest.mark.parametrize('runs,n', [(1, 50000), (6, 4099)])
 def test_vibration_on_the_time_parallel_series_kernels(ctx, case, runs, n):
