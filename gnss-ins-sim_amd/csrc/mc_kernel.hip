@@ -358,18 +358,26 @@ __device__ __forceinline__ Vec3 vibration_term(const Vec3& o, vib_ptr v, double 
     return r;
 }
 
-// run / runs: the lane's run and the batch's size (the layout of the 'psd' series, [axis][sample mod period][run])
+// The three values of sample j of a 'psd' vibration (ABI 8): the series were made before the launch (vib_psd.hip), [axis][sample mod
+// period][run], tiled to n (time_series_from_psd.py:58-63).  Zero for every other type.  Called at the TOP of a step, ~800
+// instructions before the sum that takes the values: asked for next to the sum, the loads cost their whole latency every step.
+__device__ __forceinline__ Vec3 psd_vibration(vib_ptr v, uint32_t j, int64_t run, int64_t runs) {
+    if (v->type != GINSIM_VIB_PSD) return Vec3{0.0, 0.0, 0.0};
+    const int64_t period = v->period;
+    const double* s = v->series + (int64_t)(j % (uint32_t)period) * runs + run;
+    const int64_t pl = period * runs;
+    return Vec3{__builtin_nontemporal_load(s), __builtin_nontemporal_load(s + pl), __builtin_nontemporal_load(s + 2 * pl)};
+}
+
+// psd: psd_vibration() of this sensor and sample
 template <uint32_t STREAM>
 __device__ __forceinline__ Vec3 add_vibration(const Vec3& o, vib_ptr v, const RngKey& key, uint32_t j, const NormalTables& tab,
-                                              const Vec3& phase, int64_t run, int64_t runs) {
+                                              const Vec3& phase, const Vec3& psd) {
     Vec3 r = o;
-    if (v->type == GINSIM_VIB_PSD) {                // made before the launch (vib_psd.hip), tiled to n (time_series_from_psd.py:58-63)
-        const int64_t period = v->period;
-        const double* s = v->series + (int64_t)(j % (uint32_t)period) * runs + run;
-        const int64_t pl = period * runs;
-        r.x = o.x + s[0];
-        r.y = o.y + s[pl];
-        r.z = o.z + s[2 * pl];
+    if (v->type == GINSIM_VIB_PSD) {
+        r.x = o.x + psd.x;
+        r.y = o.y + psd.y;
+        r.z = o.z + psd.z;
     } else if (v->type == GINSIM_VIB_RANDOM) {
         double z0[2], z1[2];
         normal_pairs<STREAM, 2>(key, j, z0, z1, tab);
@@ -485,6 +493,11 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a, co
             const uint32_t jj = (uint32_t)j;
             // wave-uniform truth of this step: requested here, ~800 instructions before the sensor sums use it
             const Vec3 cur_a = load3(as_uniform(a.ref_accel), j), cur_g = load3(as_uniform(a.ref_gyro), j);
+            Vec3 psd_a{0.0, 0.0, 0.0}, psd_g{0.0, 0.0, 0.0};
+            if (VIB) {
+                psd_a = psd_vibration(&kernarg_params()->vib_accel, jj, r, runs);
+                psd_g = psd_vibration(&kernarg_params()->vib_gyro, jj, r, runs);
+            }
             const bool need_acc = FREE || a.out_accel;
             const bool need_gyr = FREE || ODO || a.out_gyro;
             const bool need_odo = ODO || a.out_odo;
@@ -504,8 +517,8 @@ __global__ void __launch_bounds__(256, 2) mc_kernel(const ginsim_mc_params a, co
                 gyr = sense3<WD>(cur_g, &kernarg_params()->gyro, dg, Vec3{z0[0], z1[0], z0[1]}, Vec3{z1[1], z0[2], z1[2]});
             }
             if (VIB) {
-                if (need_acc) acc = add_vibration<S_ACC_VIB_XY>(acc, &kernarg_params()->vib_accel, key, jj, tab, vpa, r, runs);
-                if (need_gyr) gyr = add_vibration<S_GYR_VIB_XY>(gyr, &kernarg_params()->vib_gyro, key, jj, tab, vpg, r, runs);
+                if (need_acc) acc = add_vibration<S_ACC_VIB_XY>(acc, &kernarg_params()->vib_accel, key, jj, tab, vpa, psd_a);
+                if (need_gyr) gyr = add_vibration<S_GYR_VIB_XY>(gyr, &kernarg_params()->vib_gyro, key, jj, tab, vpg, psd_g);
             }
             if (need_acc && a.out_accel) store3(a.out_accel, plane, off, acc);
             if (need_gyr && a.out_gyro) store3(a.out_gyro, plane, off, gyr);
@@ -1210,8 +1223,8 @@ __global__ void __launch_bounds__(kSeriesBlock, PASS == 2 ? kSeriesWaves - 1 : k
                         o[i][k] = tb + ud + m->white[k] * (double)normal_icdf(w, tab);
                     }
                     if (VIB) {          // added last, as pathgen.py:500, 562 do
-                        const Vec3 v = S ? add_vibration<S_GYR_VIB_XY>(Vec3{o[i][0], o[i][1], o[i][2]}, &kernarg_params()->vib_gyro, key, (uint32_t)j, tab, vpg, 0, 0)
-                                         : add_vibration<S_ACC_VIB_XY>(Vec3{o[i][0], o[i][1], o[i][2]}, &kernarg_params()->vib_accel, key, (uint32_t)j, tab, vpa, 0, 0);
+                        const Vec3 v = S ? add_vibration<S_GYR_VIB_XY>(Vec3{o[i][0], o[i][1], o[i][2]}, &kernarg_params()->vib_gyro, key, (uint32_t)j, tab, vpg, Vec3{0.0, 0.0, 0.0})
+                                         : add_vibration<S_ACC_VIB_XY>(Vec3{o[i][0], o[i][1], o[i][2]}, &kernarg_params()->vib_accel, key, (uint32_t)j, tab, vpa, Vec3{0.0, 0.0, 0.0});
                         o[i][0] = v.x; o[i][1] = v.y; o[i][2] = v.z;
                     }
                     if (!FULL && out) { st(out + j, o[i][0]); st(out + pl.sc + j, o[i][1]); st(out + 2 * pl.sc + j, o[i][2]); }

@@ -94,13 +94,25 @@ _QUIET = {'b': np.zeros(3), 'b_drift': np.zeros(3), 'b_corr': np.array([np.inf, 
           'vrw': np.zeros(3)}
 
 
+def _psd_given_on_grid(vib_def, fs, n):
+    """A 'psd' vib_def whose arrays lie on the series' own frequency grid is halved IN PLACE by the reference at every call
+    (time_series_from_psd.py:44-49: no copy without the interpolation): leave the caller's arrays as the reference does."""
+    import ginsim
+    if vib_def is not None and str(vib_def['type']).lower() == 'psd':
+        made = ginsim.psd_amplitudes(vib_def, fs, n)
+        if made is not None and made[2]:
+            for k in 'xyz':
+                vib_def[k][1:-1] *= 0.5
+
+
 def acc_gen(fs, ref_a, acc_err, vib_def=None, *, seed=None):
     """pathgen.acc_gen (pathgen.py:441-501): true specific force (n,3) + bias + Gauss-Markov drift + white noise + vibration
-    (vib_def: {'type': 'random' | 'sinusoidal', 'x', 'y', 'z'[, 'freq']}; a 'psd' vibration is outside the device path)."""
+    (vib_def: {'type': 'random' | 'sinusoidal', 'x', 'y', 'z'[, 'freq']}, or {'type': 'psd', 'freq', 'x', 'y', 'z'} arrays)."""
     ref_a = np.asarray(ref_a, dtype=np.float64)
     job = _one_run_sensors(fs, ref_a, np.zeros_like(ref_a), acc_err, _QUIET, seed=seed, vib_accel=vib_def)
     out = job.sensors('accel', [0])[0]
     job.release()
+    _psd_given_on_grid(vib_def, fs, ref_a.shape[0])
     return out
 
 
@@ -110,6 +122,7 @@ def gyro_gen(fs, ref_w, gyro_err, vib_def=None, *, seed=None):
     job = _one_run_sensors(fs, np.zeros_like(ref_w), ref_w, _QUIET, gyro_err, seed=seed, vib_gyro=vib_def)
     out = job.sensors('gyro', [0])[0]
     job.release()
+    _psd_given_on_grid(vib_def, fs, ref_w.shape[0])
     return out
 
 

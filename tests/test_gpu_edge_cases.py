@@ -384,9 +384,23 @@ def test_pathgen_sensor_generators_under_their_reference_names(ctx):
     _, w_ref = ins_np.mc_sensors(92, np.array([0]), 100.0, zero, truth['ref_gyro'], quiet, gyr, vib_gyro=vs)
     np.testing.assert_allclose(wv, w_ref[0], rtol=0, atol=1e-14)
     assert abs(np.abs(wv - w)[:, 2].max() - 0.03) < 1e-3            # a sine of the peak value given
-    with pytest.raises(NotImplementedError, match='PSD'):
-        pathgen.acc_gen(100.0, truth['ref_accel'], acc, vib_def={'type': 'psd', 'freq': np.array([1.0, 10.0]), 'x': np.ones(2),
-                                                                'y': np.ones(2), 'z': np.ones(2)})
+    # a PSD (ABI 8; pathgen.py:479-484 -> time_series_from_psd.py): interpolated, and GIVEN on the series' grid -- the reference halves
+    # that one in place at every call, so the second call of the same arrays sees a quarter
+    vp = {'type': 'psd', 'freq': np.array([0.0, 10.0, 30.0]), 'x': np.array([1e-3, 4e-3, 1e-3]), 'y': np.full(3, 2e-3), 'z': np.full(3, 1e-3)}
+    ap = pathgen.acc_gen(100.0, truth['ref_accel'], acc, vp, seed=91)
+    a_ref, _ = ins_np.mc_sensors(91, np.array([0]), 100.0, truth['ref_accel'], zero, acc, quiet, vib_accel=vp)
+    np.testing.assert_allclose(ap, a_ref[0], rtol=0, atol=1e-12)
+    assert 0.2 < (ap - a).std() < 0.5 and vp['x'].tolist() == [1e-3, 4e-3, 1e-3]
+    n = truth['ref_gyro'].shape[0]
+    f = np.linspace(0.0, 50.0, n // 2 + 1)
+    vg = {'type': 'psd', 'freq': f, 'x': np.full(f.shape, 1e-6), 'y': np.full(f.shape, 2e-6), 'z': 1e-6 * (1.0 + f / 50.0)}
+    keep = {k: vg[k].copy() for k in 'xyz'}
+    w1 = pathgen.gyro_gen(100.0, truth['ref_gyro'], gyr, vg, seed=92)
+    _, w_ref = ins_np.mc_sensors(92, np.array([0]), 100.0, zero, truth['ref_gyro'], quiet, gyr, vib_gyro=dict(vg, **keep))
+    np.testing.assert_allclose(w1, w_ref[0], rtol=0, atol=1e-14)
+    assert np.array_equal(vg['y'][1:-1], 0.5 * keep['y'][1:-1]) and vg['y'][0] == keep['y'][0] and vg['y'][-1] == keep['y'][-1]
+    w2 = pathgen.gyro_gen(100.0, truth['ref_gyro'], gyr, vg, seed=92)                       # the same key, the halved arrays
+    assert 0.65 < (w2 - w).std() / (w1 - w).std() < 0.76                                    # sqrt(1/2) of the amplitude
 
 
 VIB_CASES = {
