@@ -31,7 +31,8 @@ The JSON line (rank 0) also carries, measured in the same process after the time
                        launch from rocprofv3 PMC passes (WRITE_SIZE, FETCH_SIZE x 2 on gfx950) run live on this build,
                        or from profiles/pmc_traffic.json when that file carries this build's library hash, else null
   configs[]            the other BASELINE configurations as legs: C3 (long_drive @200 Hz, 262 144 runs, stats-only),
-                       C4's per-GPU share, C5 fp32, Allan end-to-end (3600 s @ 400 Hz) and the mechanisation alone
+                       C4's per-GPU share, C5 fp32, Allan end-to-end (3600 s @ 400 Hz), the mechanisation alone, and C2 in a
+                       vibration environment (random; PSD arrays)
   cpu_baseline         the C port of the same path on the host cores (bounded sample) + the reference's own Python
                        path (timed here when /root/reference is importable, otherwise the BASELINE.md figure, labelled)
 Inputs (truth, parameters) are resident in HBM before every timed region.
@@ -300,7 +301,7 @@ def cut_truth(truth, n):
 
 
 def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precision, reps, gps=False, pmc=None, traffic=None,
-           cut=None, valu_too=False, **job_kw):
+           cut=None, valu_too=False, read_bytes_per_unit=0, **job_kw):
     ini, truth, _ = workloads.truth_from_profile(profile, fs, rf, fs_gps=10.0 if gps else 0.0, gps=gps)
     if cut:
         truth = cut_truth(truth, cut)
@@ -312,7 +313,7 @@ def leg_mc(ginsim, workloads, ctx, name, desc, profile, fs, rf, R, keep, precisi
     placed = job.placement() if keep else None
     avg, mn = time_launches(ctx, job.launch, reps, warm=2 if reps > 2 else 0)
     st = job.stats('free')
-    unit = (BYTES_PER_SAMPLE_MC if precision == 'f64' else BYTES_PER_SAMPLE_MC // 2) if keep else 0
+    unit = ((BYTES_PER_SAMPLE_MC if precision == 'f64' else BYTES_PER_SAMPLE_MC // 2) if keep else 0) + read_bytes_per_unit
     alg = unit * R * n + 72 * R
     kname = job.kernel_name()
     if keep:
@@ -935,6 +936,16 @@ def main():
                                'gyro: [0.5 0.5 0.5]d-random}): the vibration variant of the wave-specialised kernel (round 5; round 4: the plain kernel, one wavefront per SIMD)', 'turn_90deg',
                                100.0, 1, 65536, True, 'f64', 10,
                                pmc=pmc, valu_too=True, **VIB_LEG))
+            # Sim(env=<(n, 4) PSD array>) (ABI 8): the series of both sensors are made before the launch (ginsim_vib_psd_series) and
+            # read by it: 120 B written + 48 B read per sample*MC
+            import numpy as np
+            psd_f = np.array([0.0, 8.0, 11.0, 13.0, 16.0, 50.0])
+            psd = lambda u: {'type': 'psd', 'freq': psd_f, 'x': u * np.array([1e-4, 1e-4, 2e-2, 2e-2, 1e-4, 1e-4]),
+                             'y': u * np.full(6, 1e-3), 'z': u * np.full(6, 2e-3)}
+            legs.append(leg_mc(ginsim, workloads, ctx, 'C2_vibration_psd', 'the C2 launch with Sim(env={acc: PSD array, gyro: PSD array}): '
+                               'the vibration variant of the plain kernel reading the six series planes made by ginsim_vib_psd_series '
+                               '(120 B written + 48 B read per sample*MC)', 'turn_90deg', 100.0, 1, 65536, True, 'f64', 10,
+                               read_bytes_per_unit=48, vib_accel=psd(1.0), vib_gyro=psd(1e-4)))
             legs.append(leg_allan(ginsim, workloads, ctx, pmc=pmc))
             legs.append(leg_sim_e2e(workloads))
             out['configs'] = legs

@@ -1,6 +1,7 @@
 // C ABI of libginsim.so (declared in include/ginsim.h): context handling, argument validation, error
 // reporting and the host-buffer convenience entry points.  No kernels here.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <cmath>
 #include <cstdarg>
@@ -542,6 +543,25 @@ int ginsim_comm_init(ginsim_ctx* c, int32_t nranks, int32_t rank, const unsigned
 int ginsim_comm_probe(void) {
     const char* err = comm_probe();
     if (err) { set_error("comm_probe: %s", err); return GINSIM_ERR_HIP; }
+    return GINSIM_OK;
+}
+
+// where the FIRST workgroup of a launch on this context's stream lands: the accelerator complex die (XCD) of an MI300 / MI355X
+__global__ void first_xcc_kernel(uint32_t* out) {
+    if (threadIdx.x == 0) out[0] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;      // HW_REG_XCC_ID, bits 3:0
+}
+
+int ginsim_stream_first_xcc(ginsim_ctx* c, int32_t* xcc) {
+    REQUIRE(c && xcc, "stream_first_xcc: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    void* ws = nullptr;
+    HIP_TRY(scratch(c, 2, 64, &ws));
+    hipLaunchKernelGGL(first_xcc_kernel, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<uint32_t*>(ws));
+    HIP_TRY(hipGetLastError());
+    uint32_t v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, ws, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *xcc = (int32_t)v;
     return GINSIM_OK;
 }
 

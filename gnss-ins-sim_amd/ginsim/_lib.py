@@ -101,6 +101,7 @@ _SIGS = {
     'ginsim_last_error': (C.c_char_p, []),
     'ginsim_device_count': (C.c_int, [C.POINTER(C.c_int)]),
     'ginsim_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    'ginsim_stream_first_xcc': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     'ginsim_destroy': (C.c_int, [C.c_void_p]),
     'ginsim_device_name': (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     'ginsim_mem_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -163,6 +163,12 @@ class Context(object):
             return False
         return True
 
+    def first_xcc(self):
+        """The XCD on which the first workgroup of a launch on this context's stream lands (ginsim_stream_first_xcc)."""
+        v = C.c_int32(-1)
+        check(lib.ginsim_stream_first_xcc(self.handle, C.byref(v)))
+        return int(v.value)
+
     def placed_info(self):
         """ginsim_placed_info of the device's arena as a dict (sizes in bytes, times in seconds)."""
         i = _lib.PlacedInfo()

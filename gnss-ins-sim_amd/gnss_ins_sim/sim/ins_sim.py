@@ -285,13 +285,48 @@ class Sim(object):
 
     _SIBLINGS = {}          # device -> a second context (its own stream) for launches that run next to the main one
 
-    def _sibling_context(self, ctx):
+    def _block_and_rest_contexts(self, ctx, rest_workgroups):
+        """(context of the one-workgroup launch of the kept runs, context of the statistics launch over the others): `ctx` and a
+        sibling context of the same device, which way round decided by where their launches START.
+        The dispatcher deals the workgroups of a launch to the eight XCDs of an MI355X in turn, starting at a die that belongs to the
+        stream's hardware queue (ginsim_stream_first_xcc; consecutive for streams made one after the other, shifted by every stream
+        any library of the process made in between -- the FFT plans of a PSD vibration, say).  A statistics launch of W workgroups on
+        8 x 64 slots leaves a slot to spare on die (first + W) mod 8 when W is not a multiple of 8; the kept runs' workgroup on THAT
+        die costs nothing (C3: 0.93 s for the pair), on any other die it costs its die a third round of workgroups (1.20 s;
+        tools/experiments/c3_pair_matrix.py: 24 of 24 pairs as this rule says)."""
         import ginsim
-        side = Sim._SIBLINGS.get(ctx.device)
-        if side is None or side.handle is None or side is ctx:
-            side = Sim._SIBLINGS[ctx.device] = ginsim.Context(ctx.device)
+        want = int(rest_workgroups) % 8
+        hit = Sim._SIBLINGS.get(ctx.device)
+        if hit is not None and hit['of'] == ctx.handle and hit['want'] == want and hit['side'].handle is not None:
+            self._side_ctx = hit['side']
+            return hit['pair']
+        # Candidates first, questions afterwards: the dies move while the runtime is still making its hardware queues (four by
+        # default: a fresh process answers 0 for every stream, then 0 / 7 / 6 / 5 ... as the queues come; with all of them there
+        # the answers stay).  The candidates that are not taken stay alive -- closing streams could give queues back.
+        spare = hit['spare'] + [hit['side']] if hit is not None and hit['of'] == ctx.handle else []
+        spare = [c for c in spare if c.handle is not None and c is not ctx]
+        while len(spare) < 5:
+            spare.append(ginsim.Context(ctx.device))
+        for c in spare:
+            c.first_xcc()
+        mine = ctx.first_xcc()
+        pair = side = None
+        for c in spare:
+            theirs = c.first_xcc()
+            if theirs == (mine + want) % 8:
+                pair = (c, ctx)             # the kept runs on the sibling
+            elif mine == (theirs + want) % 8:
+                pair = (ctx, c)             # the kept runs here, the statistics launch on the sibling
+            if pair is not None:
+                side = c
+                break
+        if pair is None:                    # no such pair among the queues: any sibling (one more round of workgroups on one die)
+            side = spare[0]
+            pair = (side, ctx)
+        spare = [c for c in spare if c is not side]
+        Sim._SIBLINGS[ctx.device] = {'of': ctx.handle, 'want': want, 'side': side, 'pair': pair, 'spare': spare}
         self._side_ctx = side
-        return side
+        return pair
 
     @staticmethod
     def _dist():
@@ -464,11 +499,8 @@ class Sim(object):
                 ride = (0 < kcount <= KEPT_BLOCK < count and f64 and group is None and not spread and
                         per_sample * n * KEPT_BLOCK <= self.max_device_bytes)
                 if ride:
-                    # The two launches only overlap for free when the block's stream is the OLDER one (measured: block on the
-                    # context created first 0.99 s for C3, on the one created second 1.30 s -- tools/experiments/
-                    # kept_block_overlap2.py), so the block goes to whichever of the two contexts was created first
-                    side = self._sibling_context(ctx)
-                    c_block, c_rest = (side, ctx) if side.serial < ctx.serial else (ctx, side)
+                    # which of the two contexts takes which launch: by where their launches start (_block_and_rest_contexts)
+                    c_block, c_rest = self._block_and_rest_contexts(ctx, -(-(count - KEPT_BLOCK) // KEPT_BLOCK))
                     per_launch = [[k] for k in g['kinds']] if online else [list(g['kinds'])]
                     for kinds_ in per_launch:
                         kw = dict(proc_first=sample_of(self.stats_start)) if online else {}

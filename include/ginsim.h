@@ -41,6 +41,13 @@ int         ginsim_abi_version(void);
 const char* ginsim_last_error(void);
 int  ginsim_device_count(int* count);
 int  ginsim_create(int device, ginsim_ctx** out);
+/* ABI 8: the XCD (accelerator complex die, 0 .. 7 on an MI355X) on which the FIRST workgroup of a launch on this context's stream
+ * lands.  The dispatcher deals the workgroups of a launch to the XCDs in turn, starting at a die that belongs to the stream's
+ * hardware queue (measured: the same for every launch of a stream, consecutive for streams made one after the other).  Two launches
+ * that are to run side by side without costing each other a round of workgroups must fit TOGETHER into whole rounds on every die:
+ * the drop-in Sim runs the few runs it keeps as ONE workgroup next to the statistics launch over all the others (1023 workgroups on
+ * 8 x 64 slots: one die has a slot to spare) and picks the pair of contexts that puts that workgroup on that die. */
+int  ginsim_stream_first_xcc(ginsim_ctx* ctx, int32_t* xcc);
 int  ginsim_destroy(ginsim_ctx* ctx);
 int  ginsim_device_name(ginsim_ctx* ctx, char* buf, size_t cap);
 int  ginsim_mem_info(ginsim_ctx* ctx, size_t* free_bytes, size_t* total_bytes);   /* ABI 6: hipMemGetInfo of the context's device */

@@ -244,3 +244,32 @@ def test_printed_summary_is_the_reference_text(tag, start, opt):
                 continue
             fa = float(a)
             assert abs(fa - fb) <= 2e-6 * abs(fb) + 1e-12, (lo, lw)
+
+
+def test_kept_runs_and_statistics_launch_start_on_the_dies_that_fit(capsys):
+    """Sim(keep_runs=K) on a statistics-only batch runs the kept runs as one workgroup on a sibling context next to the statistics
+    launch over the others.  The dispatcher deals a launch's workgroups to the XCDs in turn from a die that belongs to the stream's
+    hardware queue (ginsim_stream_first_xcc): W statistics workgroups leave their spare slot on die (first + W) mod 8, and the
+    kept runs' workgroup must land THERE (C3: 0.93 s for the pair, 1.20 s on any other die).  The pair the Sim settles on obeys
+    that, also after another library of the process has made streams of its own (here: a PSD vibration's FFT plans)."""
+    import ginsim
+    from ginsim import workloads
+    from gnss_ins_sim.sim import ins_sim
+    ctx = ginsim.default_context()
+    assert 0 <= ctx.first_xcc() <= 7 and ctx.first_xcc() == ctx.first_xcc()
+    f = np.array([0.0, 8.0, 20.0, 50.0])
+    v = {'type': 'psd', 'freq': f, 'x': np.full(4, 1e-3), 'y': np.full(4, 1e-3), 'z': np.full(4, 2e-3)}
+    ini, truth, _ = workloads.truth_from_profile('turn_90deg', 100.0, 1)
+    acc, gyr = workloads.imu_grade('mid-accuracy')
+    ginsim.MonteCarloJob(ctx, 100.0, 1, truth, acc, gyr, ini, runs=256, seed=3, keep_sensors=True, vib_accel=v).run().release()
+    sim = ins_sim.Sim.__new__(ins_sim.Sim)
+    sim._side_ctx = None
+    for w in (1023, 1023, 511, 5):
+        blk, rest = sim._block_and_rest_contexts(ctx, w)
+        assert (blk is ctx) != (rest is ctx) and blk.device == rest.device == ctx.device
+        xs = sorted({c.first_xcc() for c in [ctx] + ins_sim.Sim._SIBLINGS[ctx.device]['spare'] + [sim._side_ctx]})
+        fits = blk.first_xcc() == (rest.first_xcc() + w) % 8
+        possible = any(a == (b + w) % 8 for a in xs for b in xs if a != b)
+        assert fits or not possible, (w, blk.first_xcc(), rest.first_xcc(), xs)
+        assert fits or w == 5, (w, xs)          # four hardware queues on consecutive dies: +1 / -1 always exist, +5 need not
+    capsys.readouterr()
