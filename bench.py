@@ -581,8 +581,15 @@ def main():
     acc, gyr = workloads.imu_grade('mid-accuracy')
     n = truth['ref_accel'].shape[0]
     keep = not args.stats_only
-    job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, algos=('free',), seed=SEED,
-                               keep_sensors=keep, keep_traj=keep, precision=args.precision)
+    job = None
+    for turn in range(world if (args.shared_device and world > 1) else 1):
+        # (TEST ONLY, --shared-device: the ranks build their arenas on the one GPU in turn -- two searches at once on ONE device
+        # disturb each other's probe timings; with a GPU per rank every rank searches its own at the same time)
+        if not (args.shared_device and world > 1) or turn == rank:
+            job = ginsim.MonteCarloJob(ctx, fs, rf, truth, acc, gyr, ini, runs=R, algos=('free',), seed=SEED,
+                                       keep_sensors=keep, keep_traj=keep, precision=args.precision)
+        if args.shared_device and world > 1:
+            dist.barrier()
     unit_bytes = BYTES_PER_SAMPLE_MC if args.precision == 'f64' else BYTES_PER_SAMPLE_MC // 2
     placement = job.placement() if keep else None           # the arena was built (one search) inside the constructor: set-up
     group = dist.group.WORLD if use_dist else None

@@ -320,8 +320,9 @@ class Sim(object):
             if pair is not None:
                 side = c
                 break
-        if pair is None:                    # no such pair among the queues: any sibling (one more round of workgroups on one die)
-            side = spare[0]
+        if pair is None:                    # no such pair among the queues: a sibling on ANOTHER die at least (the same die = the same
+            other = [c for c in spare if c.first_xcc() != mine]         # hardware queue: the two launches one after the other);
+            side = (other or spare)[0]                                  # it costs one die one more round of workgroups
             pair = (side, ctx)
         spare = [c for c in spare if c is not side]
         Sim._SIBLINGS[ctx.device] = {'of': ctx.handle, 'want': want, 'side': side, 'pair': pair, 'spare': spare}
