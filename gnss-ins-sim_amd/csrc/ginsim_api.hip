@@ -43,7 +43,7 @@ hipError_t launch_aux(const ginsim_aux_params& p, hipStream_t s);
 size_t vib_psd_scratch_bytes(int64_t period, int64_t runs);
 int launch_vib_psd(int device, hipStream_t stream, const double* amp, int64_t period, int64_t runs, uint64_t run_offset, uint64_t seed,
                    int sensor, int halve, void* scratch, double* out);
-void vib_psd_drop_plans(int device);
+void vib_psd_drop_plans(hipStream_t stream);
 hipError_t launch_rng_probe(uint64_t seed, uint64_t run, uint32_t stream, int64_t count, double* z0, double* z1,
                             uint32_t* words, hipStream_t stream_h);
 hipError_t launch_aos_to_soa(const double* src, double* dst, int64_t R, int64_t n, int C, hipStream_t s);
@@ -189,7 +189,7 @@ int ginsim_destroy(ginsim_ctx* c) {
     if (c->comm_host) (void)hipHostFree(c->comm_host);
     for (hipEvent_t e : c->comm_ev)
         if (e) (void)hipEventDestroy(e);
-    ginsim::vib_psd_drop_plans(c->device);            // hipFFT plans of the PSD vibration (rebuilt on demand)
+    ginsim::vib_psd_drop_plans(c->stream);            // this stream's hipFFT plans of the PSD vibration (it is idle now)
     (void)hipStreamDestroy(c->stream);
     ginsim::placed_free_owner(c->device, c);          // regions this context carved and never freed go back to the free list
     ginsim::placed_context_destroyed(c->device);      // the device's last context gives its placed arena back

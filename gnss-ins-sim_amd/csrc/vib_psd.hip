@@ -89,7 +89,9 @@ struct Fft {
 };
 Fft g_fft;
 std::mutex g_mu;
-std::map<std::pair<int, std::pair<int64_t, int64_t>>, fft_handle> g_plans;      // (device, (N, batch)) -> plan
+// (stream, (N, batch)) -> plan.  Per STREAM: a plan owns its work buffer, and two contexts of a process (the two launches of a Sim
+// that keeps a few runs) make their series at the same time
+std::map<std::pair<hipStream_t, std::pair<int64_t, int64_t>>, fft_handle> g_plans;
 
 bool load_fft() {
     if (g_fft.tried) return g_fft.lib != nullptr;
@@ -151,13 +153,13 @@ int launch_vib_psd(int device, hipStream_t stream, const double* amp, int64_t pe
             hipLaunchKernelGGL((psd_spectrum_kernel<S_GYR_VIB_XY>), grid, dim3(256), 0, stream, amp_d, L, nb, run_offset + (uint64_t)r0, seed, halve, X);
         e = hipGetLastError();
         if (e != hipSuccess) { set_error("vib_psd_series: %s", hipGetErrorString(e)); return GINSIM_ERR_HIP; }
-        fft_handle& plan = g_plans[{device, {period, nb}}];
+        fft_handle& plan = g_plans[{stream, {period, nb}}];
         if (!plan) {
             int n1 = (int)period;
             const int rc = g_fft.plan_many(&plan, 1, &n1, nullptr, 1, 0, nullptr, 1, 0, kFftZ2D, (int)(nb * 3));
             if (rc != 0) {
                 plan = nullptr;
-                g_plans.erase({device, {period, nb}});
+                g_plans.erase({stream, {period, nb}});
                 set_error("vib_psd_series: hipfftPlanMany(%lld points, %lld series) failed with %d", (long long)period, (long long)(nb * 3), rc);
                 return rc == 2 ? GINSIM_ERR_NOMEM : GINSIM_ERR_HIP;            // HIPFFT_ALLOC_FAILED
             }
@@ -173,11 +175,11 @@ int launch_vib_psd(int device, hipStream_t stream, const double* amp, int64_t pe
     return GINSIM_OK;
 }
 
-// the plans of a device go with its last context
-void vib_psd_drop_plans(int device) {
+// the plans of a context's stream go with the context (its stream is idle by then)
+void vib_psd_drop_plans(hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto it = g_plans.begin(); it != g_plans.end();) {
-        if (it->first.first == device) {
+        if (it->first.first == stream) {
             if (it->second && g_fft.destroy) (void)g_fft.destroy(it->second);
             it = g_plans.erase(it);
         } else {
