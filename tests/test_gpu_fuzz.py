@@ -131,6 +131,60 @@ def test_random_configuration_against_the_c_oracle(ctx, i):
     job.release()
 
 
+@pytest.mark.parametrize('i', range(80, 96))
+def test_random_psd_vibration_against_the_numpy_oracle(ctx, i):
+    """Sim(env=<PSD array>) (ABI 8): random PSDs -- a few rows to interpolate, rows beyond fs / 2 (the reference then returns zeros:
+    time_series_from_psd.py:32-34), or a PSD GIVEN on the series' own grid (halved in place by the reference at every run, so run g
+    sees 0.5^(g + 1): nothing is left of it at a run offset of 2^40) -- on the random profiles, IMU models and run offsets of this
+    file, odd and even series lengths: sensors per sample against the NumPy restatement of time_series_from_psd (np.fft.ifft, as the
+    reference; the goldens pin it), trajectories against its mechanisation."""
+    import ginsim
+    from oracle import ins_np
+    c = _random_case(i)
+    rng = np.random.RandomState(9000 + i)
+    n, fs = c['truth']['ref_accel'].shape[0], c['fs']
+
+    def psd(scale):
+        kind = rng.randint(0, 4)
+        if kind == 0:
+            return None
+        if kind == 3:                   # on the grid of this series
+            L = min(n + n % 2, 16384) // 2 + 1
+            f = np.linspace(0.0, fs / 2.0, L)
+        else:
+            f = np.sort(rng.uniform(0.0, (0.5 if kind == 1 else 0.7) * fs, rng.randint(2, 9)))
+        return {'type': 'psd', 'freq': f, 'x': scale * rng.uniform(0, 1, f.shape), 'y': scale * rng.uniform(0, 1, f.shape), 'z': scale * rng.uniform(0, 1, f.shape)}
+    va, vg = psd(1e-2), psd(1e-6)
+    R, off = min(c['runs'], 70), c['off']
+    kw = dict(algos=c['algos'], odo_err=c['odo_err'], earth_rot=c['earth_rot'], seed=c['seed'], vib_accel=va, vib_gyro=vg)
+    job = ginsim.MonteCarloJob(ctx, fs, c['rf'], c['truth'], c['acc'], c['gyr'], c['ini'], runs=R, run_offset=off, keep_sensors=True,
+                               keep_traj=True, **kw).run()
+    ids = np.unique([0, R // 2, R - 1])
+    a_ref, g_ref = ins_np.mc_sensors(c['seed'], off + ids, fs, c['truth']['ref_accel'], c['truth']['ref_gyro'], c['acc'], c['gyr'], va, vg)
+    np.testing.assert_allclose(job.sensors('accel', ids), a_ref, rtol=0, atol=2e-12, err_msg='case %d accel' % i)
+    np.testing.assert_allclose(job.sensors('gyro', ids), g_ref, rtol=0, atol=2e-14, err_msg='case %d gyro' % i)
+    for v, sensor, ref in ((va, 'accel', a_ref), (vg, 'gyro', g_ref)):
+        if v is not None and ginsim.psd_amplitudes(v, fs, n) is None:          # beyond fs / 2: the launch without an environment
+            plain = ins_np.mc_sensors(c['seed'], off + ids, fs, c['truth']['ref_accel'], c['truth']['ref_gyro'], c['acc'], c['gyr'])[sensor == 'gyro']
+            assert np.array_equal(ref, plain)
+    odo = ins_np.mc_odo(c['seed'], off + ids, c['truth']['ref_odo'], c['odo_err']) if 'odo' in c['algos'] else None
+    for a in c['algos']:
+        att, pos, vel = ins_np.free_integration(c['rf'], fs, g_ref, a_ref, c['ini'], odo=odo if a == 'odo' else None, earth_rot=c['earth_rot'])
+        got = job.trajectories(a, ids)
+        for k in range(len(ids)):
+            near = np.where(np.abs(np.cos(att[k, :, 1])) < 0.02)[0]
+            upto = int(near[0]) if near.size else n
+            if upto < 2:
+                continue
+            tol = 1e-9 * max(1.0, n / 1000.0)
+            d = np.mod(got[0][k, :upto] - att[k, :upto] + np.pi, 2 * np.pi) - np.pi
+            assert np.abs(d).max() < tol, 'case %d %s run %d attitude %.3e' % (i, a, ids[k], np.abs(d).max())
+            ref = np.concatenate([pos[k, :upto], vel[k, :upto]], axis=1)
+            err = np.abs(np.concatenate([got[1][k, :upto], got[2][k, :upto]], axis=1) - ref) / np.maximum(1.0, np.abs(ref))
+            assert err.max() < tol, 'case %d %s run %d pos/vel %.3e' % (i, a, ids[k], err.max())
+    job.release()
+
+
 @pytest.mark.parametrize('i', range(40, 52))
 def test_random_configuration_fp32_against_the_float_oracle(ctx, i):
     """The same generator through the single-precision kernels: bit for bit against the float restatement."""
