@@ -270,6 +270,15 @@ int grow(Arena& a, size_t add) {
     };
     for (size_t i = 0; i < budget; ++i) {
         if (a.nref == 3 && usable(3) >= add) break;                         // every class can give its third
+        if (now_s() - t0 > a.opt.search_seconds / 3.0) {
+            // A third of the time is gone and the driver keeps handing out chunks of two classes: two classes IN BALANCE (none gives
+            // more than three fifths) will do.  The fused kernels are as fast on them as on three (C2's launch: 0.804 / 0.807 on
+            // 8 + 7 stripes of two classes, 0.799-0.805 on 5 + 5 + 5 in the other processes of the same box,
+            // profiles/r06_placement_reliability.json box 4) -- only the bare store pattern gains from the third class.
+            size_t tk[3];
+            const size_t have[3] = {of[0].size(), of[1].size(), of[2].size()};
+            if (placed::plan(add, have, tk) && 5 * std::max({tk[0], tk[1], tk[2]}) <= 3 * add) break;
+        }
         if (now_s() - t0 > a.opt.search_seconds) {                          // out of time: settle for an uneven deal if there is one
             size_t tk[3];
             const size_t have[3] = {of[0].size(), of[1].size(), of[2].size()};

@@ -73,7 +73,8 @@ typedef struct {
     int64_t stripe_bytes;       /* 0: 512 MiB.  A power of two >= 64 MiB (below 512 MiB a chunk no longer lies in ONE class) */
     int64_t budget_bytes;       /* 0: 200 GiB.  Most physical memory one search may hold while it looks for the classes */
     int64_t limit_bytes;        /* 0: a third of the device memory.  The arena never maps more than this */
-    double  search_seconds;     /* 0: 3 s.  A search settles for the classes it has after this long */
+    double  search_seconds;     /* 0: 3 s.  A search settles for the classes it has after this long; after a third of it for two
+                                 * classes in balance (none gives more than three fifths of the stripes) */
 } ginsim_placed_options;
 
 typedef struct {
