@@ -305,7 +305,11 @@ class Sim(object):
         # the answers stay).  The candidates that are not taken stay alive -- closing streams could give queues back.
         spare = hit['spare'] + [hit['side']] if hit is not None and hit['of'] == ctx.handle else []
         spare = [c for c in spare if c.handle is not None and c is not ctx]
-        while len(spare) < 5:
+        try:                                # one more stream than the runtime has hardware queues: all of them exist afterwards
+            want_spare = 1 + max(1, int(os.environ.get('GPU_MAX_HW_QUEUES', '4')))
+        except ValueError:
+            want_spare = 5
+        while len(spare) < want_spare:
             spare.append(ginsim.Context(ctx.device))
         for c in spare:
             c.first_xcc()
