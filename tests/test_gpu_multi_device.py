@@ -192,6 +192,32 @@ def test_sim_devices_equals_sim_on_one_context(tmp_path, capsys):
     _compare_sims(two, one, 300, tmp_path, capsys)
 
 
+def test_sim_devices_with_a_psd_environment(capsys):
+    """Sim(env=<PSD arrays>, devices=[0, 0]) (ABI 8): every context makes the vibration series of ITS runs (phases by the global run
+    id, an FFT plan of its own per stream) -- the same sensors and trajectories as the plain Sim to rounding (the series of a run
+    come out of FFT batches of other sizes), the gyroscope's PSD given on the series' grid and therefore halved per global run."""
+    n = 1000
+    f = np.linspace(0.0, 50.0, n // 2 + 1)
+    def env():
+        g = 1e-6 * (1.0 + np.cos(f / 7.0) ** 2)
+        return {'acc': np.array([[0.0, 1e-3, 2e-3, 1e-3], [12.0, 4e-3, 1e-3, 2e-3], [45.0, 1e-3, 1e-3, 1e-3]]), 'gyro': np.stack([f, g, 0.5 * g, 2.0 * g], axis=1)}
+    e1, e2 = env(), env()
+    one = _sim(None, runs=200, keep=True, env=e1)
+    two = _sim([0, 0], runs=200, keep=True, env=e2)
+    assert two.mc.devices == [0, 0]
+    np.testing.assert_array_equal(e1['gyro'], e2['gyro'])              # both left the caller's array as the reference does: halved 200 times
+    assert e1['gyro'][5, 1] == 0.0 or e1['gyro'][5, 1] < 1e-60 and e1['gyro'][0, 1] == env()['gyro'][0, 1]
+    for r in (0, 99, 100, 199):
+        for name, tol in (('accel', 1e-13), ('gyro', 1e-15), ('odo', 0.0)):
+            np.testing.assert_allclose(getattr(two.dmgr, name).data[r], getattr(one.dmgr, name).data[r], rtol=0, atol=tol)
+        for name, tol in (('vel', 1e-10), ('att_euler', 1e-11)):
+            for algo in ('algo0', 'algo1'):
+                np.testing.assert_allclose(getattr(two.dmgr, name).data['%s_%d' % (algo, r)], getattr(one.dmgr, name).data['%s_%d' % (algo, r)], rtol=0, atol=tol)
+    plain = _sim(None, runs=200, keep=True)
+    assert np.abs(one.dmgr.accel.data[3] - plain.dmgr.accel.data[3]).std() > 0.05        # the environment is there
+    capsys.readouterr()
+
+
 def test_sim_devices_writes_the_same_files(tmp_path, capsys):
     """results(data_dir) of a Sim spread over two contexts: the CSV files of the saved runs and the summary are byte-identical
     to the single-context Sim's (Sim_data.save_to_file, sim_data.py:117-165; the views route every run to the device that holds it)."""
