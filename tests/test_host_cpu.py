@@ -24,6 +24,15 @@ def test_library_exports_every_declared_symbol():
     assert ginsim.lib.ginsim_abi_version() == 8
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/ginsim.h is the C ABI: it must compile as C99 on its own (what a cgo / JNI / ctypes-generator user feeds it to)."""
+    import subprocess
+    src = tmp_path / 'h.c'
+    src.write_text('#include "ginsim.h"\nint main(void) { return GINSIM_ABI_VERSION == 8 ? 0 : 1; }\n')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I' + os.path.join(REPO, 'include'), '-fsyntax-only', str(src)],
+                   check=True, timeout=120)
+
+
 def test_no_gpu_fails_loudly():
     import ginsim
     if ginsim.device_count() > 0:
