@@ -141,13 +141,13 @@ def vec_str(a, fast=True):
             pl, pr, es = max(pl, len(ip)), max(pr, len(fpart)), max(es, len(ex) - 1)
         out = [fs(v, precision=pr, min_digits=pr, unique=True, trim='k', sign=False, pad_left=pl, exp_digits=es) for v in vals]
     else:
+        # one dragon4 call per value: the second pass of numpy's printer writes the same digits again and only pads them -- the
+        # integer part to the common width on the left, the fraction on the right (the point stays: trim='.')
         fp = np.format_float_positional
-        pl = pr = 0
-        for v in vals:
-            ip, _, fpart = fp(v, precision=8, fractional=True, unique=True, trim='.', sign=False).partition('.')
-            pl, pr = max(pl, len(ip)), max(pr, len(fpart))
-        out = [fp(v, precision=8, min_digits=0, unique=True, fractional=True, trim='.', sign=False, pad_left=pl, pad_right=pr)
-               for v in vals]
+        parts = [fp(v, precision=8, fractional=True, unique=True, trim='.', sign=False).partition('.') for v in vals]
+        pl = max(len(q[0]) for q in parts)
+        pr = max(len(q[2]) for q in parts)
+        out = [q[0].rjust(pl) + '.' + q[2].ljust(pr) for q in parts]
     return '[' + ' '.join(out) + ']'
 
 
