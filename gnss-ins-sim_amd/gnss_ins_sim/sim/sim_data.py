@@ -132,17 +132,21 @@ def vec_str(a, fast=True):
     if nz:
         mx, mn = max(nz), min(nz)
         exp = mx >= 1.e8 or mn < 0.0001 or mx / mn > 1000.
+    # one dragon4 call per value: the second pass of numpy's printer writes the same digits again and only pads them
     if exp:
+        # ... the integer part to the common width on the left, the fraction with zeros and the exponent's digits with leading zeros
         fs = np.format_float_scientific
-        pl = pr = es = 0
+        parts = []
         for v in vals:
             fr, _, ex = fs(v, precision=8, unique=True, trim='.', sign=False).partition('e')
             ip, _, fpart = fr.partition('.')
-            pl, pr, es = max(pl, len(ip)), max(pr, len(fpart)), max(es, len(ex) - 1)
-        out = [fs(v, precision=pr, min_digits=pr, unique=True, trim='k', sign=False, pad_left=pl, exp_digits=es) for v in vals]
+            parts.append((ip, fpart, ex))
+        pl = max(len(q[0]) for q in parts)
+        pr = max(len(q[1]) for q in parts)
+        es = max(len(q[2]) - 1 for q in parts)
+        out = [q[0].rjust(pl) + '.' + q[1].ljust(pr, '0') + 'e' + q[2][0] + q[2][1:].rjust(es, '0') for q in parts]
     else:
-        # one dragon4 call per value: the second pass of numpy's printer writes the same digits again and only pads them -- the
-        # integer part to the common width on the left, the fraction on the right (the point stays: trim='.')
+        # ... the integer part to the common width on the left, the fraction with blanks on the right (the point stays: trim='.')
         fp = np.format_float_positional
         parts = [fp(v, precision=8, fractional=True, unique=True, trim='.', sign=False).partition('.') for v in vals]
         pl = max(len(q[0]) for q in parts)

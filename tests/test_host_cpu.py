@@ -374,7 +374,10 @@ def test_summary_vector_text_equals_numpy_str():
               np.array([9.99999999e7, 1, 1]), np.array([1e8, 1, 1]), np.array([-0.0, 1.0, 2.0]), np.array([1e-5, 0, 0]),
               np.array([123456789.123, 0, 0]), np.array([0.1, 100.0, 0.1]), np.array([0.1, 100.1, 0.1]),
               np.array([1.0, 1000.0, 1.0]), np.array([1.0, 1000.1, 1.0]), np.array([2.5]), np.array([1.0, -2.0]),
-              np.array([np.nan, 1.0, 2.0]), np.array([np.inf, 1.0, -2.0]), np.arange(6.0), np.array([1, 2, 3])]
+              np.array([np.nan, 1.0, 2.0]), np.array([np.inf, 1.0, -2.0]), np.arange(6.0), np.array([1, 2, 3]),
+              # three-digit exponents next to two-digit ones, zeros of both signs in the exponent form, one element
+              np.array([1e-300, 1.0, 2.0]), np.array([1e100, 1e-100, 3.0]), np.array([1.5e-5, 0.0, -0.0]), np.array([-2.5e-7]),
+              np.array([1.23456789e-5, -1e-5, 1e-5]), np.array([5e-324, 1.0, 1.0]), np.array([1.7976931348623157e308, 1.0, -1.0])]
     # vectors of 4-8 elements can exceed numpy's line width and are wrapped by str(); the fast writer does not
     # wrap, so they must take the str() path -- long values of every size that would not fit one line
     for size in range(4, 9):
