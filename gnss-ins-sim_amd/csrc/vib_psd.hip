@@ -132,7 +132,8 @@ int launch_vib_psd(int device, hipStream_t stream, const double* amp, int64_t pe
                    int sensor, int halve, void* scratch, double* out) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!load_fft()) {
-        set_error("vib_psd_series: libhipfft.so could not be loaded (%s): the PSD vibration needs hipFFT", dlerror() ? dlerror() : "symbols missing");
+        const char* why = dlerror();            // (reading it clears it)
+        set_error("vib_psd_series: libhipfft.so could not be loaded (%s): the PSD vibration needs hipFFT", why ? why : "symbols missing");
         return GINSIM_ERR_HIP;
     }
     const int64_t L = period / 2 + 1, block = vib_psd_block_runs(period, runs);
